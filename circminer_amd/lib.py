@@ -1,0 +1,291 @@
+"""ctypes mirror of include/circminer_hot.h and the loader of the product library.
+
+The product library (``circminer_amd/csrc/libcmhot.so``) is hand-written HIP for gfx950 behind a
+C-ABI; this module only declares the structs / prototypes and never computes anything itself.
+There is no CPU fallback: if the library is missing or no HIP device is present the calls fail.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libcmhot.so")
+
+CM_BESTCHAINLIM = 30
+CM_MAX_CHAIN_FRAGS = 16
+CM_CONTIG_SIZE = 1_100_000_000
+
+CAT = dict(CONCRD=0, DISCRD=1, CHIORF=2, CHIBSJ=3, CHI2BSJ=4, CONGEN=5, CHIFUS=6, CONGNM=7, OEA2=8,
+           CANDID=9, OEANCH=10, ORPHAN=11, NOPROC_MANYHIT=12, NOPROC_NOMATCH=13)
+
+u8p, u16p, u32p, u64p, i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_int32))
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kmer", "seed_lim", "max_read_len", "scan_level", "max_ed", "max_sc", "band",
+                                         "max_tlen", "max_intron", "max_chain_len", "device", "reserved")]
+
+
+def default_params(**kw) -> Params:
+    """Defaults of reference src/commandline_parser.cpp:7-33 / src/common.h:39-53."""
+    d = dict(kmer=20, seed_lim=500, max_read_len=300, scan_level=0, max_ed=4, max_sc=7, band=3, max_tlen=500,
+             max_intron=2_000_000, max_chain_len=30, device=0, reserved=0)
+    d.update(kw)
+    return Params(**d)
+
+
+class IndexView(C.Structure):
+    _fields_ = [("contig_num", C.c_int32), ("ref_len", C.c_uint32), ("genome", u8p), ("bucket_off", u32p),
+                ("checksum", u16p), ("pos", u32p), ("n_entries", C.c_uint64)]
+
+
+class AnnotView(C.Structure):
+    _fields_ = [("n_iv", C.c_uint32), ("iv_spos", u32p), ("iv_epos", u32p), ("iv_max_end", u32p), ("iv_min_end", u32p),
+                ("iv_max_next_exon", u32p), ("iv_seg_off", u32p), ("iv_seg", u32p),
+                ("n_seg", C.c_uint32), ("seg_start", u32p), ("seg_end", u32p), ("seg_next_exon_beg", u32p),
+                ("seg_gene_id", u32p), ("seg_tid_off", u32p), ("seg_tid", u32p),
+                ("n_trans", C.c_uint32), ("trans_start_ind", i32p), ("t2s_off", u32p), ("t2s", u8p),
+                ("n_gene", C.c_uint32), ("gene_start", u32p), ("gene_end", u32p),
+                ("n_bits", C.c_uint64), ("near_border_bits", u64p), ("intronic_bits", u64p),
+                ("n_chr", C.c_uint32), ("chr_shift", u32p), ("chr_id", i32p)]
+
+
+class MappedRead(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("spos_r1", "spos_r2", "epos_r1", "epos_r2", "qspos_r1", "qspos_r2",
+                                          "qepos_r1", "qepos_r2", "mlen_r1", "mlen_r2")] + \
+               [(n, C.c_int32) for n in ("ed_r1", "ed_r2", "type", "tlen", "contig_num", "chr_id")] + \
+               [("junc_num", C.c_uint16), ("r1_forward", C.c_uint8), ("r2_forward", C.c_uint8),
+                ("gm_compatible", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+MAPPED_DTYPE = np.dtype([(n, "<u4") for n in ("spos_r1", "spos_r2", "epos_r1", "epos_r2", "qspos_r1", "qspos_r2",
+                                               "qepos_r1", "qepos_r2", "mlen_r1", "mlen_r2")] +
+                        [(n, "<i4") for n in ("ed_r1", "ed_r2", "type", "tlen", "contig_num", "chr_id")] +
+                        [("junc_num", "<u2"), ("r1_forward", "u1"), ("r2_forward", "u1"), ("gm_compatible", "u1"),
+                         ("pad", "u1", (3,))])
+assert MAPPED_DTYPE.itemsize == C.sizeof(MappedRead) == 72
+
+CHAIN_DTYPE = np.dtype([("score", "<f4"), ("chain_len", "<u4"), ("rpos", "<u4", (CM_MAX_CHAIN_FRAGS,)),
+                        ("qpos", "<i4", (CM_MAX_CHAIN_FRAGS,))])
+assert CHAIN_DTYPE.itemsize == 136
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("seq1", u8p), ("off1", u64p), ("seq2", u8p), ("off2", u64p)]
+
+
+class ChrInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("contig_id", C.c_uint32), ("start_pos", C.c_uint32), ("len", C.c_uint32)]
+
+
+def ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+class ReadBatch:
+    """Host-side concatenated reads (keeps the numpy buffers alive)."""
+
+    def __init__(self, seq1: np.ndarray, seq2: np.ndarray, len1=None, len2=None):
+        if seq1.ndim == 2:
+            n, L1 = seq1.shape
+            L2 = seq2.shape[1]
+            self.off1 = (np.arange(n + 1, dtype=np.uint64) * L1)
+            self.off2 = (np.arange(n + 1, dtype=np.uint64) * L2)
+            self.seq1 = np.ascontiguousarray(seq1, dtype=np.uint8).reshape(-1)
+            self.seq2 = np.ascontiguousarray(seq2, dtype=np.uint8).reshape(-1)
+        else:
+            self.seq1 = np.ascontiguousarray(seq1, dtype=np.uint8)
+            self.seq2 = np.ascontiguousarray(seq2, dtype=np.uint8)
+            self.off1 = np.concatenate([[0], np.cumsum(len1)]).astype(np.uint64)
+            self.off2 = np.concatenate([[0], np.cumsum(len2)]).astype(np.uint64)
+            n = len(self.off1) - 1
+        if self.seq1.size == 0:
+            self.seq1 = np.zeros(1, np.uint8)
+        if self.seq2.size == 0:
+            self.seq2 = np.zeros(1, np.uint8)
+        self.n = int(n)
+        self.c = Reads(self.n, ptr(self.seq1, u8p), ptr(self.off1, u64p), ptr(self.seq2, u8p), ptr(self.off2, u64p))
+
+    def max_len(self) -> int:
+        if self.n == 0:
+            return 0
+        return int(max(np.diff(self.off1).max(), np.diff(self.off2).max()))
+
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """Load libcmhot.so and declare every prototype of include/circminer_hot.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the hot path is HIP-only; there is no CPU fallback)")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    pp = C.POINTER
+    sigs = {
+        "cm_create": (C.c_int, [pp(Params), pp(vp)]),
+        "cm_destroy": (None, [vp]),
+        "cm_last_error": (C.c_char_p, [vp]),
+        "cm_load_contig": (C.c_int, [vp, C.c_int, pp(IndexView)]),
+        "cm_load_annotation": (C.c_int, [vp, C.c_int, pp(AnnotView)]),
+        "cm_unload_contig": (C.c_int, [vp, C.c_int]),
+        "cm_reads_upload": (C.c_int, [vp, pp(Reads), vp]),
+        "cm_map_round": (C.c_int, [vp, C.c_int, C.c_int]),
+        "cm_reads_download": (C.c_int, [vp, vp, vp, vp]),
+        "cm_map_batch": (C.c_int, [vp, C.c_int, C.c_int, pp(Reads), vp, vp, vp]),
+        "cm_sync": (C.c_int, [vp]),
+        "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
+        "cm_chain_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+        "cm_prof_enable": (C.c_int, [vp, C.c_int]),
+        "cm_prof_reset": (C.c_int, [vp]),
+        "cm_prof_get": (C.c_int, [vp, pp(C.c_double), pp(C.c_uint64)]),
+        "cm_prof_counters": (C.c_int, [vp, pp(C.c_uint64)]),
+        "cm_host_build_index": (C.c_int, [u8p, C.c_uint32, C.c_int32, C.c_int32, C.c_int, pp(IndexView)]),
+        "cm_host_free_index": (None, [pp(IndexView)]),
+        "cm_host_build_annotation": (C.c_int, [C.c_char_p, pp(ChrInfo), C.c_uint32, u32p, C.c_uint32, C.c_int32,
+                                               pp(AnnotView)]),
+        "cm_host_free_annotation": (None, [pp(AnnotView), C.c_uint32]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
+                    "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
+                    "cm_sync", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
+                    "cm_host_free_annotation"]
+
+
+class HostIndex:
+    """Owns the host-side index + annotation of a packed genome (built by the C++ host builders)."""
+
+    def __init__(self, contigs, chr_table, gtf_path, kmer=20, max_read_len=300, n_threads=8):
+        L = load()
+        self.L = L
+        self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
+        self.views = []
+        for ci, g in enumerate(self.contigs):
+            iv = IndexView()
+            rc = L.cm_host_build_index(ptr(g, u8p), len(g), kmer, ci, n_threads, C.byref(iv))
+            if rc != 0:
+                raise RuntimeError(f"cm_host_build_index failed: {rc}")
+            self.views.append(iv)
+        n_con = len(self.contigs)
+        self._names = [t[0].encode() for t in chr_table]
+        chrs = (ChrInfo * len(chr_table))(*[ChrInfo(self._names[i], t[1], t[2], t[3]) for i, t in enumerate(chr_table)])
+        clen = np.asarray([len(c) for c in self.contigs], dtype=np.uint32)
+        self.annots = (AnnotView * n_con)()
+        rc = L.cm_host_build_annotation(gtf_path.encode(), chrs, len(chr_table), ptr(clen, u32p), n_con, max_read_len,
+                                        self.annots)
+        if rc != 0:
+            raise RuntimeError(f"cm_host_build_annotation failed: {rc}")
+        self.chr_table = list(chr_table)
+        self.n_contigs = n_con
+
+    def close(self):
+        if self.views:
+            for iv in self.views:
+                self.L.cm_host_free_index(C.byref(iv))
+            self.L.cm_host_free_annotation(self.annots, self.n_contigs)
+            self.views = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HotPath:
+    """Thin OO wrapper over the cm_* C-ABI (one context per GPU)."""
+
+    def __init__(self, params: Params):
+        self.L = load()
+        self.params = params
+        self.h = C.c_void_p()
+        rc = self.L.cm_create(C.byref(params), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"cm_create failed ({rc}): no usable HIP device / bad params")
+        self.n = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.L.cm_last_error(self.h).decode()}")
+
+    def load_contig(self, slot, iv: IndexView, av: AnnotView = None):
+        self._chk(self.L.cm_load_contig(self.h, slot, C.byref(iv)), "cm_load_contig")
+        if av is not None:
+            self._chk(self.L.cm_load_annotation(self.h, slot, C.byref(av)), "cm_load_annotation")
+
+    def upload(self, batch: ReadBatch, prior: np.ndarray = None):
+        self.n = batch.n
+        p = prior.ctypes.data if prior is not None else None
+        self._chk(self.L.cm_reads_upload(self.h, C.byref(batch.c), p), "cm_reads_upload")
+
+    def map_round(self, slot, is_last):
+        self._chk(self.L.cm_map_round(self.h, slot, int(is_last)), "cm_map_round")
+
+    def sync(self):
+        self._chk(self.L.cm_sync(self.h), "cm_sync")
+
+    def download(self):
+        st = np.zeros(self.n, dtype=MAPPED_DTYPE)
+        cat = np.zeros(self.n, dtype=np.int32)
+        act = np.zeros(self.n, dtype=np.uint8)
+        self._chk(self.L.cm_reads_download(self.h, st.ctypes.data, cat.ctypes.data, act.ctypes.data), "cm_reads_download")
+        return st, cat, act
+
+    def seeds(self, slot, n_slots_cap=16):
+        cap = self.n * 4 * n_slots_cap
+        a = np.zeros(cap, np.uint32)
+        b = np.zeros(cap, np.uint32)
+        c = np.zeros(cap, np.uint32)
+        ns = C.c_uint32(0)
+        self._chk(self.L.cm_seed_batch(self.h, slot, a.ctypes.data, b.ctypes.data, c.ctypes.data, cap, C.byref(ns)),
+                  "cm_seed_batch")
+        k = self.n * 4 * ns.value
+        return a[:k], b[:k], c[:k], ns.value
+
+    def chains(self, slot):
+        ch = np.zeros(self.n * 4 * CM_BESTCHAINLIM, dtype=CHAIN_DTYPE)
+        nc = np.zeros(self.n * 4, np.int32)
+        hh = np.zeros(self.n * 4, np.int32)
+        self._chk(self.L.cm_chain_batch(self.h, slot, ch.ctypes.data, nc.ctypes.data, hh.ctypes.data), "cm_chain_batch")
+        return ch, nc, hh
+
+    def prof(self, on=True):
+        self._chk(self.L.cm_prof_enable(self.h, int(on)), "cm_prof_enable")
+
+    def prof_reset(self):
+        self._chk(self.L.cm_prof_reset(self.h), "cm_prof_reset")
+
+    def prof_get(self):
+        ms = (C.c_double * 4)()
+        n = (C.c_uint64 * 4)()
+        self._chk(self.L.cm_prof_get(self.h, ms, n), "cm_prof_get")
+        cnt = (C.c_uint64 * 4)()
+        self._chk(self.L.cm_prof_counters(self.h, cnt), "cm_prof_counters")
+        return list(ms), list(n), list(cnt)
+
+    def close(self):
+        if self.h:
+            self.L.cm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,239 @@
+/*
+ * circminer_hot.h — C-ABI of the MI355X-native CircMiner mapping hot path.
+ *
+ * The reference (CircMiner 0.4.5) has no plugin/FFI boundary: the seam this
+ * library replaces is
+ *
+ *     int FilterRead::process_read(int thid, Record* r1, Record* r2, int kmer_size,
+ *                                  GIMatchedKmer* fl, GIMatchedKmer* bl,
+ *                                  chain_list& fbc_r1, chain_list& bbc_r1,
+ *                                  chain_list& fbc_r2, chain_list& bbc_r2)
+ *                                                       (src/filter.h:49-52, src/filter.cpp:124-241)
+ *
+ * called once per read pair from map_reads (src/circminer.cpp:384), together with the
+ * process-wide state it reads: the loaded mrsfast k-mer table (src/mrsfast/HashTable.c:971-1098),
+ * the decoded contig string (src/match_read.cpp:288-299,334), the GTF model
+ * (src/gene_annotation.{h,cpp}) and the threshold globals (src/common.h:92-103).
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No C++ / torch types.
+ * All functions return 0 on success or a negative CM_E* code; none of them calls exit().
+ */
+#ifndef CIRCMINER_HOT_H
+#define CIRCMINER_HOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- category codes: src/common.h:59-72 (the order matters) ---- */
+enum {
+    CM_CONCRD = 0, CM_DISCRD = 1, CM_CHIORF = 2, CM_CHIBSJ = 3, CM_CHI2BSJ = 4, CM_CONGEN = 5,
+    CM_CHIFUS = 6, CM_CONGNM = 7, CM_OEA2 = 8, CM_CANDID = 9, CM_OEANCH = 10, CM_ORPHAN = 11,
+    CM_NOPROC_MANYHIT = 12, CM_NOPROC_NOMATCH = 13
+};
+
+/* ---- error codes ---- */
+enum {
+    CM_OK = 0,
+    CM_EINVAL = -1,     /* bad argument / unsupported parameter combination            */
+    CM_ENODEV = -2,     /* no HIP device (the product path never falls back to the CPU) */
+    CM_ENOMEM = -3,     /* host or device allocation failed                             */
+    CM_EHIP = -4,       /* a HIP runtime call or kernel failed                          */
+    CM_ESTATE = -5,     /* contig / annotation not loaded                               */
+    CM_ELIMIT = -6      /* a documented capacity limit of the device path was exceeded  */
+};
+
+#define CM_WINDOW_SIZE 14          /* WINDOW_SIZE, src/common.cpp:7                         */
+#define CM_BESTCHAINLIM 30         /* BESTCHAINLIM, src/common.h:51; chain.h:14-17          */
+#define CM_MAX_CHAIN_FRAGS 16      /* >= ceil(maxReadLength/k) used slots (even slots only) */
+#define CM_CONTIG_SIZE 1100000000u /* DEF_CONTIG_SIZE, src/common.h:81 (gspos stride)       */
+
+/* ---- thresholds: the reference keeps these as globals (src/common.h:92-103,
+ *      defaults src/commandline_parser.cpp:7-33) ---- */
+typedef struct cm_params {
+    int32_t kmer;            /* WINDOW_SIZE + checkSumLength, 14..22 (src/commandline_parser.cpp:242-247) */
+    int32_t seed_lim;        /* seedLim       default 500     */
+    int32_t max_read_len;    /* maxReadLength default 300     */
+    int32_t scan_level;      /* scanLevel     default 0       */
+    int32_t max_ed;          /* maxEd         default 4       */
+    int32_t max_sc;          /* maxSc         default 7       */
+    int32_t band;            /* bandWidth     default 3       */
+    int32_t max_tlen;        /* maxTlen       default 500     */
+    int32_t max_intron;      /* maxIntronLen  default 2000000 */
+    int32_t max_chain_len;   /* maxChainLen   default 30 (must be <= CM_BESTCHAINLIM, see chain.h:14-17) */
+    int32_t device;          /* HIP device ordinal            */
+    int32_t reserved;
+} cm_params;
+
+/* ---- one packed contig of the k-mer index, as loadHashTable leaves it in memory
+ *      (src/mrsfast/HashTable.c:971-1057) but flattened: bucket hv owns entries
+ *      [bucket_off[hv], bucket_off[hv+1]) sorted by (checksum, pos)
+ *      (src/mrsfast/Sort.c:116-117); pos is the 1-based k-mer start
+ *      (HashTable.c:785-806).  genome is what pac2char serves
+ *      (src/match_read.cpp:288-299): ASCII, genome[p-1] = base at 1-based p. ---- */
+typedef struct cm_index_view {
+    int32_t contig_num;          /* contigNum = atoi(contigName)-1, src/circminer.cpp:266-268 */
+    uint32_t ref_len;            /* getRefGenLength()                                         */
+    const uint8_t *genome;       /* ref_len bytes, 'A','C','G','T','N'                        */
+    const uint32_t *bucket_off;  /* 4^14 + 1 offsets                                          */
+    const uint16_t *checksum;    /* n_entries                                                 */
+    const uint32_t *pos;         /* n_entries                                                 */
+    uint64_t n_entries;
+} cm_index_view;
+
+/* ---- flattened query side of GTFParser for one packed contig
+ *      (src/gene_annotation.{h,cpp}, src/interval_tree_impl.h) ---- */
+typedef struct cm_annot_view {
+    /* disjoint intervals, ascending (FlatIntervalTree::disjoint_intervals) */
+    uint32_t n_iv;
+    const uint32_t *iv_spos, *iv_epos;
+    const uint32_t *iv_max_end, *iv_min_end, *iv_max_next_exon; /* interval_tree_impl.h:198-211 */
+    const uint32_t *iv_seg_off;  /* n_iv+1 : CSR into iv_seg                                   */
+    const uint32_t *iv_seg;      /* indices into the unique-segment tables, seg_list order     */
+    /* unique segments (UniqSeg, src/common.h:227-251) */
+    uint32_t n_seg;
+    const uint32_t *seg_start, *seg_end, *seg_next_exon_beg, *seg_gene_id;
+    const uint32_t *seg_tid_off; /* n_seg+1 : CSR into seg_tid (trans_id vector order)         */
+    const uint32_t *seg_tid;
+    /* transcripts */
+    uint32_t n_trans;
+    const int32_t *trans_start_ind;  /* get_trans_start_ind, gene_annotation.h:143-145         */
+    const uint32_t *t2s_off;         /* n_trans+1 : CSR into t2s                               */
+    const uint8_t *t2s;              /* trans2seg states 0/1/2/3, interval_tree_impl.h:232-241 */
+    /* genes (gid2ginfo, src/gene_annotation.cpp:243-245) */
+    uint32_t n_gene;
+    const uint32_t *gene_start, *gene_end;
+    /* position bitsets (src/common.h:117-118); bit p = contig position p */
+    uint64_t n_bits;
+    const uint64_t *near_border_bits;
+    const uint64_t *intronic_bits;
+    /* chromosomes packed into this contig, ascending by shift (con2chr, gene_annotation.cpp:424-457) */
+    uint32_t n_chr;
+    const uint32_t *chr_shift;   /* ContigLen.start_pos                                        */
+    const int32_t *chr_id;       /* global chromosome ordinal (row of .index.info)             */
+} cm_annot_view;
+
+/* ---- POD mirror of MatchedRead (src/common.h:311-352); carried between rounds through the
+ *      23-token FASTQ header in the reference (src/filter.cpp:413-455, fastq_parser.cpp:203-269).
+ *      chr_r1 == chr_r2 always (src/common.cpp:295-296) so one chr_id is kept; -1 is "-". ---- */
+typedef struct cm_mapped_read {
+    uint32_t spos_r1, spos_r2, epos_r1, epos_r2;
+    uint32_t qspos_r1, qspos_r2, qepos_r1, qepos_r2;
+    uint32_t mlen_r1, mlen_r2;
+    int32_t ed_r1, ed_r2;
+    int32_t type;
+    int32_t tlen;
+    int32_t contig_num;
+    int32_t chr_id;
+    uint16_t junc_num;
+    uint8_t r1_forward, r2_forward, gm_compatible, pad[3];
+} cm_mapped_read;
+
+/* ---- one chain (chain_t, src/common.h:150-154) as produced by chain_seeds_sorted_kbest ---- */
+typedef struct cm_chain {
+    float score;
+    uint32_t chain_len;
+    uint32_t rpos[CM_MAX_CHAIN_FRAGS];
+    int32_t qpos[CM_MAX_CHAIN_FRAGS];   /* fragment_t.len is always kmer (src/chain.cpp:265,293) */
+} cm_chain;
+
+typedef struct cm_ctx cm_ctx;
+
+/* Reads are passed as concatenated upper/lower-case ASCII with offsets:
+ * pair i = R1 bytes [off1[i], off1[i+1]) of seq1, R2 bytes [off2[i], off2[i+1]) of seq2. */
+typedef struct cm_reads {
+    uint64_t n_pairs;
+    const uint8_t *seq1;
+    const uint64_t *off1;   /* n_pairs+1 */
+    const uint8_t *seq2;
+    const uint64_t *off2;   /* n_pairs+1 */
+} cm_reads;
+
+/* ---------------- context ---------------- */
+int cm_create(const cm_params *p, cm_ctx **out);
+void cm_destroy(cm_ctx *ctx);
+const char *cm_last_error(const cm_ctx *ctx);      /* never NULL */
+
+/* Stage one packed contig (index + decoded genome) into HBM.  Replaces loadHashTable +
+ * pac2char_whole_contig (src/circminer.cpp:232,244).  slot is the caller's handle (0..15). */
+int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv);
+/* Stage the flattened annotation of the same contig.  Replaces gtf_parser.load_gtf's
+ * query-side state for contigNum (src/circminer.cpp:205-206). */
+int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av);
+int cm_unload_contig(cm_ctx *ctx, int slot);
+
+/* Upload a batch of read pairs once; they stay resident for all rounds.
+ * prior may be NULL (= first round, fill_map_info's "cnt != 23" state). */
+int cm_reads_upload(cm_ctx *ctx, const cm_reads *reads, const cm_mapped_read *prior);
+
+/* One mapping round of the resident batch against contig `slot`:
+ * FilterRead::process_read for every pair still active + the skip rule of
+ * map_reads (src/circminer.cpp:386-397).  Pairs whose carried state says they were
+ * retired in an earlier round (active[i]==0) are left untouched.
+ * Asynchronous on the ctx stream; cm_sync() or cm_reads_download() waits. */
+int cm_map_round(cm_ctx *ctx, int slot, int is_last_round);
+
+/* Copy back the carried state, the per-pair return value of process_read in the last
+ * cm_map_round (state[i], -1 if the pair was inactive) and the active flags after it. */
+int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active);
+
+/* Convenience wrapper = upload + one round + download (the literal batched process_read). */
+int cm_map_batch(cm_ctx *ctx, int slot, int is_last_round, const cm_reads *reads,
+                 const cm_mapped_read *prior, cm_mapped_read *out_state, int32_t *out_category);
+
+int cm_sync(cm_ctx *ctx);
+
+/* ---------------- finer-grained entry points used by the parity tests ---------------- */
+/* Seeds (GenomeSeeder::split_match_hash, src/match_read.cpp:270-286) of the resident batch:
+ * for probe q = ((pair*2 + mate)*2 + orient)*n_slots + s (orient 0 = forward, 1 = reverse
+ * complement; s = seed ordinal, qpos = s*kmer):
+ *   out_start[q] = index of first hit in the contig's entry arrays (valid if cnt>0 or high)
+ *   out_cnt[q]   = frag_count after the seedLim rule (0 if > seedLim)
+ *   out_raw[q]   = occurrence count before the rule (0 = frags==NULL)
+ * n_slots = max over the batch of floor(len/kmer); returned through out_n_slots. */
+int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt, uint32_t *out_raw,
+                  uint32_t cap_probes, uint32_t *out_n_slots);
+/* Chains (chain_seeds_sorted_kbest, src/chain.cpp:73-301) of the resident batch: problem
+ * r = (pair*2 + mate)*2 + orient; out_nchain[r] chains stored at out_chains[r*CM_BESTCHAINLIM ...],
+ * out_high[r] = high_hits of get_best_chains (src/filter.cpp:478-481). */
+int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nchain, int32_t *out_high);
+
+/* ---------------- timing hooks for bench.py (HIP events on the ctx stream) ---------------- */
+/* Milliseconds spent in each kernel class since the last cm_prof_reset():
+ * [0]=seed_probe [1]=chain [2]=pair_extend_classify [3]=scan/other; and launch counts. */
+int cm_prof_enable(cm_ctx *ctx, int on);
+int cm_prof_reset(cm_ctx *ctx);
+int cm_prof_get(cm_ctx *ctx, double ms[4], uint64_t launches[4]);
+/* Algorithmic byte counters of SURVEY §8(d) accumulated by the kernels since cm_prof_reset():
+ * [0]=probes [1]=binary-search touches [2]=hits consumed (cnt<=seedLim) [3]=pair-rounds. */
+int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]);
+
+/* ---------------- host-side builders (stay on host; north_star "index build ... on host") ---- */
+/* In-memory equivalent of generateHashTableOnDisk for one contig
+ * (src/mrsfast/HashTable.c:257-380,769-839): caller frees with cm_host_free_index. */
+int cm_host_build_index(const uint8_t *genome, uint32_t ref_len, int32_t kmer, int32_t contig_num,
+                        int n_threads, cm_index_view *out);
+void cm_host_free_index(cm_index_view *iv);
+
+/* GTF -> flattened annotation for every packed contig (GTFParser::load_gtf,
+ * src/gene_annotation.cpp:191-399).  chromosome table = rows of .index.info
+ * (src/genome.cpp:147-167): name, packed contig id (1-based), start_pos.
+ * out must point to n_contigs views; free with cm_host_free_annotation. */
+typedef struct cm_chr_info {
+    const char *name;
+    uint32_t contig_id;   /* 1-based */
+    uint32_t start_pos;   /* shift   */
+    uint32_t len;
+} cm_chr_info;
+int cm_host_build_annotation(const char *gtf_path, const cm_chr_info *chrs, uint32_t n_chr,
+                             const uint32_t *contig_len, uint32_t n_contigs, int32_t max_read_len,
+                             cm_annot_view *out);
+void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIRCMINER_HOT_H */

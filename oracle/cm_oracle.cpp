@@ -1,0 +1,1581 @@
+// ============================================================================================
+// cm_oracle.cpp — CPU restatement of CircMiner 0.4.5's per-pair mapping hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may build, load or call it, and only as the checker / the reported
+// CPU baseline.  The product path (circminer_amd/csrc, libcmhot.so) never links or calls it.
+//
+// PARITY UNPINNED: the reference cannot be built in this image (every source includes the absent
+// submodule headers logger.h / mrsfast/Common.h) and it ships no tests, golden
+// vectors or fixtures, so this restatement is checked only against planted-truth
+// properties of synthetic data, never against reference outputs.
+//
+// Each function cites the reference file:line it follows.  The data it runs on is the flattened
+// index / annotation of include/circminer_hot.h (pure data layout, shared with the product).
+// Compile with -ffp-contract=off: chain scores are fp64 sums whose rounding order matters.
+// ============================================================================================
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "circminer_hot.h"
+
+namespace {
+
+// ---- constants, reference src/common.h:34-53 ----
+const int INF_I = 1000000000;         // (int)INF, INF = 1e9
+const uint32_t MINLB = 0;
+const uint32_t MAXUB = 4294967295u;
+const int MAXDISCRDTLEN = 20000;
+const uint32_t LARIAT2BEGTH = 1000;
+const int DPTINF = 10000000;          // src/align.cpp:12
+
+struct Ctx {
+    cm_params P;
+    const cm_index_view *X;
+    const cm_annot_view *A;
+    int kmer() const { return P.kmer; }
+};
+
+// ============================ A1: hashVal / checkSumVal ============================
+// Declared in the absent mrsfast/Common.h; semantics fixed by the in-tree index builder
+// (src/mrsfast/HashTable.c:271-279, 799-806): A0 C1 G2 T3 MSB-first, -1 on anything else.
+int pack2(const uint8_t *s, int n) {
+    int v = 0;
+    for (int i = 0; i < n; ++i) {
+        int b;
+        switch (s[i]) {
+            case 'A': b = 0; break;
+            case 'C': b = 1; break;
+            case 'G': b = 2; break;
+            case 'T': b = 3; break;
+            default: return -1;
+        }
+        v = (v << 2) | b;
+    }
+    return v;
+}
+
+// ============================ A2-A4: seeding ============================
+struct MatchedKmer {        // GIMatchedKmer, src/common.h:165-170
+    int64_t frags;          // index of first hit in the entry arrays, -1 == NULL
+    uint32_t frag_count;
+    int32_t qpos;
+    uint32_t raw;           // occurrences before the seedLim rule (diagnostic only)
+};
+
+inline uint32_t frag_info(const Ctx &c, const MatchedKmer &mk, uint32_t i) { return c.X->pos[mk.frags + i]; }
+
+// GenomeSeeder::get_exact_locs_hash, src/match_read.cpp:54-110 (+ getCandidates, HashTable.c:1093-1098)
+int get_exact_locs_hash(const Ctx &c, const uint8_t *seq, int32_t qpos, MatchedKmer *mk) {
+    mk->frag_count = 0;
+    mk->frags = -1;
+    mk->qpos = qpos;
+    mk->raw = 0;
+    int hv = pack2(seq, CM_WINDOW_SIZE);
+    if (hv < 0) return 0;
+    int cl = c.kmer() - CM_WINDOW_SIZE;
+    int cv = pack2(seq + CM_WINDOW_SIZE, cl);
+    if (cv < 0) return 0;
+    const uint32_t b0 = c.X->bucket_off[hv], b1 = c.X->bucket_off[hv + 1];
+    if (b1 == b0) return 0;                      // getCandidates: NULL list or [0].info == 0
+    const uint16_t *it = c.X->checksum + b0;     // it[m-1] here == it[m].checksum in the reference
+    uint32_t lb = 1, ub = b1 - b0, mid;
+    int16_t target = (int16_t)cv;                // quirk: int16 vs uint16 field (match_read.cpp:77)
+    uint32_t LB = 0, UB = 0;
+    while (lb < ub) {
+        mid = (lb + ub) / 2;
+        if ((int)target <= (int)it[mid - 1]) ub = mid;
+        else lb = mid + 1;
+    }
+    if (ub < lb || (int)target != (int)it[lb - 1]) return 0;
+    UB = LB = lb;
+    lb = LB;
+    ub = b1 - b0;
+    while (lb < ub) {
+        mid = (lb + ub + 1) / 2;
+        if ((int)target < (int)it[mid - 1]) ub = mid - 1;
+        else lb = mid;
+    }
+    if ((int)target == (int)it[lb - 1]) UB = lb;
+    mk->frag_count = UB - LB + 1;
+    mk->raw = mk->frag_count;
+    mk->frags = (int64_t)b0 + (LB - 1);
+    return (int)(UB - LB + 1);
+}
+
+int max_seg_cnt(const Ctx &c) { return 2 * (int)std::ceil(1.0 * c.P.max_read_len / c.kmer()) - 1; }
+
+// GenomeSeeder::kmer_match_skip_hash(shift 0, skip k, ll_step 2) via split_match_hash,
+// src/match_read.cpp:180-286
+int split_match_hash(const Ctx &c, const uint8_t *rseq, int rseq_len, MatchedKmer *mk_res) {
+    const int k = c.kmer();
+    int msc = max_seg_cnt(c);
+    for (int j = 0; j < msc; ++j) {
+        mk_res[j].frag_count = 0;
+        mk_res[j].frags = -1;
+        mk_res[j].raw = 0;
+    }
+    int em = 0, invalid = 0;
+    MatchedKmer *cur = mk_res;
+    for (int i = 0; i < rseq_len; i += k) {
+        if (rseq_len - i < k) break;
+        if (i != 0) cur += 2;
+        cur->qpos = i;
+        int occ = get_exact_locs_hash(c, rseq + i, i, cur);
+        if (occ <= 0) invalid++;
+        else if ((uint32_t)occ > (uint32_t)c.P.seed_lim) invalid++;
+        em++;
+    }
+    for (int i = 0; i < em * 2; i += 2)
+        if (mk_res[i].frag_count > (uint32_t)c.P.seed_lim) mk_res[i].frag_count = 0;   // frags stays non-NULL
+    return em - invalid;
+}
+
+// ============================ A7: annotation queries ============================
+// FlatIntervalTree::search, src/interval_tree_impl.h:136-150
+int iv_search(const cm_annot_view *A, uint32_t target) {
+    int beg = 0, end = (int)A->n_iv, mid;
+    while (end - beg > 1) {
+        mid = (beg + end) / 2;
+        if (target < A->iv_spos[mid]) end = mid;
+        else beg = mid;
+    }
+    return end;
+}
+// FlatIntervalTree::find_ind, :165-175 — returns interval index or -1 (NULL); ind as in the reference
+int iv_find_ind(const cm_annot_view *A, uint32_t pos, int &ind) {
+    ind = -1;
+    if (pos < A->iv_spos[0]) return -1;
+    ind = iv_search(A, pos) - 1;
+    if (ind < 0 || A->iv_epos[ind] < pos) return -1;
+    return ind;
+}
+int iv_get_node(const cm_annot_view *A, int ind) { return (ind < 0 || ind >= (int)A->n_iv) ? -1 : ind; }   // :178-182
+inline uint32_t iv_nseg(const cm_annot_view *A, int iv) { return A->iv_seg_off[iv + 1] - A->iv_seg_off[iv]; }
+inline uint32_t iv_segid(const cm_annot_view *A, int iv, uint32_t i) { return A->iv_seg[A->iv_seg_off[iv] + i]; }
+inline bool bit(const uint64_t *b, uint64_t n, uint64_t p) { return p < n && ((b[p >> 6] >> (p & 63)) & 1); }
+
+// GTFParser::get_location_overlap[_ind], src/gene_annotation.cpp:538-568
+int get_location_overlap_ind(const Ctx &c, uint32_t loc, int &ind) {
+    int r = iv_find_ind(c.A, loc, ind);
+    if (r < 0 || iv_nseg(c.A, r) == 0) return -1;
+    return r;
+}
+int get_location_overlap(const Ctx &c, uint32_t loc) { int ind; return get_location_overlap_ind(c, loc, ind); }
+
+// GTFParser::get_upper_bound_lookup, src/gene_annotation.cpp:464-533
+uint32_t get_upper_bound_lookup(const Ctx &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end,
+                                int &ol_exons) {
+    const cm_annot_view *A = c.A;
+    max_end = 0;
+    int it_ind = -1;
+    int ov = iv_find_ind(A, spos, it_ind);
+    uint32_t epos = spos + mlen - 1;
+    if (ov < 0 || iv_nseg(A, ov) == 0) {
+        ol_exons = -1;
+        int nx = iv_get_node(A, it_ind + 1);
+        // the reference dereferences NULL here when spos lies beyond the last interval; that is
+        // unreachable through get_upper_bound because such positions are never near a border.
+        max_end = (nx < 0 ? 0u : A->iv_spos[nx]) - 1;
+        if (max_end < epos) return 0;
+        uint32_t a = spos + rlen + (uint32_t)c.P.max_ed, b = max_end - mlen + 1;
+        return a < b ? a : b;
+    }
+    ol_exons = -1;
+    uint32_t min_end = 1000000000u, max_next_exon = 0;
+    if (epos > A->iv_epos[ov]) {
+        for (uint32_t i = 0; i < iv_nseg(A, ov); ++i) {
+            uint32_t s = iv_segid(A, ov, i);
+            if (A->seg_end[s] >= epos) {
+                max_end = std::max(max_end, A->seg_end[s]);
+                min_end = std::min(min_end, A->seg_end[s]);
+                max_next_exon = std::max(max_next_exon, A->seg_next_exon_beg[s]);
+            }
+        }
+    } else {
+        max_end = A->iv_max_end[ov];
+        min_end = A->iv_min_end[ov];
+        max_next_exon = A->iv_max_next_exon[ov];
+    }
+    if (max_end > 0 && max_end >= epos) {
+        ol_exons = ov;
+        if (min_end < rlen + epos && max_next_exon != 0) return max_next_exon + mlen - 1;
+        return max_end - mlen + 1;
+    }
+    max_end = 0;
+    ol_exons = -1;
+    return 0;
+}
+
+// GTFParser::get_upper_bound, src/gene_annotation.h:123-133
+uint32_t get_upper_bound(const Ctx &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end, int &ol_exons) {
+    if (bit(c.A->near_border_bits, c.A->n_bits, spos)) return get_upper_bound_lookup(c, spos, mlen, rlen, max_end, ol_exons);
+    max_end = 0;
+    ol_exons = -1;
+    return spos + rlen + (uint32_t)c.P.max_ed;
+}
+
+// GTFParser::get_shift, src/gene_annotation.cpp:451-457 — returns row in the contig's chr table
+int get_shift(const Ctx &c, uint32_t loc) {
+    uint32_t i;
+    for (i = 1; i < c.A->n_chr; ++i)
+        if (loc < c.A->chr_shift[i]) return (int)i - 1;
+    return (int)i - 1;
+}
+
+// ============================ A6: chaining ============================
+struct Frag { uint32_t rpos; int32_t qpos; uint32_t len; };            // fragment_t, common.h:138-146
+struct Chain { std::vector<Frag> frags; uint32_t chain_len = 0; float score = 0; };   // chain_t
+struct ChainList { std::vector<Chain> chains; int best_chain_count = 0; };            // chain_list
+struct Cell { double score; int prev_list; int prev_ind; };            // chain_cell, chain.h:8-12
+struct CellList { Cell chain_list[CM_BESTCHAINLIM]; uint32_t count; }; // chain_cell_list, chain.h:14-17
+
+// check_junction, src/chain.cpp:28-64
+bool check_junction(const Ctx &c, uint32_t s1, uint32_t s2, int ol_exons, int kmer, int read_dist, int &trans_dist) {
+    trans_dist = INF_I;
+    if (ol_exons < 0) return false;
+    uint32_t e1 = s1 + kmer - 1;
+    if (s2 <= e1) return false;
+    int e12end, beg2s2, trans_dist2intron = -1;
+    const cm_annot_view *A = c.A;
+    for (uint32_t i = 0; i < iv_nseg(A, ol_exons); ++i) {
+        uint32_t s = iv_segid(A, ol_exons, i);
+        e12end = (int)(A->seg_end[s] - e1);
+        beg2s2 = (int)(s2 - A->seg_next_exon_beg[s]);
+        if (e12end >= 0 && e12end < read_dist && beg2s2 + kmer < 0) trans_dist2intron = (int)(s2 - e1 - 1);
+        if (e12end < 0 || beg2s2 < 0) continue;
+        trans_dist = e12end + beg2s2;
+        if (std::abs(trans_dist - read_dist) <= c.P.max_ed) return true;
+    }
+    if (trans_dist2intron != -1) {
+        trans_dist = trans_dist2intron;
+        return true;
+    }
+    trans_dist = INF_I;
+    return false;
+}
+
+// chain_seeds_sorted_kbest, src/chain.cpp:73-301
+void chain_seeds_sorted_kbest(const Ctx &c, int seq_len, MatchedKmer *fl, ChainList &best_chain) {
+    const int kmer = c.kmer();
+    best_chain.best_chain_count = 0;
+    int kmer_cnt = 2 * (int)std::ceil(1.0 * seq_len / kmer) - 1;
+    const uint32_t max_best = (uint32_t)c.P.max_chain_len;
+    while (kmer_cnt >= 1 && fl[kmer_cnt - 1].frag_count <= 0) kmer_cnt--;
+    if (kmer_cnt <= 0) return;
+
+    std::vector<std::vector<Cell>> dp(kmer_cnt);
+    for (int ii = kmer_cnt - 1; ii >= 0; ii--) {
+        dp[ii].resize(fl[ii].frag_count);
+        for (uint32_t i = 0; i < fl[ii].frag_count; i++) dp[ii][i] = Cell{(double)kmer, -1, -1};
+    }
+    std::map<double, CellList> score2chain;
+    std::vector<uint32_t> lb_ind(kmer_cnt);
+    uint32_t max_exon_end = 0;
+    int ol_exons = -1;
+
+    for (int ii = kmer_cnt - 2; ii >= 0; ii--) {
+        MatchedKmer *cur_mk = fl + ii;
+        uint32_t read_remain = (uint32_t)(seq_len - cur_mk->qpos - kmer);
+        for (int k = 0; k < kmer_cnt; k++) lb_ind[k] = 0;
+        for (uint32_t i = 0; i < cur_mk->frag_count; i++) {
+            const int32_t cur_info = (int32_t)frag_info(c, *cur_mk, i);      // GeneralIndex.info is int
+            uint32_t seg_start = (uint32_t)cur_info;
+            uint32_t seg_end = (uint32_t)cur_info + kmer - 1;
+            uint32_t max_lpos_lim = MAXUB;
+            for (int jj = ii + 1; jj < kmer_cnt; jj++) {
+                MatchedKmer *pc = fl + jj;
+                if (pc->frag_count <= 0 || lb_ind[jj] >= pc->frag_count) continue;
+                if (cur_info + c.P.max_intron < (int32_t)frag_info(c, *pc, lb_ind[jj])) continue;
+                while (lb_ind[jj] < pc->frag_count && (int32_t)frag_info(c, *pc, lb_ind[jj]) <= cur_info) lb_ind[jj]++;
+                if (lb_ind[jj] >= pc->frag_count) continue;
+                if (max_lpos_lim == MAXUB)
+                    max_lpos_lim = get_upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol_exons);
+                int distr = pc->qpos - cur_mk->qpos - kmer;
+                int read_dist = distr;
+                uint32_t j = lb_ind[jj];
+                while (j < pc->frag_count && frag_info(c, *pc, j) <= max_lpos_lim) {
+                    uint32_t pinfo = frag_info(c, *pc, j);
+                    int genome_dist, distt, trans_dist;
+                    if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
+                    else genome_dist = INF_I;
+                    if (std::abs(genome_dist - read_dist) <= c.P.max_ed) {
+                        distt = genome_dist;
+                    } else if (check_junction(c, seg_start, pinfo, ol_exons, kmer, read_dist, trans_dist)) {
+                        distt = trans_dist;
+                    } else {
+                        j++;
+                        continue;
+                    }
+                    // score_alpha / score_beta, chain.cpp:13-22: (prev + 2e4*k) - 0.1*|distr-distt|
+                    int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
+                    double beta = 0.1 * (maxd - mind);
+                    double alpha = 2e4 * kmer;
+                    double temp_score = dp[jj][j].score + alpha - beta;
+                    if (temp_score > dp[ii][i].score) {
+                        dp[ii][i].score = temp_score;
+                        dp[ii][i].prev_list = jj;
+                        dp[ii][i].prev_ind = (int)j;
+                        auto it = score2chain.find(temp_score);
+                        if (it == score2chain.end()) {
+                            CellList e;
+                            e.count = 0;
+                            it = score2chain.insert(std::make_pair(temp_score, e)).first;
+                        }
+                        if (it->second.count < max_best) {
+                            Cell t{dp[ii][i].score, ii, (int)i};
+                            it->second.chain_list[it->second.count++] = t;
+                        }
+                    }
+                    j++;
+                }
+            }
+        }
+    }
+
+    uint32_t best_count = 0;
+    double best_score = score2chain.empty() ? (double)kmer : score2chain.rbegin()->first;
+    std::set<uint32_t> repeats;
+    for (auto it = score2chain.rbegin(); it != score2chain.rend(); ++it) {
+        for (uint32_t l = 0; l < it->second.count; l++) {
+            if (best_count >= max_best) break;
+            Cell bi = it->second.chain_list[l];
+            uint32_t spos = frag_info(c, fl[bi.prev_list], (uint32_t)bi.prev_ind);
+            if (bi.score < best_score && repeats.find(spos) != repeats.end()) continue;
+            uint32_t i = 0, j = best_count++;
+            Chain &ch = best_chain.chains[j];
+            ch.frags.clear();
+            while (bi.prev_list != -1) {
+                Frag f{frag_info(c, fl[bi.prev_list], (uint32_t)bi.prev_ind), fl[bi.prev_list].qpos, (uint32_t)kmer};
+                ch.frags.push_back(f);
+                if (i != 0) repeats.insert(f.rpos);
+                int tl = bi.prev_list;
+                bi.prev_list = dp[tl][bi.prev_ind].prev_list;
+                bi.prev_ind = dp[tl][bi.prev_ind].prev_ind;
+                i++;
+            }
+            ch.score = (float)bi.score;
+            ch.chain_len = i;
+        }
+    }
+    if (best_count == 0) {
+        for (int ii = kmer_cnt - 1; ii >= 0; ii--) {
+            for (uint32_t i = 0; i < fl[ii].frag_count; i++) {
+                if (best_count >= max_best) break;
+                uint32_t j = best_count++;
+                Chain &ch = best_chain.chains[j];
+                ch.frags.assign(1, Frag{frag_info(c, fl[ii], i), fl[ii].qpos, (uint32_t)kmer});
+                ch.score = (float)dp[ii][i].score;
+                ch.chain_len = 1;
+            }
+        }
+    }
+    best_chain.best_chain_count = (int)best_count;
+}
+
+// FilterRead::get_best_chains, src/filter.cpp:469-482
+void get_best_chains(const Ctx &c, const uint8_t *seq, int seq_len, ChainList &bc, MatchedKmer *fl, int &high_hits) {
+    int msc = max_seg_cnt(c);
+    split_match_hash(c, seq, seq_len, fl);
+    chain_seeds_sorted_kbest(c, seq_len, fl, bc);
+    high_hits = 0;
+    for (int i = 0; i < msc; i += 2)
+        if (fl[i].frags >= 0 && fl[i].frag_count == 0) high_hits++;
+}
+
+// ============================ A14/A15/A16: alignment ============================
+// ScoreMatrix::init, src/align.cpp:739-760: case-insensitive ACGT identity, everything else
+// (including N vs N) is a mismatch.
+inline bool same_base(uint8_t a, uint8_t b) {
+    uint8_t x = a & 0xDF, y = b & 0xDF;
+    return x == y && (x == 'A' || x == 'C' || x == 'G' || x == 'T') &&
+           ((a >= 'A' && a <= 'Z') || (a >= 'a' && a <= 'z')) && ((b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z'));
+}
+inline int diff_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? 0 : 1; }        // edit_mat.init(0,1,1,..)
+inline int score_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? 1 : -3; }      // score_mat.init(1,-3,-3,8)
+const int SC_IND = -3, SC_XD = 8, SC_MAT = 1, SC_MIS = -3;
+
+struct AlignRes {      // src/align.h:12-121
+    uint32_t pos; int ed, sclen, indel, qcovlen, rcovlen, score;
+    explicit AlignRes(uint32_t p) : pos(p), ed(0), sclen(0), indel(0), qcovlen(0), rcovlen(0), score(-INF_I) {}
+    void set(uint32_t p, int e, int s, int i, int qc, int scr) { pos = p; ed = e; sclen = s; indel = i; qcovlen = qc; rcovlen = qc - i; score = scr; }
+    void update(int e, int s, uint32_t np, int i, int qc, int scr) { pos = np; ed += e; sclen = s; indel += i; qcovlen += qc; rcovlen += qc - i; score = scr; }
+};
+bool update_by_score_right(AlignRes &b, const AlignRes &r) {
+    if (b.score < r.score || (b.score == r.score && r.pos < b.pos)) { b.set(r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score); return true; }
+    return false;
+}
+bool update_by_score_left(AlignRes &b, const AlignRes &r) {
+    if (b.score < r.score || (b.score == r.score && r.pos > b.pos)) { b.set(r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score); return true; }
+    return false;
+}
+void update_side(const Ctx &c, AlignRes &b, const AlignRes &r, bool right) {   // update_right / update_left
+    if (r.qcovlen > b.qcovlen) {
+        int pre_ed = b.ed;
+        if (r.ed <= c.P.max_ed && r.sclen <= c.P.max_sc && 2 * (r.ed - pre_ed) < (r.qcovlen - b.qcovlen))
+            b.set(r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score);
+    } else if (r.qcovlen < b.qcovlen) {
+        if (r.ed <= c.P.max_ed && r.sclen <= c.P.max_sc && 2 * (b.ed - r.ed) >= (b.qcovlen - r.qcovlen))
+            b.set(r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score);
+    } else {
+        bool pos_better = right ? (r.pos < b.pos) : (r.pos > b.pos);
+        if ((r.ed < b.ed) || (r.ed == b.ed && r.sclen < b.sclen) || (r.ed == b.ed && r.sclen == b.sclen && pos_better))
+            b.set(r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score);
+    }
+}
+struct AlignCandid {   // src/align.h:123-153
+    int ed, sclen, indel, score;
+    AlignCandid(int e, int s, int i) : ed(e), sclen(s), indel(i), score(-1 * s - 2 * e) {}
+    AlignCandid(int e, int s, int i, int scr) : ed(e), sclen(s), indel(i), score(scr) {}
+    bool operator<(const AlignCandid &r) const {
+        if (score != r.score) return score > r.score;
+        if (ed != r.ed) return ed < r.ed;
+        return std::abs(indel) < std::abs(r.indel);
+    }
+    void update(const AlignCandid &r) { if (r < *this) *this = r; }
+};
+
+// The reference keeps 600x600 member matrices that are never cleared and relies on sentinels
+// written per call.  Here every call gets its own matrix pre-filled with a poison value and any
+// read of a poisoned cell aborts: that is the proof that no call depends on stale cells.
+struct Mat {
+    int n1, m1;
+    std::vector<int64_t> v;
+    static int64_t poison() { return INT64_MIN; }
+    Mat(int n, int m) : n1(n + 8), m1(m + 8), v((size_t)(n + 8) * (m + 8), poison()) {}
+    int64_t &w(int i, int j) { return v[(size_t)i * m1 + j]; }
+    int64_t r(int i, int j) const {
+        int64_t x = v[(size_t)i * m1 + j];
+        if (x == poison()) { fprintf(stderr, "oracle: stale DP cell read (%d,%d)\n", i, j); abort(); }
+        return x;
+    }
+};
+inline int64_t min3(int64_t a, int64_t b, int64_t c) { return std::min(std::min(a, b), c); }
+inline int64_t max3(int64_t a, int64_t b, int64_t c) { return std::max(std::max(a, b), c); }
+
+// Alignment::global_alignment / _reverse, src/align.cpp:166-212
+void global_alignment(Mat &dp, const uint8_t *s, int n, const uint8_t *t, int m, bool rev) {
+    for (int i = 0; i <= n; i++) dp.w(i, 0) = i;
+    for (int j = 0; j <= m; j++) dp.w(0, j) = j;
+    for (int i = 1; i <= n; i++)
+        for (int j = 1; j <= m; j++) {
+            int d = rev ? diff_ch(s[n - i], t[m - j]) : diff_ch(s[i - 1], t[j - 1]);
+            dp.w(i, j) = min3(dp.r(i - 1, j - 1) + d, dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
+        }
+}
+// Alignment::global_one_side_banded_alignment, src/align.cpp:219-252
+int global_one_side_banded_alignment(const uint8_t *s, int n, const uint8_t *t, int m, int w) {
+    Mat dp(std::max(n, 0) + w + 2, std::max(m, 0) + w + 2);
+    if (w < 0 || n <= w) {
+        global_alignment(dp, s, n, t, m, false);
+        return (int)dp.r(n, m);
+    }
+    int i, j;
+    j = 0;
+    for (i = 1; i <= n; i++) dp.w(i, j++) = DPTINF;
+    i = 0;
+    for (j = w + 1; j <= m; j++) dp.w(i++, j) = DPTINF;
+    for (j = 0; j <= w; j++) dp.w(0, j) = j;
+    for (i = 1; i <= n; i++)
+        for (j = i; j <= i + w; j++)
+            dp.w(i, j) = min3(dp.r(i - 1, j - 1) + diff_ch(s[i - 1], t[j - 1]), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
+    return (int)dp.r(n, m);
+}
+// Alignment::global_banded_alignment / _reverse, src/align.cpp:395-509
+void global_banded_alignment(Mat &dp, const uint8_t *s, int n, const uint8_t *t, int m, int w, bool rev) {
+    if (w < 0 || n <= 2 * w || m <= w) {
+        global_alignment(dp, s, n, t, m, rev);
+        return;
+    }
+    auto D = [&](int i, int j) { return rev ? diff_ch(s[n - i], t[m - j]) : diff_ch(s[i - 1], t[j - 1]); };
+    int i, j;
+    j = 0;
+    for (i = w + 1; i <= n; i++) dp.w(i, j++) = DPTINF;
+    i = 0;
+    for (j = w + 1; j <= m; j++) dp.w(i++, j) = DPTINF;
+    for (i = 0; i <= w; i++) { dp.w(i, 0) = i; dp.w(0, i) = i; }
+    for (j = 1; j <= w; j++)
+        for (i = 1; i <= j + w; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
+    for (j = w + 1; j <= n - w; j++)
+        for (i = j - w; i <= j + w; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
+    for (j = n - w + 1; j <= m; j++)
+        for (i = j - w; i <= n; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
+}
+// Alignment::local_alignment_right / _left, src/align.cpp:556-600
+int local_alignment_side(const Ctx &c, const uint8_t *s, int n, const uint8_t *t, int m, int &indel, int &align_score, bool rev) {
+    const int max_indel = c.P.band;
+    const uint32_t max_edit = (uint32_t)c.P.max_ed;
+    Mat dp(std::max(n, m) + 2 * c.P.band + 4, std::max(n, m) + 2 * c.P.band + 4);
+    global_banded_alignment(dp, s, n, t, m, c.P.band, rev);
+    AlignCandid best((int)max_edit + 1, c.P.max_sc + 1, max_indel + 1);
+    for (int i = std::max(0, m - max_indel); i <= std::min(m + max_indel, n); i++) {
+        int64_t v = dp.r(i, m);
+        if ((uint32_t)v <= max_edit) best.update(AlignCandid((int)v, 0, m - i));
+    }
+    align_score = -1 * best.ed;
+    indel = best.indel;
+    return best.ed;
+}
+// Alignment::global_banded_alignment_drop, src/align.cpp:254-390
+void global_banded_alignment_drop(Mat &dpx, const uint8_t *s, int n, const uint8_t *t, int m, int w, int &on_s, int &on_t) {
+    int32_t pre_optimum = 0, cur_optimum = 0;
+    int i, j, k;
+    j = 0;
+    for (i = w + 1; i <= n; i++) dpx.w(i, j++) = -DPTINF;
+    i = 0;
+    for (j = w + 1; j <= m; j++) dpx.w(i++, j) = -DPTINF;
+    for (i = 0; i <= w; i++) { dpx.w(i, 0) = i * SC_IND; dpx.w(0, i) = i * SC_IND; }
+    on_s = 0;
+    on_t = 0;
+    if (m <= 0 || n <= 0) return;
+    int lb = 1, ub = 1;
+    int new_ub, pre_ub = 0, best_i = 0, best_j = 0;
+    for (k = 2; k <= m + n; ++k) {
+        new_ub = -1;
+        for (i = lb; i <= ub; ++i) {
+            j = k - i;
+            int64_t v = max3(dpx.r(i - 1, j - 1) + score_ch(s[i - 1], t[j - 1]), dpx.r(i - 1, j) + SC_IND, dpx.r(i, j - 1) + SC_IND);
+            dpx.w(i, j) = v;
+            cur_optimum = std::max<int32_t>(cur_optimum, (int32_t)v);
+            if (v >= cur_optimum) { cur_optimum = (int32_t)v; best_i = i; best_j = j; }
+            if (v + SC_XD < pre_optimum) dpx.w(i, j) = -DPTINF;
+            if (dpx.r(i, j) > -DPTINF) new_ub = i;
+        }
+        int lb_t = k - lb;
+        if (lb_t == m || (k > w && ((k - w) % 2 == 0))) ++lb;
+        if (ub < n && (k <= w || (k > w && ((k - w) % 2 == 1)))) ++ub;
+        if ((pre_ub == -1 && new_ub == -1) || lb > ub) break;
+        pre_ub = new_ub;
+        pre_optimum = std::max(pre_optimum, cur_optimum);
+    }
+    on_s = best_i;
+    on_t = best_j;
+}
+// DropAlignment::local_alignment_right_sc / _left_sc, src/align.cpp:669-723
+int local_alignment_sc(const Ctx &c, const uint8_t *s, int n, const uint8_t *t, int m, int &sc_len, int &indel, int &align_score, bool left) {
+    const int max_indel = c.P.band;
+    const uint32_t max_edit = (uint32_t)c.P.max_ed;
+    std::vector<uint8_t> rs, rt;
+    if (left) {   // reverse_str, src/utils.cpp:819-824
+        rs.assign(s, s + n); std::reverse(rs.begin(), rs.end());
+        rt.assign(t, t + m); std::reverse(rt.begin(), rt.end());
+        s = rs.data(); t = rt.data();
+    }
+    int on_s, on_t;
+    Mat dpx(std::max(std::max(n, m), 0) + c.P.band + 4, std::max(std::max(n, m), 0) + c.P.band + 4);
+    global_banded_alignment_drop(dpx, s, n, t, m, c.P.band, on_s, on_t);
+    int32_t score = (int32_t)dpx.r(on_s, on_t);
+    uint32_t ed = (uint32_t)((SC_MAT * std::max(on_s, on_t) - score) / (SC_MAT - SC_MIS));
+    int indel_cnt = on_t - on_s, clip = m - on_t;
+    AlignCandid best((int)max_edit + 1, std::max(c.P.max_sc, m) + 1, max_indel + 1, 0);
+    if (ed <= max_edit) {
+        AlignCandid cand((int)ed, clip, indel_cnt, score);
+        if (left) best = cand;          // best.set(...)   align.cpp:714
+        else best.update(cand);         // best.update(...) align.cpp:683
+    }
+    align_score = score;
+    sc_len = best.sclen;
+    indel = best.indel;
+    return best.ed;
+}
+
+// GenomeSeeder::pac2char, src/match_read.cpp:288-299.  start == 0 reads one byte in front of the
+// malloc'd contig string in the reference; with glibc that byte is the (zero) top byte of the
+// mmap chunk size, so strncpy yields an all-NUL window — reproduced here as zeros.
+bool pac2char(const Ctx &c, uint32_t start, int len, std::vector<uint8_t> &out) {
+    int ref_len = (int)c.X->ref_len;
+    if ((int)start < 0 || (int)start + len - 1 > ref_len) return false;
+    out.assign((size_t)std::max(len, 0) + 1, 0);
+    if (start == 0) return true;
+    for (int i = 0; i < len; ++i) out[i] = c.X->genome[start - 1 + i];
+    return true;
+}
+
+// ============================ mates / reads ============================
+struct MatchedMate {     // src/common.h:260-307, ctor src/common.cpp:147-152
+    uint32_t spos = 0, epos = 0, qspos = 0, qepos = 0;
+    int right_ed, left_ed, middle_ed;
+    int sclen_right = 0, sclen_left = 0;
+    uint32_t matched_len = 0;
+    int dir = 0;
+    int type = CM_ORPHAN;
+    uint16_t junc_num = 0;
+    bool is_concord = false, left_ok = false, right_ok = false;
+    bool looked_up_spos = false, looked_up_epos = false;
+    int exon_ind_spos = -1, exon_ind_epos = -1;
+    int exons_spos = -1, exons_epos = -1;    // interval index, -1 == NULL
+    explicit MatchedMate(const Ctx &c) : right_ed(c.P.max_ed + 1), left_ed(c.P.max_ed + 1), middle_ed(c.P.max_ed + 1) {}
+};
+
+void default_mr(const Ctx &c, cm_mapped_read &m) {   // fill_map_info else-branch, fastq_parser.cpp:243-267
+    memset(&m, 0, sizeof(m));
+    m.r1_forward = 1; m.r2_forward = 1;
+    m.ed_r1 = c.P.max_ed + 1; m.ed_r2 = c.P.max_ed + 1;
+    m.type = CM_NOPROC_NOMATCH; m.tlen = INF_I; m.chr_id = -1;
+}
+inline int ed_of(const MatchedMate &m) { return m.left_ed + m.middle_ed + m.right_ed; }
+
+// MatchedRead::go_for_update, src/common.cpp:362-411
+bool go_for_update(const cm_mapped_read &t, const MatchedMate &r1, const MatchedMate &r2, int32_t tlen, bool gm, int type) {
+    if (type < t.type) return true;
+    if (type > t.type) return false;
+    if (gm && !t.gm_compatible) return true;
+    if (!gm && t.gm_compatible) return false;
+    int edit_dist = ed_of(r1) + ed_of(r2);
+    uint32_t ml = r1.matched_len + r2.matched_len;
+    if (type < CM_CHIBSJ) {
+        if ((t.ed_r1 + t.ed_r2) > edit_dist) return true;
+        if ((t.ed_r1 + t.ed_r2) < edit_dist) return false;
+        if (t.tlen > tlen) return true;
+        if (t.tlen < tlen) return false;
+        if ((t.mlen_r1 + t.mlen_r2) < ml) return true;
+        if ((t.mlen_r1 + t.mlen_r2) > ml) return false;
+    } else {
+        if ((t.mlen_r1 + t.mlen_r2) < ml) return true;
+        if ((t.mlen_r1 + t.mlen_r2) > ml) return false;
+        if ((t.ed_r1 + t.ed_r2) > edit_dist) return true;
+        if ((t.ed_r1 + t.ed_r2) < edit_dist) return false;
+    }
+    return false;
+}
+// MatchedRead::update, src/common.cpp:286-351
+bool mr_update(const Ctx &c, cm_mapped_read &t, const MatchedMate &r1, const MatchedMate &r2, int chr_row, int32_t tlen,
+               uint16_t jun_between, bool gm, int type, bool r1_first) {
+    if (!go_for_update(t, r1, r2, tlen, gm, type)) return false;
+    uint32_t shift = c.A->chr_shift[chr_row];
+    t.type = type;
+    t.chr_id = c.A->chr_id[chr_row];
+    const MatchedMate &a = r1_first ? r1 : r2, &b = r1_first ? r2 : r1;
+    t.spos_r1 = a.spos - shift; t.epos_r1 = a.epos - shift; t.qspos_r1 = a.qspos; t.qepos_r1 = a.qepos;
+    t.mlen_r1 = a.matched_len; t.ed_r1 = ed_of(a);
+    t.spos_r2 = b.spos - shift; t.epos_r2 = b.epos - shift; t.qspos_r2 = b.qspos; t.qepos_r2 = b.qepos;
+    t.mlen_r2 = b.matched_len; t.ed_r2 = ed_of(b);
+    t.r1_forward = a.dir > 0; t.r2_forward = b.dir > 0;
+    t.tlen = tlen;
+    t.junc_num = (uint16_t)(jun_between + r1.junc_num + r2.junc_num);
+    t.gm_compatible = gm;
+    t.contig_num = c.X->contig_num;
+    return true;
+}
+bool mr_update_type(cm_mapped_read &t, int type) { if (type < t.type) { t.type = type; return true; } return false; }
+
+// ============================ A17 helpers (utils.cpp) ============================
+void update_match_mate_info(const Ctx &c, bool lok, bool rok, int err, MatchedMate &mm) {   // utils.cpp:22-32
+    mm.left_ok = lok && (mm.sclen_left <= c.P.max_sc);
+    mm.right_ok = rok && (mm.sclen_right <= c.P.max_sc);
+    if (lok && rok && (err <= c.P.max_ed) && (mm.sclen_right <= c.P.max_sc) && (mm.sclen_left <= c.P.max_sc)) {
+        mm.is_concord = true;
+        mm.type = CM_CONCRD;
+    } else if (lok || rok) mm.type = CM_CANDID;
+    else mm.type = CM_ORPHAN;
+}
+int estimate_middle_error(const Ctx &c, const Chain &ch) {   // utils.cpp:35-49
+    int mid_err = 0;
+    for (uint32_t i = 0; i + 1 < ch.chain_len; i++) {
+        if (ch.frags[i + 1].qpos > (int32_t)(ch.frags[i].qpos + ch.frags[i].len)) {
+            int diff = (int)(ch.frags[i + 1].rpos - ch.frags[i].rpos) - (ch.frags[i + 1].qpos - ch.frags[i].qpos);
+            if (diff == 0) mid_err++;
+            else if (diff > 0 && diff <= c.P.band) mid_err += diff;
+            else if (diff < 0 && diff >= -c.P.band) mid_err -= diff;
+        }
+    }
+    return mid_err;
+}
+// is_concord / is_concord2, utils.cpp:116-153
+bool is_concord_impl(const Chain &a, uint32_t seq_len, MatchedMate &mr, bool v2) {
+    if (a.chain_len < 2) {
+        mr.is_concord = false;
+    } else {
+        const Frag &l = a.frags[a.chain_len - 1];
+        if ((uint32_t)(l.qpos + l.len - a.frags[0].qpos) >= seq_len) {
+            mr.is_concord = true;
+            mr.type = CM_CONCRD;
+            mr.spos = a.frags[0].rpos;
+            mr.epos = l.rpos + l.len - 1;
+            mr.matched_len = l.qpos + l.len - a.frags[0].qpos;
+            mr.qspos = a.frags[0].qpos;
+            mr.qepos = l.qpos + l.len - 1;
+        } else {
+            mr.is_concord = false;
+            if (v2 && (a.frags[0].qpos == 0 || (uint32_t)(l.qpos + l.len) == seq_len)) mr.type = CM_CANDID;
+        }
+    }
+    return mr.is_concord;
+}
+void overlap_to_epos(const Ctx &c, MatchedMate &mr) {   // utils.cpp:667-674
+    if (mr.looked_up_epos || mr.exons_epos >= 0) return;
+    mr.exons_epos = get_location_overlap_ind(c, mr.epos, mr.exon_ind_epos);
+    mr.looked_up_epos = true;
+}
+void overlap_to_spos(const Ctx &c, MatchedMate &mr) {   // utils.cpp:676-683
+    if (mr.looked_up_spos || mr.exons_spos >= 0) return;
+    mr.exons_spos = get_location_overlap_ind(c, mr.spos, mr.exon_ind_spos);
+    mr.looked_up_spos = true;
+}
+// calc_tlen, utils.cpp:53-113
+int calc_tlen(const Ctx &c, const MatchedMate &sm, const MatchedMate &lm, int &intron_num) {
+    const cm_annot_view *A = c.A;
+    int min_tlen = INF_I;
+    for (uint32_t i = 0; i < iv_nseg(A, sm.exons_epos); i++) {
+        uint32_t sg = iv_segid(A, sm.exons_epos, i);
+        for (uint32_t j = A->seg_tid_off[sg]; j < A->seg_tid_off[sg + 1]; j++) {
+            uint32_t tid = A->seg_tid[j];
+            int start_ind = A->trans_start_ind[tid];
+            uint32_t start_table_ind = (uint32_t)(sm.exon_ind_epos - start_ind);   // unsigned: "< 0" never true
+            uint32_t end_table_ind = (uint32_t)(lm.exon_ind_spos - start_ind);
+            uint32_t tsz = A->t2s_off[tid + 1] - A->t2s_off[tid];
+            const uint8_t *t2s = A->t2s + A->t2s_off[tid];
+            if (lm.exon_ind_spos < start_ind || end_table_ind >= tsz || t2s[end_table_ind] == 0) continue;
+            int in, tlen;
+            if (start_table_ind == end_table_ind) {
+                in = 0;
+                tlen = (int)(lm.spos - sm.epos + 1);
+            } else {
+                bool pre_zero = false;
+                in = 0;
+                tlen = (int)(A->iv_epos[sm.exons_epos] - sm.epos + 1);
+                int this_it_ind = sm.exon_ind_epos;
+                for (uint32_t k = start_table_ind + 1; k < end_table_ind; k++) {
+                    this_it_ind++;
+                    if (t2s[k] != 0) {
+                        tlen += (int)(A->iv_epos[this_it_ind] - A->iv_spos[this_it_ind] + 1);
+                        pre_zero = false;
+                    } else {
+                        if (!pre_zero) in++;
+                        pre_zero = true;
+                    }
+                }
+                tlen += (int)(lm.spos - A->iv_spos[lm.exons_spos] + 1);
+            }
+            if (tlen < min_tlen) { intron_num = in; min_tlen = tlen; }
+        }
+    }
+    return (min_tlen == INF_I) ? -1 : (int)(min_tlen + sm.matched_len - 1 + lm.matched_len - 1);
+}
+bool seg_same_exon(const cm_annot_view *A, uint32_t a, uint32_t b) { return A->seg_start[a] == A->seg_start[b] && A->seg_end[a] == A->seg_end[b]; }
+bool same_gene_mm(const Ctx &c, const MatchedMate &mm, const MatchedMate &other) {   // utils.cpp:629-639
+    const cm_annot_view *A = c.A;
+    for (uint32_t i = 0; i < iv_nseg(A, mm.exons_spos); i++) {
+        uint32_t g = A->seg_gene_id[iv_segid(A, mm.exons_spos, i)];
+        if (A->gene_start[g] <= other.spos && other.epos <= A->gene_end[g]) return true;
+    }
+    return false;
+}
+bool same_gene_iv(const Ctx &c, int mate_iv, uint32_t s, uint32_t e) {   // utils.cpp:617-627
+    const cm_annot_view *A = c.A;
+    for (uint32_t i = 0; i < iv_nseg(A, mate_iv); i++) {
+        uint32_t g = A->seg_gene_id[iv_segid(A, mate_iv, i)];
+        if (A->gene_start[g] <= s && e <= A->gene_end[g]) return true;
+    }
+    return false;
+}
+// same_transcript (2-interval form) + intersect_trans, utils.cpp:322-354
+bool same_transcript(const Ctx &c, int s, int r, std::vector<uint32_t> &common_tid) {
+    common_tid.clear();
+    if (s < 0 || r < 0) return false;
+    const cm_annot_view *A = c.A;
+    std::vector<uint32_t> t1, t2;
+    for (uint32_t i = 0; i < iv_nseg(A, s); i++) { uint32_t g = iv_segid(A, s, i); for (uint32_t k = A->seg_tid_off[g]; k < A->seg_tid_off[g + 1]; k++) t1.push_back(A->seg_tid[k]); }
+    for (uint32_t i = 0; i < iv_nseg(A, r); i++) { uint32_t g = iv_segid(A, r, i); for (uint32_t k = A->seg_tid_off[g]; k < A->seg_tid_off[g + 1]; k++) t2.push_back(A->seg_tid[k]); }
+    for (uint32_t a : t1)
+        for (uint32_t b : t2)
+            if (a == b) { common_tid.push_back(a); break; }
+    return !common_tid.empty();
+}
+// concordant_explanation, utils.cpp:157-213
+bool concordant_explanation(const Ctx &c, const MatchedMate &sm, const MatchedMate &lm, cm_mapped_read &mr, int chr_row, bool r1_sm, int pair_type) {
+    if (sm.spos > lm.spos) return false;
+    const cm_annot_view *A = c.A;
+    int32_t tlen;
+    bool on_cdna = (sm.exons_spos >= 0) && (sm.exons_epos >= 0) && (lm.exons_spos >= 0) && (lm.exons_epos >= 0);
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) {
+        tlen = (int32_t)(lm.spos - sm.epos - 1 + lm.matched_len + sm.matched_len);
+        if (tlen <= c.P.max_tlen) mr_update(c, mr, sm, lm, chr_row, tlen, 0, false, CM_CONGNM, r1_sm);
+        else if (tlen <= MAXDISCRDTLEN) mr_update(c, mr, sm, lm, chr_row, tlen, 0, false, CM_CONGNM, r1_sm);
+    } else {
+        for (uint32_t i = 0; i < iv_nseg(A, sm.exons_spos); i++)
+            for (uint32_t j = 0; j < iv_nseg(A, lm.exons_spos); j++)
+                if (seg_same_exon(A, iv_segid(A, sm.exons_spos, i), iv_segid(A, lm.exons_spos, j))) {
+                    tlen = (int32_t)(lm.spos + lm.matched_len - sm.spos);
+                    if (tlen <= c.P.max_tlen) mr_update(c, mr, sm, lm, chr_row, tlen, 0, on_cdna, (pair_type == 0) ? CM_CONCRD : CM_CONGEN, r1_sm);
+                    else mr_update(c, mr, sm, lm, chr_row, tlen, 0, on_cdna, CM_DISCRD, r1_sm);
+                }
+    }
+    if (sm.exons_epos < 0 || lm.exons_spos < 0) {
+        tlen = (int32_t)(lm.spos - sm.epos - 1 + sm.matched_len + lm.matched_len);
+        if (tlen <= c.P.max_tlen) mr_update(c, mr, sm, lm, chr_row, tlen, 0, false, CM_CONGNM, r1_sm);
+        else if (tlen <= MAXDISCRDTLEN) mr_update(c, mr, sm, lm, chr_row, tlen, 0, false, CM_CONGNM, r1_sm);
+    } else {
+        int intron_num = 0;   // always assigned before use: by calc_tlen when tlen >= 0, else by the tlen < 0 branch
+        tlen = calc_tlen(c, sm, lm, intron_num);
+        if (tlen >= 0 && tlen <= c.P.max_tlen) {
+            mr_update(c, mr, sm, lm, chr_row, tlen, (uint16_t)intron_num, on_cdna, (pair_type == 0) ? CM_CONCRD : CM_CONGEN, r1_sm);
+        } else {
+            if (tlen < 0) {
+                tlen = (int32_t)(lm.spos - sm.epos - 1 + sm.matched_len + lm.matched_len);
+                intron_num = 0;
+            }
+            mr_update(c, mr, sm, lm, chr_row, tlen, (uint16_t)intron_num, on_cdna, CM_DISCRD, r1_sm);
+        }
+    }
+    return mr.type == CM_CONCRD;
+}
+// check_chimeric, utils.cpp:215-231
+bool check_chimeric(const Ctx &c, const MatchedMate &sm, const MatchedMate &lm, cm_mapped_read &mr, int chr_row, bool r1_sm) {
+    if (mr.type == CM_CONCRD) return false;
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) return false;
+    const cm_annot_view *A = c.A;
+    for (uint32_t i = 0; i < iv_nseg(A, sm.exons_spos); i++)
+        for (uint32_t j = 0; j < iv_nseg(A, lm.exons_spos); j++)
+            if (A->seg_gene_id[iv_segid(A, sm.exons_spos, i)] == A->seg_gene_id[iv_segid(A, lm.exons_spos, j)] && sm.spos < lm.spos) {
+                mr_update(c, mr, sm, lm, chr_row, (int32_t)(lm.epos - sm.spos + 1), 0, false, CM_CHIORF, r1_sm);
+                return true;
+            }
+    return false;
+}
+// shared tail of check_bsj / check_2bsj, utils.cpp:242-265 / :296-319
+bool bsj_tail(const Ctx &c, MatchedMate &sm, MatchedMate &lm, cm_mapped_read &mr, int chr_row, bool r1_sm, int type) {
+    const cm_annot_view *A = c.A;
+    int32_t tl = (int32_t)(lm.epos - sm.spos + 1);
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) {
+        if ((sm.exons_spos >= 0 && same_gene_mm(c, sm, lm)) || (lm.exons_spos >= 0 && same_gene_mm(c, lm, sm))) {
+            mr_update(c, mr, sm, lm, chr_row, tl, 0, false, type, r1_sm);
+            return true;
+        }
+        // ciRNA / lariat
+        if (bit(A->intronic_bits, A->n_bits, sm.spos) && bit(A->intronic_bits, A->n_bits, lm.spos) &&
+            sm.exon_ind_spos >= 0 && lm.exon_ind_epos >= 0 && sm.exon_ind_spos == lm.exon_ind_epos &&
+            (uint32_t)(sm.spos - A->iv_epos[sm.exon_ind_spos]) <= LARIAT2BEGTH) {
+            mr_update(c, mr, sm, lm, chr_row, tl, 0, false, type, r1_sm);
+            return true;
+        }
+        return false;
+    }
+    for (uint32_t i = 0; i < iv_nseg(A, sm.exons_spos); i++)
+        for (uint32_t j = 0; j < iv_nseg(A, lm.exons_spos); j++)
+            if (A->seg_gene_id[iv_segid(A, sm.exons_spos, i)] == A->seg_gene_id[iv_segid(A, lm.exons_spos, j)]) {
+                mr_update(c, mr, sm, lm, chr_row, tl, 0, false, type, r1_sm);
+                return true;
+            }
+    return false;
+}
+bool check_bsj(const Ctx &c, MatchedMate &sm, MatchedMate &lm, cm_mapped_read &mr, int chr_row, bool r1_sm) {   // utils.cpp:235-266
+    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD) return false;
+    if (!sm.right_ok || !lm.left_ok) return false;
+    return bsj_tail(c, sm, lm, mr, chr_row, r1_sm, CM_CHIBSJ);
+}
+bool check_2bsj(const Ctx &c, MatchedMate &sm, MatchedMate &lm, cm_mapped_read &mr, int chr_row, bool r1_sm) {  // utils.cpp:270-320
+    if (mr.type < CM_CHI2BSJ) return false;
+    if (sm.spos > lm.spos) return false;
+    if (sm.right_ok && lm.right_ok && sm.spos != lm.spos) return false;
+    if (sm.left_ok && lm.left_ok && sm.epos != lm.epos) return false;
+    if (sm.left_ok && lm.right_ok) return false;
+    return bsj_tail(c, sm, lm, mr, chr_row, r1_sm, CM_CHI2BSJ);
+}
+// is_left_chain, utils.cpp:827-887
+bool is_left_chain(const Chain &a, const Chain &b, int read_length) {
+    uint32_t a_beg = a.frags[0].rpos, b_beg = b.frags[0].rpos;
+    uint32_t a_end = a.frags[a.chain_len - 1].rpos + a.frags[a.chain_len - 1].len - 1;
+    uint32_t b_end = b.frags[b.chain_len - 1].rpos + b.frags[b.chain_len - 1].len - 1;
+    bool non_overlapping = (b_beg > a_end) || (a_beg > b_end);
+    if (non_overlapping) return a_beg < b_beg;
+    uint32_t i = 0, j = 0;
+    int best_distance = INF_I, best_i = -1, best_j = -1;
+    while (i < a.chain_len && j < b.chain_len) {
+        uint32_t bj_beg = b.frags[j].rpos, ai_end = a.frags[i].rpos + a.frags[i].len - 1;
+        if (ai_end < bj_beg) {
+            int d = (int)(bj_beg - ai_end);
+            if (d < best_distance) { best_distance = d; best_i = (int)i; best_j = (int)j; }
+            ++i;
+            continue;
+        }
+        uint32_t ai_beg = a.frags[i].rpos, bj_end = b.frags[j].rpos + b.frags[j].len - 1;
+        if (bj_end < ai_beg) {
+            int d = (int)(ai_beg - bj_end);
+            if (d < best_distance) { best_distance = d; best_i = (int)i; best_j = (int)j; }
+            ++j;
+            continue;
+        }
+        best_i = (int)i;
+        best_j = (int)j;
+        break;
+    }
+    uint32_t common_bp = std::max(a.frags[best_i].rpos, b.frags[best_j].rpos);
+    int32_t a_ov = a.frags[best_i].qpos + (int32_t)(common_bp - a.frags[best_i].rpos);
+    int32_t b_ov = b.frags[best_j].qpos + (int32_t)(common_bp - b.frags[best_j].rpos);
+    if (a_ov < read_length && b_ov < read_length) return a_ov >= b_ov;
+    return a_beg < b_beg;
+}
+
+// ============================ A11-A13, A19: extension (extend.cpp) ============================
+struct AllCoord {   // src/common.h:393-402, order src/common.cpp:456-464
+    uint32_t rspos, rlen, qspos, qlen;
+    bool operator<(const AllCoord &r) const {
+        if (rspos != r.rspos) return rspos < r.rspos;
+        if (qspos != r.qspos) return qspos < r.qspos;
+        if (rlen != r.rlen) return rlen < r.rlen;
+        return qlen < r.qlen;
+    }
+};
+typedef std::map<AllCoord, AlignRes> Memo;
+
+struct Ext {
+    const Ctx &c;
+    explicit Ext(const Ctx &cc) : c(cc) {}
+    int band() const { return c.P.band; }
+
+    // extend_right_middle / extend_left_middle, extend.cpp:435-461 / :653-679
+    bool extend_middle(uint32_t pos, uint32_t exon_len, const uint8_t *qseq, uint32_t qseq_len, int ed_th, AlignRes &best,
+                       AlignRes &curr, AlignRes &exon_res, bool right) {
+        std::vector<uint8_t> ref;
+        if (!pac2char(c, right ? pos + 1 : pos - exon_len, (int)exon_len, ref)) return false;
+        int indel, sc;
+        uint32_t seq_remain = std::min<uint32_t>(exon_len + band(), qseq_len);
+        int edit_dist = local_alignment_side(c, qseq, (int)seq_remain, ref.data(), (int)exon_len, indel, sc, !right);
+        uint32_t new_pos = right ? pos + exon_len : pos - exon_len;
+        exon_res.set(new_pos, edit_dist, 0, -1 * indel, (int)exon_len - indel, sc);
+        if (curr.ed + edit_dist <= ed_th) {
+            curr.update(edit_dist, 0, new_pos, -1 * indel, (int)exon_len - indel, sc);
+            update_side(c, best, curr, right);
+            return true;
+        }
+        return false;
+    }
+    // extend_right_end / extend_left_end, extend.cpp:463-487 / :681-705
+    void extend_end(uint32_t pos, uint32_t ref_len, const uint8_t *qseq, int qseq_len, int ed_th, AlignRes &best, AlignRes &curr,
+                    AlignRes &exon_res, bool right) {
+        std::vector<uint8_t> ref;
+        if (!pac2char(c, right ? pos + 1 : pos - ref_len, (int)ref_len, ref)) return;
+        int sclen, indel, sc;
+        int edit_dist = local_alignment_sc(c, ref.data(), (int)ref_len, qseq, qseq_len, sclen, indel, sc, !right);
+        uint32_t new_pos = right ? pos + qseq_len - indel : pos - qseq_len + indel;
+        exon_res.set(new_pos, edit_dist, sclen, indel, qseq_len, sc);
+        int actual_mapped_bp = qseq_len - sclen;
+        if ((curr.ed + edit_dist <= ed_th) && (sclen <= c.P.max_sc) && (actual_mapped_bp >= sclen)) {
+            curr.update(edit_dist, sclen, new_pos, indel, qseq_len, sc);
+            if (right) update_by_score_right(best, curr);
+            else update_by_score_left(best, curr);
+        }
+    }
+    // shared "found in memo / compute" step for the middle pieces; returns false on the
+    // reference's early `return`
+    bool middle_step(Memo &memo, const AllCoord &key, uint32_t pos, uint32_t exon_len, const uint8_t *q, uint32_t qlen, int ed_th,
+                     AlignRes &best, AlignRes &curr, AlignRes &exon_res, bool right, int &indel) {
+        auto it = memo.find(key);
+        if (it != memo.end()) {
+            if (curr.ed + it->second.ed > ed_th) return false;
+            curr.update(it->second.ed, it->second.sclen, it->second.pos, it->second.indel, it->second.qcovlen, it->second.score);
+            update_side(c, best, curr, right);
+            indel = it->second.indel;
+            return true;
+        }
+        bool ok = extend_middle(pos, exon_len, q, qlen, ed_th, best, curr, exon_res, right);
+        memo.insert(std::make_pair(key, exon_res));
+        if (!ok) return false;
+        indel = exon_res.indel;
+        return true;
+    }
+    void end_step(Memo &memo, const AllCoord &key, uint32_t pos, uint32_t ref_len, const uint8_t *q, int qlen, int ed_th,
+                  AlignRes &best, AlignRes &curr, AlignRes &exon_res, bool right) {
+        auto it = memo.find(key);
+        if (it != memo.end()) {
+            int actual = it->second.qcovlen - it->second.sclen;
+            if ((curr.ed + it->second.ed > ed_th) || (it->second.sclen > c.P.max_sc) || (actual < it->second.sclen)) return;
+            curr.update(it->second.ed, it->second.sclen, it->second.pos, it->second.indel, it->second.qcovlen, it->second.score);
+            if (right) update_by_score_right(best, curr);
+            else update_by_score_left(best, curr);
+        } else {
+            extend_end(pos, ref_len, q, qlen, ed_th, best, curr, exon_res, right);
+            memo.insert(std::make_pair(key, exon_res));
+        }
+    }
+
+    // extend_right_trans, extend.cpp:490-650
+    void extend_right_trans(uint32_t tid, uint32_t pos, int ref_len, const uint8_t *qseq, int qseq_len, int ed_th, uint32_t ub,
+                            AlignRes &best, bool &consecutive, Memo &memo) {
+        const cm_annot_view *A = c.A;
+        consecutive = false;
+        AlignRes curr(ub), exon_res(ub);
+        int it_ind;
+        int it_seg = get_location_overlap_ind(c, pos, it_ind);
+        int covered = 0;
+        if (it_seg < 0) return;
+        int it_ind_start = A->trans_start_ind[tid];
+        int rel_ind = it_ind - it_ind_start;
+        uint32_t tsz = A->t2s_off[tid + 1] - A->t2s_off[tid];
+        const uint8_t *t2s = A->t2s + A->t2s_off[tid];
+        uint32_t rspos = pos;
+        int exon_len = (int)(A->iv_epos[it_seg] - pos);
+        int remain_ref_len = ref_len;
+        int indel;
+        for (unsigned int i = (unsigned int)(rel_ind + 1); i < tsz; i++) {
+            if (exon_len >= qseq_len - covered) break;
+            if (t2s[i] == 1) {
+                indel = 0;
+                if (exon_len > 0) {
+                    if (rspos + exon_len > ub) return;
+                    uint32_t rq = (uint32_t)std::min(exon_len + band(), qseq_len - covered);
+                    AllCoord key{rspos, (uint32_t)exon_len, (uint32_t)covered, rq};
+                    if (!middle_step(memo, key, rspos, (uint32_t)exon_len, qseq + covered, rq, ed_th, best, curr, exon_res, true, indel)) return;
+                }
+                remain_ref_len -= exon_len;
+                covered += exon_len + indel;
+                exon_len = 0;
+                it_seg = iv_get_node(A, (int)i + it_ind_start);
+                rspos = A->iv_spos[it_seg] - 1;
+            }
+            if (t2s[i] != 0) {
+                it_seg = iv_get_node(A, (int)i + it_ind_start);
+                exon_len += (int)(A->iv_epos[it_seg] - A->iv_spos[it_seg] + 1);
+            }
+        }
+        if ((exon_len > 0) && (exon_len < qseq_len - covered) && (rspos + exon_len <= ub)) {
+            uint32_t rq = (uint32_t)std::min(exon_len + band(), qseq_len - covered);
+            AllCoord key{rspos, (uint32_t)exon_len, (uint32_t)covered, rq};
+            middle_step(memo, key, rspos, (uint32_t)exon_len, qseq + covered, rq, ed_th, best, curr, exon_res, true, indel);
+            return;
+        }
+        if (covered >= qseq_len || (rspos + qseq_len - covered > ub) || (exon_len < qseq_len - covered)) return;
+        consecutive = (rspos == pos);
+        remain_ref_len = std::min(remain_ref_len, exon_len);
+        AllCoord key{rspos, (uint32_t)remain_ref_len, (uint32_t)covered, (uint32_t)(qseq_len - covered)};
+        end_step(memo, key, rspos, (uint32_t)remain_ref_len, qseq + covered, qseq_len - covered, ed_th, best, curr, exon_res, true);
+    }
+
+    // extend_left_trans, extend.cpp:707-875
+    void extend_left_trans(uint32_t tid, uint32_t pos, int ref_len, const uint8_t *qseq, int qseq_len, int ed_th, uint32_t lb,
+                           AlignRes &best, bool &consecutive, Memo &memo) {
+        const cm_annot_view *A = c.A;
+        consecutive = false;
+        AlignRes curr(lb), exon_res(lb);
+        int it_ind;
+        int covered = 0;
+        int it_seg = get_location_overlap_ind(c, pos, it_ind);
+        if (it_seg < 0) return;
+        int it_ind_start = A->trans_start_ind[tid];
+        int rel_ind = it_ind - it_ind_start;
+        const uint8_t *t2s = A->t2s + A->t2s_off[tid];
+        // NOTE: the reference indexes trans2seg[tid][i] for i = rel_ind..0 without a size check; a
+        // rel_ind beyond the table is an out-of-bounds vector read there.  Clamp = treat as 0.
+        uint32_t tsz = A->t2s_off[tid + 1] - A->t2s_off[tid];
+        uint32_t lepos = pos;
+        int exon_len = 0;
+        int remain_ref_len = ref_len;
+        int indel;
+        bool first_seg = true;
+        for (int i = rel_ind; i >= 0; i--) {
+            uint8_t st = ((uint32_t)i < tsz) ? t2s[i] : 0;
+            if (st != 0) {
+                it_seg = iv_get_node(A, i + it_ind_start);
+                if (first_seg) {
+                    exon_len = (int)(pos - A->iv_spos[it_seg]);
+                    first_seg = false;
+                } else {
+                    if (exon_len == 0) lepos = A->iv_epos[it_seg] + 1;
+                    exon_len += (int)(A->iv_epos[it_seg] - A->iv_spos[it_seg] + 1);
+                }
+            }
+            if (exon_len >= qseq_len - covered) break;
+            if (st == 1) {
+                indel = 0;
+                if (exon_len > 0) {
+                    if (lepos < lb + exon_len) return;
+                    uint32_t rq = (uint32_t)std::min(exon_len + band(), qseq_len - covered);
+                    AllCoord key{lepos, (uint32_t)exon_len, (uint32_t)covered, rq};
+                    if (!middle_step(memo, key, lepos, (uint32_t)exon_len, qseq + qseq_len - covered - rq, rq, ed_th, best, curr, exon_res, false, indel)) return;
+                }
+                remain_ref_len -= exon_len;
+                covered += exon_len + indel;
+                exon_len = 0;
+            }
+        }
+        if ((exon_len > 0) && (exon_len < qseq_len - covered) && (lepos >= lb + exon_len)) {
+            uint32_t rq = (uint32_t)std::min(exon_len + band(), qseq_len - covered);
+            AllCoord key{lepos, (uint32_t)exon_len, (uint32_t)covered, rq};
+            middle_step(memo, key, lepos, (uint32_t)exon_len, qseq + qseq_len - covered - rq, rq, ed_th, best, curr, exon_res, false, indel);
+            return;
+        }
+        if (covered >= qseq_len || (lepos < lb + qseq_len - covered) || (exon_len < qseq_len - covered)) return;
+        consecutive = (lepos == pos);
+        remain_ref_len = std::min(remain_ref_len, exon_len);
+        AllCoord key{lepos, (uint32_t)remain_ref_len, (uint32_t)covered, (uint32_t)(qseq_len - covered)};
+        end_step(memo, key, lepos, (uint32_t)remain_ref_len, qseq, qseq_len - covered, ed_th, best, curr, exon_res, false);
+    }
+
+    // extend_right / extend_left, extend.cpp:285-432
+    bool extend_side(const std::vector<uint32_t> &common_tid, const uint8_t *seq, uint32_t &pos, int len, int ed_th, uint32_t bound,
+                     AlignRes &best, bool right) {
+        int seq_len = len, ref_len = len + band();
+        uint32_t orig_pos = pos;
+        int indel;
+        bool consecutive = false;
+        AlignRes curr(bound);
+        best.set(pos, ed_th + 1, len + 1, band() + 1, 0, 0);
+        Memo memo;
+        for (uint32_t tid : common_tid) {
+            if (right) extend_right_trans(tid, pos, ref_len, seq, seq_len, ed_th, bound, best, consecutive, memo);
+            else extend_left_trans(tid, pos, ref_len, seq, seq_len, ed_th, bound, best, consecutive, memo);
+        }
+        uint32_t best_pos = best.pos;
+        int min_ed = best.ed, sclen_best = best.sclen;
+        if (min_ed <= ed_th) {
+            pos = right ? best_pos - sclen_best : best_pos + sclen_best;
+            if (best.qcovlen >= seq_len && sclen_best <= c.P.max_sc) return true;
+        }
+        std::vector<uint8_t> ref;
+        if (!consecutive && pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) {   // intron retention
+            int sc;
+            min_ed = local_alignment_sc(c, ref.data(), ref_len, seq, seq_len, sclen_best, indel, sc, !right);
+            if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
+                uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;
+                curr.set(np, min_ed, sclen_best, indel, seq_len, sc);
+                bool upd = right ? update_by_score_right(best, curr) : update_by_score_left(best, curr);
+                if (upd) {
+                    pos = right ? np - sclen_best : np + sclen_best;
+                    return true;
+                }
+            }
+        }
+        if (best.qcovlen <= 0) {
+            pos = orig_pos;
+            best.set(pos, 0, 0, 0, 0, -INF_I);
+        }
+        int qremain = seq_len - best.qcovlen;
+        if (qremain + best.sclen <= c.P.max_sc) {
+            best.set(pos, best.ed, best.sclen + qremain, best.indel, seq_len, best.score);
+            return true;
+        }
+        return (best.qcovlen >= seq_len && best.ed <= ed_th);
+    }
+
+    // extend_chain_right / extend_chain_left, extend.cpp:215-280
+    bool extend_chain_right(const std::vector<uint32_t> &tids, const Chain &ch, const uint8_t *seq, int seq_len, uint32_t ub, MatchedMate &mr, int &err) {
+        const Frag &l = ch.frags[ch.chain_len - 1];
+        uint32_t rm_pos = l.rpos + l.len - 1;
+        int remain_end = seq_len - (int)(l.qpos + l.len);
+        bool right_ok = (remain_end <= 0);
+        AlignRes best(ub);
+        if (remain_end > 0) right_ok = extend_side(tids, seq + seq_len - remain_end, rm_pos, remain_end, c.P.max_ed - err, ub, best, true);
+        int sclen_right = best.sclen, err_right = best.ed;
+        remain_end -= best.qcovlen;
+        mr.epos = rm_pos;
+        mr.matched_len -= right_ok ? sclen_right : remain_end;
+        mr.qepos -= right_ok ? sclen_right : remain_end;
+        mr.sclen_right = sclen_right;
+        mr.right_ed = best.ed;
+        err += err_right;
+        return right_ok;
+    }
+    bool extend_chain_left(const std::vector<uint32_t> &tids, const Chain &ch, const uint8_t *seq, int32_t qspos, uint32_t lb, MatchedMate &mr, int &err) {
+        uint32_t lm_pos = ch.frags[0].rpos;
+        int remain_beg = ch.frags[0].qpos - qspos;
+        bool left_ok = (remain_beg <= 0);
+        AlignRes best(lb);
+        if (remain_beg > 0) left_ok = extend_side(tids, seq, lm_pos, remain_beg, c.P.max_ed - err, lb, best, false);
+        int sclen_left = best.sclen, err_left = best.ed;
+        remain_beg -= best.qcovlen;
+        mr.spos = lm_pos;
+        mr.matched_len -= left_ok ? sclen_left : remain_beg;
+        mr.qspos += left_ok ? sclen_left : remain_beg;
+        mr.sclen_left = sclen_left;
+        mr.left_ed = best.ed;
+        err += err_left;
+        return left_ok;
+    }
+    // calc_middle_ed, extend.cpp:878-920
+    int calc_middle_ed(const Chain &ch, int edth, const uint8_t *qseq, int qseq_len) {
+        std::vector<uint8_t> rseq((size_t)qseq_len + 4 * band() + 1, 0), tmp;   // stack buffer in the reference
+        int mid_err = 0;
+        if (ch.chain_len == 0) return 0;
+        for (uint32_t i = 0; i + 1 < ch.chain_len; i++) {
+            if (ch.frags[i + 1].qpos > (int32_t)(ch.frags[i].qpos + ch.frags[i].len)) {
+                int diff = (int)(ch.frags[i + 1].rpos - ch.frags[i].rpos) - (ch.frags[i + 1].qpos - ch.frags[i].qpos);
+                int32_t qspos = ch.frags[i].qpos + (int32_t)ch.frags[i].len;
+                int qlen = ch.frags[i + 1].qpos - qspos;
+                uint32_t rspos = ch.frags[i].rpos + ch.frags[i].len;
+                int rlen = qlen + diff;
+                if (rlen < 0) rlen = 0;
+                if ((diff >= 0 && diff <= band()) || (diff < 0 && diff >= -band())) {
+                    if (pac2char(c, rspos, rlen, tmp)) std::copy(tmp.begin(), tmp.end(), rseq.begin());   // failure ignored: stale buffer
+                    if (diff >= 0) mid_err += global_one_side_banded_alignment(qseq + qspos, qlen, rseq.data(), rlen, diff);
+                    else mid_err += global_one_side_banded_alignment(rseq.data(), rlen, qseq + qspos, qlen, -diff);
+                }
+                if (mid_err > edth) return edth + 1;
+            }
+        }
+        return mid_err;
+    }
+    // extend_both_mates, extend.cpp:37-125
+    bool extend_both_mates(const Chain &lch, const Chain &rch, const std::vector<uint32_t> &tids, const uint8_t *lseq, const uint8_t *rseq,
+                           int lqspos, int rqspos, int lseq_len, int rseq_len, MatchedMate &lmm, MatchedMate &rmm) {
+        const int maxEd = c.P.max_ed;
+        lmm.middle_ed = calc_middle_ed(lch, maxEd, lseq, lseq_len);
+        rmm.middle_ed = calc_middle_ed(rch, maxEd, rseq, rseq_len);
+        if (lmm.middle_ed <= maxEd) is_concord_impl(lch, (uint32_t)lseq_len, lmm, true);
+        if (rmm.middle_ed <= maxEd) is_concord_impl(rch, (uint32_t)rseq_len, rmm, true);
+        if (lmm.middle_ed > maxEd || rmm.middle_ed > maxEd) return false;
+        bool l_extend = true, r_extend = true;
+        lmm.is_concord = false;
+        if (lch.chain_len <= 0) { lmm.type = CM_ORPHAN; lmm.matched_len = 0; l_extend = false; }
+        rmm.is_concord = false;
+        if (rch.chain_len <= 0) { rmm.type = CM_ORPHAN; rmm.matched_len = 0; r_extend = false; }
+        bool llok = false, lrok = false, rlok = false, rrok = false;
+        int lerr = lmm.middle_ed, rerr = rmm.middle_ed;
+        if (l_extend) {
+            lmm.matched_len = (uint32_t)(lseq_len - lqspos + 1);
+            lmm.qspos = (uint32_t)lqspos;
+            lmm.qepos = (uint32_t)lseq_len;
+            llok = extend_chain_left(tids, lch, lseq, lqspos - 1, MINLB, lmm, lerr);
+        }
+        if (r_extend) {
+            rmm.matched_len = (uint32_t)(rseq_len - rqspos + 1);
+            rmm.qspos = (uint32_t)rqspos;
+            rmm.qepos = (uint32_t)rseq_len;
+            rlok = extend_chain_left(tids, rch, rseq, rqspos - 1, l_extend ? lmm.spos : MINLB, rmm, rerr);
+        }
+        if (r_extend) rrok = extend_chain_right(tids, rch, rseq, rseq_len, MAXUB, rmm, rerr);
+        if (l_extend) lrok = extend_chain_right(tids, lch, lseq, lseq_len, r_extend ? rmm.epos : MAXUB, lmm, lerr);
+        if (l_extend) update_match_mate_info(c, llok, lrok, lerr, lmm);
+        if (r_extend) update_match_mate_info(c, rlok, rrok, rerr, rmm);
+        return true;
+    }
+    // extend_chain_both_sides, extend.cpp:131-213
+    int extend_chain_both_sides(const Chain &ch, const uint8_t *seq, int seq_len, MatchedMate &mr, int dir) {
+        const int maxEd = c.P.max_ed;
+        mr.is_concord = false;
+        if (ch.chain_len <= 0) { mr.type = CM_ORPHAN; return mr.type; }
+        mr.middle_ed = estimate_middle_error(c, ch);
+        if (is_concord_impl(ch, (uint32_t)seq_len, mr, false)) { mr.dir = dir; return mr.type; }
+        uint32_t lm_pos = ch.frags[0].rpos;
+        int remain_beg = ch.frags[0].qpos;
+        bool left_ok = (remain_beg <= 0);
+        AlignRes bl(MINLB);
+        std::vector<uint32_t> empty;
+        if (remain_beg > 0) left_ok = extend_side(empty, seq, lm_pos, remain_beg, maxEd - mr.middle_ed, MINLB, bl, false);
+        int err_left = bl.ed, sclen_left = bl.sclen;
+        remain_beg -= bl.qcovlen;
+        const Frag &l = ch.frags[ch.chain_len - 1];
+        uint32_t rm_pos = l.rpos + l.len - 1;
+        int remain_end = seq_len - (int)(l.qpos + l.len);
+        bool right_ok = (remain_end <= 0);
+        AlignRes br(MAXUB);
+        if (remain_end > 0) right_ok = extend_side(empty, seq + seq_len - remain_end, rm_pos, remain_end, maxEd - mr.middle_ed - err_left, MAXUB, br, true);
+        int err_right = br.ed, sclen_right = br.sclen;
+        remain_end -= br.qcovlen;
+        mr.spos = lm_pos;
+        mr.epos = rm_pos;
+        mr.matched_len = (uint32_t)seq_len;
+        mr.matched_len -= left_ok ? sclen_left : remain_beg;
+        mr.matched_len -= right_ok ? sclen_right : remain_end;
+        mr.qspos = (uint32_t)(1 + (left_ok ? sclen_left : remain_beg));
+        mr.qepos = (uint32_t)(seq_len - (right_ok ? sclen_right : remain_end));
+        mr.right_ed = br.ed;
+        mr.left_ed = bl.ed;
+        mr.dir = dir;
+        if (left_ok && right_ok && (err_left + err_right <= maxEd) && sclen_left <= c.P.max_sc && sclen_right <= c.P.max_sc) {
+            mr.is_concord = true;
+            mr.type = CM_CONCRD;
+        } else if (left_ok || right_ok) mr.type = CM_CANDID;
+        else mr.type = CM_ORPHAN;
+        return mr.type;
+    }
+};
+
+// ============================ A8-A10: the per-pair controller (filter.cpp) ============================
+struct Rec { const uint8_t *seq; std::vector<uint8_t> rc; int seq_len; };
+
+struct MatePair { int type; int fi, rj; std::vector<uint32_t> common_tid; };
+
+// FilterRead::pair_chains, filter.cpp:484-551
+void pair_chains(const Ctx &c, const ChainList &fwd, const ChainList &rev, std::vector<MatePair> &mate_pairs, std::vector<char> &fp,
+                 std::vector<char> &rp, int saved_type) {
+    std::vector<int> fe_list(fwd.best_chain_count), re_list(rev.best_chain_count);
+    for (int i = 0; i < fwd.best_chain_count; i++) fe_list[i] = get_location_overlap(c, fwd.chains[i].frags[0].rpos);
+    for (int j = 0; j < rev.best_chain_count; j++) re_list[j] = get_location_overlap(c, rev.chains[j].frags[0].rpos);
+    mate_pairs.clear();
+    fp.assign(c.P.max_chain_len, 0);
+    rp.assign(c.P.max_chain_len, 0);
+    for (int i = 0; i < fwd.best_chain_count; i++)
+        for (int j = 0; j < rev.best_chain_count; j++) {
+            const Chain &F = fwd.chains[i], &R = rev.chains[j];
+            uint32_t fs = F.frags[0].rpos, rs = R.frags[0].rpos;
+            uint32_t fe = F.frags[F.chain_len - 1].rpos + F.frags[F.chain_len - 1].len;
+            uint32_t re = R.frags[R.chain_len - 1].rpos + R.frags[R.chain_len - 1].len;
+            int tlen = (int)((fs < rs) ? (re - fs) : (fe - rs));
+            MatePair temp;
+            bool same_tr = false, same_gen = false;
+            if (fe_list[i] >= 0 && re_list[j] >= 0) same_tr = same_transcript(c, fe_list[i], re_list[j], temp.common_tid);
+            if (!same_tr && fe_list[i] >= 0 &&
+                ((c.P.scan_level == 0 && saved_type > CM_CONGEN) || (c.P.scan_level > 0 && saved_type >= CM_CONGEN)))
+                same_gen = same_gene_iv(c, fe_list[i], rs, re);
+            if (!same_gen && re_list[j] >= 0 && saved_type >= CM_CONGEN) same_gen = same_gene_iv(c, re_list[j], fs, fe);
+            if (same_tr || same_gen || ((tlen <= MAXDISCRDTLEN) && (saved_type >= CM_CONGNM))) {
+                temp.fi = i;
+                temp.rj = j;
+                temp.type = same_tr ? 0 : (same_gen ? 1 : 2);
+                mate_pairs.push_back(temp);
+                fp[i] = 1;
+                rp[j] = 1;
+            }
+        }
+}
+
+// FilterRead::process_mates, filter.cpp:244-395
+int process_mates(const Ctx &c, Ext &ext, const ChainList &fwd, const Rec &frec, const ChainList &bwd, const Rec &brec, cm_mapped_read &mr,
+                  bool r1_forward) {
+    std::vector<MatePair> mate_pairs;
+    std::vector<char> fpaired, bpaired;
+    pair_chains(c, fwd, bwd, mate_pairs, fpaired, bpaired, mr.type);
+    int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN;
+    bool r1_genic = false, r2_genic = false;
+    for (size_t i = 0; i < mate_pairs.size(); i++) {
+        MatchedMate r1_mm(c), r2_mm(c);
+        r1_mm.dir = 1;
+        r2_mm.dir = -1;
+        const Chain &F = fwd.chains[mate_pairs[i].fi], &R = bwd.chains[mate_pairs[i].rj];
+        bool success;
+        bool is_forward_left = is_left_chain(F, R, frec.seq_len);
+        if (is_forward_left) {
+            success = ext.extend_both_mates(F, R, mate_pairs[i].common_tid, frec.seq, brec.rc.data(), 1, 1, frec.seq_len, brec.seq_len, r1_mm, r2_mm);
+            if (success) {
+                int row = get_shift(c, r1_mm.spos);
+                overlap_to_epos(c, r1_mm); overlap_to_spos(c, r1_mm);
+                overlap_to_epos(c, r2_mm); overlap_to_spos(c, r2_mm);
+                if (r1_mm.type == CM_CONCRD && r2_mm.type == CM_CONCRD) {
+                    if (concordant_explanation(c, r1_mm, r2_mm, mr, row, r1_forward, mate_pairs[i].type) && c.P.scan_level == 0) return CM_CONCRD;
+                } else if ((r1_mm.type == CM_CANDID && r2_mm.type == CM_CONCRD) || (r1_mm.type == CM_CONCRD && r2_mm.type == CM_CANDID)) {
+                    check_bsj(c, r1_mm, r2_mm, mr, row, r1_forward);
+                } else if (r1_mm.type == CM_CANDID && r2_mm.type == CM_CANDID) {
+                    check_2bsj(c, r1_mm, r2_mm, mr, row, r1_forward);
+                }
+            }
+        } else {
+            success = ext.extend_both_mates(R, F, mate_pairs[i].common_tid, brec.rc.data(), frec.seq, 1, 1, brec.seq_len, frec.seq_len, r2_mm, r1_mm);
+            if (success) {
+                int row = get_shift(c, r2_mm.spos);
+                overlap_to_epos(c, r1_mm); overlap_to_spos(c, r1_mm);
+                overlap_to_epos(c, r2_mm); overlap_to_spos(c, r2_mm);
+                if (r1_mm.type == CM_CONCRD && r2_mm.type == CM_CONCRD) {
+                    check_chimeric(c, r2_mm, r1_mm, mr, row, !r1_forward);
+                } else if ((r1_mm.type == CM_CANDID && r2_mm.type == CM_CONCRD) || (r1_mm.type == CM_CONCRD && r2_mm.type == CM_CANDID)) {
+                    check_bsj(c, r2_mm, r1_mm, mr, row, !r1_forward);
+                } else if (r1_mm.type == CM_CANDID && r2_mm.type == CM_CANDID) {
+                    check_2bsj(c, r2_mm, r1_mm, mr, row, !r1_forward);
+                }
+            }
+        }
+        min_ret1 = std::min(r1_mm.type, min_ret1);
+        min_ret2 = std::min(r2_mm.type, min_ret2);
+        r1_genic = (r1_mm.exons_spos >= 0) || (r1_mm.exons_epos >= 0);
+        r2_genic = (r2_mm.exons_spos >= 0) || (r2_mm.exons_epos >= 0);
+    }
+    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return mr.type;
+    MatchedMate mm1(c);     // NOT reset between chains: the looked_up_* caches go stale exactly as in the reference
+    if (min_ret1 != CM_CONCRD)
+        for (int i = 0; i < fwd.best_chain_count; i++)
+            if (!fpaired[i]) {
+                int ex_ret = ext.extend_chain_both_sides(fwd.chains[i], frec.seq, frec.seq_len, mm1, 1);
+                min_ret1 = std::min(ex_ret, min_ret1);
+                overlap_to_spos(c, mm1); overlap_to_epos(c, mm1);
+                r1_genic = (mm1.exons_spos >= 0) || (mm1.exons_epos >= 0);
+            }
+    MatchedMate mm2(c);
+    if (min_ret2 != CM_CONCRD)
+        for (int i = 0; i < bwd.best_chain_count; i++)
+            if (!bpaired[i]) {
+                int ex_ret = ext.extend_chain_both_sides(bwd.chains[i], brec.rc.data(), brec.seq_len, mm2, -1);
+                min_ret2 = std::min(ex_ret, min_ret2);
+                overlap_to_spos(c, mm2); overlap_to_epos(c, mm2);
+                r2_genic = (mm2.exons_spos >= 0) || (mm2.exons_epos >= 0);
+            }
+    int new_type = (((min_ret1 == CM_ORPHAN) && (min_ret2 == CM_CONCRD)) || ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_ORPHAN))) ? CM_OEANCH
+                 : ((min_ret1 == CM_ORPHAN) || (min_ret2 == CM_ORPHAN)) ? CM_ORPHAN
+                 : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD) && (r1_genic && r2_genic)) ? CM_CHIFUS
+                 : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD)) ? CM_OEA2 : CM_CANDID;
+    mr_update_type(mr, new_type);
+    return mr.type;
+}
+
+void make_rec(Rec &r, const uint8_t *seq, int len) {   // FASTQParser::set_reverse_comp + set_comp, fastq_parser.cpp:141-162
+    r.seq = seq;
+    r.seq_len = len;
+    r.rc.assign((size_t)len + 1, 0);
+    for (int i = 0; i < len; ++i) {
+        uint8_t ch = seq[len - 1 - i], o;
+        switch (ch) {
+            case 'A': case 'a': o = 'T'; break;
+            case 'C': case 'c': o = 'G'; break;
+            case 'G': case 'g': o = 'C'; break;
+            case 'T': case 't': o = 'A'; break;
+            case 'N': case 'n': o = 'N'; break;
+            default: o = 0; break;     // comp[] is zero-initialised static storage for other bytes
+        }
+        r.rc[i] = o;
+    }
+}
+
+struct Scratch {
+    std::vector<MatchedKmer> fl, bl;
+    ChainList fbc_r1, bbc_r1, fbc_r2, bbc_r2;
+    int fhh_r1 = 0, bhh_r1 = 0, fhh_r2 = 0, bhh_r2 = 0;
+    explicit Scratch(const Ctx &c) : fl(max_seg_cnt(c) + 2), bl(max_seg_cnt(c) + 2) {
+        for (ChainList *l : {&fbc_r1, &bbc_r1, &fbc_r2, &bbc_r2}) l->chains.resize(CM_BESTCHAINLIM);
+    }
+};
+
+// FilterRead::process_read (PE), filter.cpp:124-241
+int process_read(const Ctx &c, Scratch &S, const Rec &r1, const Rec &r2, cm_mapped_read &mr) {
+    Ext ext(c);
+    get_best_chains(c, r1.seq, r1.seq_len, S.fbc_r1, S.fl.data(), S.fhh_r1);
+    get_best_chains(c, r1.rc.data(), r1.seq_len, S.bbc_r1, S.bl.data(), S.bhh_r1);
+    get_best_chains(c, r2.seq, r2.seq_len, S.fbc_r2, S.fl.data(), S.fhh_r2);
+    get_best_chains(c, r2.rc.data(), r2.seq_len, S.bbc_r2, S.bl.data(), S.bhh_r2);
+    int n1 = S.fbc_r1.best_chain_count + S.bbc_r1.best_chain_count, n2 = S.fbc_r2.best_chain_count + S.bbc_r2.best_chain_count;
+    if (n1 + n2 <= 0) {
+        if ((S.fhh_r1 + S.bhh_r1 > 0) && (S.fhh_r2 + S.bhh_r2 > 0)) { mr_update_type(mr, CM_NOPROC_MANYHIT); return CM_NOPROC_MANYHIT; }
+        mr_update_type(mr, CM_NOPROC_NOMATCH);
+        return CM_NOPROC_NOMATCH;
+    }
+    if (n1 <= 0 || n2 <= 0) { mr_update_type(mr, CM_OEANCH); return CM_OEANCH; }
+    float fc1 = S.fbc_r1.best_chain_count > 0 ? S.fbc_r1.chains[0].score : 0;
+    float bc1 = S.bbc_r1.best_chain_count > 0 ? S.bbc_r1.chains[0].score : 0;
+    float fc2 = S.fbc_r2.best_chain_count > 0 ? S.fbc_r2.chains[0].score : 0;
+    float bc2 = S.bbc_r2.best_chain_count > 0 ? S.bbc_r2.chains[0].score : 0;
+    // float + float evaluated in float (x86-64 SSE; FLT_EVAL_METHOD 0)
+    volatile float lhs = fc1 + bc2, rhs = fc2 + bc1;
+    int a1, a2;
+    if (lhs >= rhs) {
+        a1 = process_mates(c, ext, S.fbc_r1, r1, S.bbc_r2, r2, mr, true);
+        if (c.P.scan_level == 0 && a1 == CM_CONCRD) return CM_CONCRD;
+        a2 = process_mates(c, ext, S.fbc_r2, r2, S.bbc_r1, r1, mr, false);
+        if (c.P.scan_level == 0 && a2 == CM_CONCRD) return CM_CONCRD;
+        return mr.type;
+    }
+    a1 = process_mates(c, ext, S.fbc_r2, r2, S.bbc_r1, r1, mr, false);
+    if (c.P.scan_level == 0 && a1 == CM_CONCRD) return CM_CONCRD;
+    a2 = process_mates(c, ext, S.fbc_r1, r1, S.bbc_r2, r2, mr, true);
+    if (c.P.scan_level == 0 && a2 == CM_CONCRD) return CM_CONCRD;
+    return mr.type;
+}
+
+bool mapped_type(int t) {   // filter.cpp:422-423, fastq_parser.cpp:216-219
+    return t == CM_CONCRD || t == CM_DISCRD || t == CM_CHIORF || t == CM_CHIBSJ || t == CM_CHI2BSJ || t == CM_CONGNM || t == CM_CONGEN;
+}
+
+void copy_chain(const Chain &s, cm_chain &d) {
+    memset(&d, 0, sizeof(d));
+    d.score = s.score;
+    d.chain_len = s.chain_len;
+    for (uint32_t i = 0; i < s.chain_len && i < CM_MAX_CHAIN_FRAGS; ++i) { d.rpos[i] = s.frags[i].rpos; d.qpos[i] = s.frags[i].qpos; }
+}
+
+}  // namespace
+
+// ============================ C entry points for tests / bench ============================
+extern "C" {
+
+// Seeds of every (pair, mate, orientation): same layout as cm_seed_batch (include/circminer_hot.h).
+int oracle_seed_batch(const cm_params *P, const cm_index_view *X, const cm_reads *R, uint32_t n_slots, uint32_t *out_start,
+                      uint32_t *out_cnt, uint32_t *out_raw) {
+    Ctx c{*P, X, nullptr};
+    std::vector<MatchedKmer> fl(max_seg_cnt(c) + 2);
+    for (uint64_t p = 0; p < R->n_pairs; ++p)
+        for (int mate = 0; mate < 2; ++mate) {
+            const uint8_t *s = mate ? R->seq2 + R->off2[p] : R->seq1 + R->off1[p];
+            int len = (int)(mate ? R->off2[p + 1] - R->off2[p] : R->off1[p + 1] - R->off1[p]);
+            Rec r;
+            make_rec(r, s, len);
+            for (int o = 0; o < 2; ++o) {
+                split_match_hash(c, o ? r.rc.data() : r.seq, len, fl.data());
+                uint64_t base = (((uint64_t)p * 2 + mate) * 2 + o) * n_slots;
+                for (uint32_t sl = 0; sl < n_slots; ++sl) {
+                    bool used = (int)(sl * 2) < max_seg_cnt(c) && (int)(sl + 1) * c.kmer() <= len;
+                    const MatchedKmer &mk = fl[sl * 2];
+                    out_start[base + sl] = (used && mk.frags >= 0) ? (uint32_t)mk.frags : 0;
+                    out_cnt[base + sl] = used ? mk.frag_count : 0;
+                    out_raw[base + sl] = used ? mk.raw : 0;
+                }
+            }
+        }
+    return 0;
+}
+
+int oracle_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, cm_chain *out_chains,
+                       int32_t *out_nchain, int32_t *out_high) {
+    Ctx c{*P, X, A};
+    Scratch S(c);
+    for (uint64_t p = 0; p < R->n_pairs; ++p)
+        for (int mate = 0; mate < 2; ++mate) {
+            const uint8_t *s = mate ? R->seq2 + R->off2[p] : R->seq1 + R->off1[p];
+            int len = (int)(mate ? R->off2[p + 1] - R->off2[p] : R->off1[p + 1] - R->off1[p]);
+            Rec r;
+            make_rec(r, s, len);
+            for (int o = 0; o < 2; ++o) {
+                int hh;
+                get_best_chains(c, o ? r.rc.data() : r.seq, len, S.fbc_r1, S.fl.data(), hh);
+                uint64_t q = ((uint64_t)p * 2 + mate) * 2 + o;
+                out_nchain[q] = S.fbc_r1.best_chain_count;
+                out_high[q] = hh;
+                for (int k = 0; k < CM_BESTCHAINLIM; ++k) {
+                    if (k < S.fbc_r1.best_chain_count) copy_chain(S.fbc_r1.chains[k], out_chains[q * CM_BESTCHAINLIM + k]);
+                    else memset(&out_chains[q * CM_BESTCHAINLIM + k], 0, sizeof(cm_chain));
+                }
+            }
+        }
+    return 0;
+}
+
+// One mapping round (map_reads, src/circminer.cpp:354-406) over pairs [p0, p1).
+// state[] is the carried MatchedRead (in/out), active[] in/out, category[] out (-1 if inactive).
+int oracle_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last,
+                     cm_mapped_read *state, uint8_t *active, int32_t *category, uint64_t p0, uint64_t p1) {
+    Ctx c{*P, X, A};
+    Scratch S(c);
+    if (P->max_chain_len > CM_BESTCHAINLIM) return CM_EINVAL;
+    for (uint64_t p = p0; p < p1 && p < R->n_pairs; ++p) {
+        if (!active[p]) { category[p] = -1; continue; }
+        Rec r1, r2;
+        make_rec(r1, R->seq1 + R->off1[p], (int)(R->off1[p + 1] - R->off1[p]));
+        make_rec(r2, R->seq2 + R->off2[p], (int)(R->off2[p + 1] - R->off2[p]));
+        cm_mapped_read &mr = state[p];
+        int st = process_read(c, S, r1, r2, mr);
+        category[p] = st;
+        bool skip = (P->scan_level == 0 && st == CM_CONCRD) ||
+                    (P->scan_level == 1 && st == CM_CONCRD && mr.gm_compatible && (mr.ed_r1 + mr.ed_r2 == 0) &&
+                     (mr.mlen_r1 + mr.mlen_r2 == (uint32_t)(r1.seq_len + r2.seq_len)));
+        bool requeue = (!is_last && !skip) || (is_last && (mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ));
+        active[p] = requeue ? 1 : 0;
+        // what the next round's fill_map_info would read back from the remain FASTQ header
+        // (filter.cpp:422-444, fastq_parser.cpp:214-267): unmapped types keep only `type`.
+        if (requeue && !is_last && !mapped_type(mr.type)) {
+            int t = mr.type;
+            default_mr(c, mr);
+            mr.type = t;
+        }
+    }
+    return 0;
+}
+
+void oracle_default_state(const cm_params *P, cm_mapped_read *state, uint8_t *active, uint64_t n) {
+    Ctx c{*P, nullptr, nullptr};
+    for (uint64_t i = 0; i < n; ++i) { default_mr(c, state[i]); active[i] = 1; }
+}
+
+// Stand-alone DP entry points (property tests of A14).
+int oracle_edit_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *indel, int *score) {
+    Ctx c{*P, nullptr, nullptr};
+    return local_alignment_side(c, s, n, t, m, *indel, *score, left != 0);
+}
+int oracle_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *sclen, int *indel, int *score) {
+    Ctx c{*P, nullptr, nullptr};
+    return local_alignment_sc(c, s, n, t, m, *sclen, *indel, *score, left != 0);
+}
+int oracle_one_side(const uint8_t *s, int n, const uint8_t *t, int m, int w) { return global_one_side_banded_alignment(s, n, t, m, w); }
+
+}  // extern "C"

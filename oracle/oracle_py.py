@@ -1,0 +1,99 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libcmoracle.so).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under circminer_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from circminer_amd import lib as cl
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_build", "libcmoracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "cm_oracle.cpp")
+    hdr = os.path.join(HERE, "..", "include", "circminer_hot.h")
+    if (not force and os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return SO
+    subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return SO
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            build()
+        L = C.CDLL(SO)
+        vp, pp = C.c_void_p, C.POINTER
+        L.oracle_seed_batch.restype = C.c_int
+        L.oracle_seed_batch.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.Reads), C.c_uint32, vp, vp, vp]
+        L.oracle_chain_batch.restype = C.c_int
+        L.oracle_chain_batch.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.AnnotView), pp(cl.Reads), vp, vp, vp]
+        L.oracle_map_round.restype = C.c_int
+        L.oracle_map_round.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.AnnotView), pp(cl.Reads), C.c_int, vp, vp, vp,
+                                       C.c_uint64, C.c_uint64]
+        L.oracle_default_state.restype = None
+        L.oracle_default_state.argtypes = [pp(cl.Params), vp, vp, C.c_uint64]
+        L.oracle_edit_side.restype = C.c_int
+        L.oracle_edit_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int)]
+        L.oracle_drop_sc.restype = C.c_int
+        L.oracle_drop_sc.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int), pp(C.c_int)]
+        L.oracle_one_side.restype = C.c_int
+        L.oracle_one_side.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def seeds(params, iv, batch, n_slots):
+    L = load()
+    k = batch.n * 4 * n_slots
+    a, b, c = (np.zeros(max(k, 1), np.uint32) for _ in range(3))
+    rc = L.oracle_seed_batch(C.byref(params), C.byref(iv), C.byref(batch.c), n_slots, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    assert rc == 0
+    return a[:k], b[:k], c[:k]
+
+
+def chains(params, iv, av, batch):
+    L = load()
+    ch = np.zeros(max(batch.n, 1) * 4 * cl.CM_BESTCHAINLIM, dtype=cl.CHAIN_DTYPE)
+    nc = np.zeros(max(batch.n, 1) * 4, np.int32)
+    hh = np.zeros(max(batch.n, 1) * 4, np.int32)
+    rc = L.oracle_chain_batch(C.byref(params), C.byref(iv), C.byref(av), C.byref(batch.c), ch.ctypes.data, nc.ctypes.data, hh.ctypes.data)
+    assert rc == 0
+    return ch[:batch.n * 4 * cl.CM_BESTCHAINLIM], nc[:batch.n * 4], hh[:batch.n * 4]
+
+
+def default_state(params, n):
+    L = load()
+    st = np.zeros(max(n, 1), dtype=cl.MAPPED_DTYPE)
+    act = np.zeros(max(n, 1), dtype=np.uint8)
+    L.oracle_default_state(C.byref(params), st.ctypes.data, act.ctypes.data, n)
+    return st[:n], act[:n]
+
+
+def map_round(params, iv, av, batch, is_last, state, active, p0=0, p1=None):
+    L = load()
+    cat = np.full(max(batch.n, 1), -1, dtype=np.int32)
+    rc = L.oracle_map_round(C.byref(params), C.byref(iv), C.byref(av), C.byref(batch.c), int(is_last), state.ctypes.data,
+                            active.ctypes.data, cat.ctypes.data, p0, batch.n if p1 is None else p1)
+    assert rc == 0, rc
+    return cat[:batch.n]
+
+
+def map_all_rounds(params, host_index, batch):
+    """Every round of `mapping()` (reference src/circminer.cpp:229-308) on the CPU oracle."""
+    st, act = default_state(params, batch.n)
+    cats = []
+    for ci in range(host_index.n_contigs):
+        last = ci == host_index.n_contigs - 1
+        cats.append(map_round(params, host_index.views[ci], host_index.annots[ci], batch, last, st, act))
+    return st, act, cats

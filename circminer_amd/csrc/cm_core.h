@@ -1,0 +1,1510 @@
+// cm_core.h — per-probe / per-problem / per-pair bodies of the MI355X mapping kernels.
+//
+// This is the product's device code.  Every function is written for one GPU lane working on flat
+// HBM-resident arrays (cm_index_view / cm_annot_view with device pointers): no heap, no STL, no
+// recursion, fixed-size private state.  The __global__ wrappers, launch geometry and the C-ABI
+// live in cm_hot.hip.  The same bodies also compile as plain C++ so that tests/ can step through
+// them on the build box, which has no GPU (tests/hostemu.cpp, never shipped or linked into
+// libcmhot.so).
+//
+// Reference semantics reproduced here (file:line of CircMiner 0.4.5, /root/reference):
+//   seeds      src/match_read.cpp:54-110,180-286 ; src/mrsfast/HashTable.c:1093-1098
+//   chaining   src/chain.cpp:13-64,73-301 ; src/gene_annotation.h:123-133 ; gene_annotation.cpp:464-533
+//   alignment  src/align.cpp:166-252 (edit), :254-390 (X-drop), :395-509 (banded), :556-600, :669-723
+//   extension  src/extend.cpp:37-125,131-432,435-875,878-920 ; src/align.h:12-153
+//   pairing    src/filter.cpp:124-395,469-551 ; src/utils.cpp:22-320,617-683,827-887
+//   ordering   src/common.cpp:286-411
+#pragma once
+#include <stdint.h>
+
+#include "circminer_hot.h"
+
+#if defined(__HIPCC__)
+#define CM_HD __host__ __device__
+#else
+#define CM_HD
+#endif
+
+namespace cmc {
+
+constexpr int INF_I = 1000000000;          // (int)INF, src/common.h:34
+constexpr uint32_t MINLB = 0u;
+constexpr uint32_t MAXUB = 4294967295u;
+constexpr int MAXDISCRDTLEN = 20000;       // src/common.h:40
+constexpr uint32_t LARIAT2BEGTH = 1000u;   // src/common.h:53
+constexpr int DPTINF = 10000000;           // src/align.cpp:12
+constexpr int SC_MAT = 1, SC_MIS = -3, SC_IND = -3, SC_XD = 8;   // score_mat.init(1,-3,-3,8), src/circminer.cpp:74
+constexpr int MAX_SEEDS = CM_MAX_CHAIN_FRAGS;   // seeds per read the device path supports
+constexpr int MAX_BAND = 8;                 // bandWidth supported by the private DP rows
+constexpr int MAX_TID = 64;                 // |common_tid| supported per mate pair
+constexpr int MEMO_N = 8;                   // memoised exon alignments per extend call
+
+enum { ERR_POOL = 1, ERR_TID = 2, ERR_SEEDS = 4, ERR_BAND = 8 };
+
+struct Core {
+    cm_params P;
+    cm_index_view X;    // device pointers
+    cm_annot_view A;    // device pointers
+};
+
+template <class T> CM_HD inline T cmin(T a, T b) { return a < b ? a : b; }
+template <class T> CM_HD inline T cmax(T a, T b) { return a > b ? a : b; }
+CM_HD inline int cabs(int a) { return a < 0 ? -a : a; }
+
+// ------------------------------------------------------------------------------------------
+// string views: reads (either orientation, any slice, optionally reversed), genome windows,
+// and the all-NUL window that pac2char(start == 0) yields in the reference.
+// ------------------------------------------------------------------------------------------
+CM_HD inline uint8_t comp_base(uint8_t ch) {      // FASTQParser::set_comp, src/fastq_parser.cpp:141-153
+    switch (ch) {
+        case 'A': case 'a': return 'T';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        case 'T': case 't': return 'A';
+        case 'N': case 'n': return 'N';
+        default: return 0;
+    }
+}
+struct SV {
+    const uint8_t *p;
+    int32_t off;
+    int32_t step;     // +1 / -1
+    int32_t mode;     // 0 plain, 1 complemented, 2 all-NUL
+    CM_HD inline uint8_t at(int i) const {
+        if (mode == 2) return 0;
+        uint8_t x = p[off + i * step];
+        return mode == 1 ? comp_base(x) : x;
+    }
+    CM_HD inline SV sub(int a) const { return SV{p, off + a * step, step, mode}; }          // view starting at a
+    CM_HD inline SV rev(int m) const { return SV{p, off + (m - 1) * step, -step, mode}; }   // first m chars reversed
+};
+struct Read {             // one mate in one orientation
+    const uint8_t *p;
+    int32_t len;
+    int32_t rc;
+    CM_HD inline SV view() const { return rc ? SV{p, len - 1, -1, 1} : SV{p, 0, 1, 0}; }
+};
+
+CM_HD inline int base_code_strict(uint8_t ch) {   // hashVal / checkSumVal alphabet: upper-case only
+    switch (ch) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
+}
+CM_HD inline int base_code_ci(uint8_t ch) {       // ScoreMatrix::init alphabet, src/align.cpp:745-759
+    switch (ch) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+CM_HD inline bool same_base(uint8_t a, uint8_t b) {
+    int x = base_code_ci(a);
+    return x >= 0 && x == base_code_ci(b);
+}
+CM_HD inline int diff_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? 0 : 1; }
+CM_HD inline int score_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? SC_MAT : SC_MIS; }
+
+// ------------------------------------------------------------------------------------------
+// K1 body: one k-mer probe (A1-A3)
+// ------------------------------------------------------------------------------------------
+struct Probe {
+    uint32_t start;     // first hit in the entry arrays
+    uint32_t raw;       // occurrences (0 == frags NULL)
+    uint32_t touches;   // binary-search element touches (algorithmic-byte counter)
+};
+CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
+    Probe r{0u, 0u, 0u};
+    const int cl = c.P.kmer - CM_WINDOW_SIZE;
+    int hv = 0, cv = 0;
+    for (int i = 0; i < CM_WINDOW_SIZE; ++i) {
+        int b = base_code_strict(s.at(qpos + i));
+        if (b < 0) return r;
+        hv = (hv << 2) | b;
+    }
+    for (int i = 0; i < cl; ++i) {
+        int b = base_code_strict(s.at(qpos + CM_WINDOW_SIZE + i));
+        if (b < 0) return r;
+        cv = (cv << 2) | b;
+    }
+    const uint32_t b0 = c.X.bucket_off[hv], b1 = c.X.bucket_off[hv + 1];
+    if (b1 == b0) return r;
+    const uint16_t *it = c.X.checksum + b0;
+    const int target = (int)(int16_t)cv;     // int16 quirk, src/match_read.cpp:77
+    uint32_t lb = 1, ub = b1 - b0, mid;
+    while (lb < ub) {
+        mid = (lb + ub) / 2;
+        ++r.touches;
+        if (target <= (int)it[mid - 1]) ub = mid;
+        else lb = mid + 1;
+    }
+    ++r.touches;
+    if (ub < lb || target != (int)it[lb - 1]) return r;
+    const uint32_t LB = lb;
+    uint32_t UB = lb;
+    ub = b1 - b0;
+    while (lb < ub) {
+        mid = (lb + ub + 1) / 2;
+        ++r.touches;
+        if (target < (int)it[mid - 1]) ub = mid - 1;
+        else lb = mid;
+    }
+    ++r.touches;
+    if (target == (int)it[lb - 1]) UB = lb;
+    r.start = b0 + (LB - 1);
+    r.raw = UB - LB + 1;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// annotation queries (A7)
+// ------------------------------------------------------------------------------------------
+CM_HD inline bool bit_at(const uint64_t *b, uint64_t n, uint64_t p) { return p < n && ((b[p >> 6] >> (p & 63)) & 1ull); }
+CM_HD inline uint32_t iv_nseg(const cm_annot_view &A, int iv) { return A.iv_seg_off[iv + 1] - A.iv_seg_off[iv]; }
+CM_HD inline uint32_t iv_segid(const cm_annot_view &A, int iv, uint32_t i) { return A.iv_seg[A.iv_seg_off[iv] + i]; }
+
+CM_HD inline int iv_find_ind(const cm_annot_view &A, uint32_t pos, int &ind) {   // interval_tree_impl.h:136-175
+    ind = -1;
+    if (pos < A.iv_spos[0]) return -1;
+    int beg = 0, end = (int)A.n_iv;
+    while (end - beg > 1) {
+        int mid = (beg + end) / 2;
+        if (pos < A.iv_spos[mid]) end = mid;
+        else beg = mid;
+    }
+    ind = end - 1;
+    if (ind < 0 || A.iv_epos[ind] < pos) return -1;
+    return ind;
+}
+CM_HD inline int overlap_ind(const Core &c, uint32_t loc, int &ind) {            // gene_annotation.cpp:555-568
+    int r = iv_find_ind(c.A, loc, ind);
+    if (r < 0 || iv_nseg(c.A, r) == 0) return -1;
+    return r;
+}
+CM_HD inline int overlap(const Core &c, uint32_t loc) { int ind; return overlap_ind(c, loc, ind); }
+
+CM_HD inline uint32_t upper_bound_lookup(const Core &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end, int &ol) {
+    const cm_annot_view &A = c.A;
+    max_end = 0;
+    int it_ind = -1;
+    int ov = iv_find_ind(A, spos, it_ind);
+    const uint32_t epos = spos + mlen - 1;
+    if (ov < 0 || iv_nseg(A, ov) == 0) {
+        ol = -1;
+        int nx = it_ind + 1;
+        max_end = ((nx < 0 || nx >= (int)A.n_iv) ? 0u : A.iv_spos[nx]) - 1u;
+        if (max_end < epos) return 0;
+        return cmin(spos + rlen + (uint32_t)c.P.max_ed, max_end - mlen + 1);
+    }
+    ol = -1;
+    uint32_t min_end = 1000000000u, max_next = 0;
+    if (epos > A.iv_epos[ov]) {
+        const uint32_t n = iv_nseg(A, ov);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t s = iv_segid(A, ov, i);
+            uint32_t e = A.seg_end[s];
+            if (e >= epos) {
+                max_end = cmax(max_end, e);
+                min_end = cmin(min_end, e);
+                max_next = cmax(max_next, A.seg_next_exon_beg[s]);
+            }
+        }
+    } else {
+        max_end = A.iv_max_end[ov];
+        min_end = A.iv_min_end[ov];
+        max_next = A.iv_max_next_exon[ov];
+    }
+    if (max_end > 0 && max_end >= epos) {
+        ol = ov;
+        if (min_end < rlen + epos && max_next != 0) return max_next + mlen - 1;
+        return max_end - mlen + 1;
+    }
+    max_end = 0;
+    ol = -1;
+    return 0;
+}
+CM_HD inline uint32_t upper_bound(const Core &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end, int &ol) {
+    if (bit_at(c.A.near_border_bits, c.A.n_bits, spos)) return upper_bound_lookup(c, spos, mlen, rlen, max_end, ol);
+    max_end = 0;
+    ol = -1;
+    return spos + rlen + (uint32_t)c.P.max_ed;
+}
+CM_HD inline int chr_row(const Core &c, uint32_t loc) {      // GTFParser::get_shift
+    uint32_t i;
+    for (i = 1; i < c.A.n_chr; ++i)
+        if (loc < c.A.chr_shift[i]) return (int)i - 1;
+    return (int)i - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 body: k-best chaining of one (read, orientation) (A6)
+// ------------------------------------------------------------------------------------------
+struct Event { double score; uint32_t cell; uint32_t pad; };
+struct ChainWork {
+    double *dp_score;                 // this problem's cells
+    int32_t *dp_prev;                 // (list << 16 | ind) or -1
+    uint8_t *pool;                    // event pool shared by the launch
+    unsigned long long pool_bytes;
+    unsigned long long *pool_cursor;
+    int *err;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+CM_HD inline unsigned long long pool_take(unsigned long long *cur, unsigned long long n) { return atomicAdd(cur, n); }
+CM_HD inline void flag_err(int *e, int bits) { atomicOr(e, bits); }
+#else
+inline unsigned long long pool_take(unsigned long long *cur, unsigned long long n) { return __sync_fetch_and_add(cur, n); }
+inline void flag_err(int *e, int bits) { __sync_fetch_and_or(e, bits); }
+#endif
+
+CM_HD inline bool check_junction(const Core &c, uint32_t s1, uint32_t s2, int ol, int kmer, int read_dist, int &trans_dist) {
+    trans_dist = INF_I;
+    if (ol < 0) return false;
+    const uint32_t e1 = s1 + kmer - 1;
+    if (s2 <= e1) return false;
+    int td2intron = -1;
+    const cm_annot_view &A = c.A;
+    const uint32_t n = iv_nseg(A, ol);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t s = iv_segid(A, ol, i);
+        const int e12end = (int)(A.seg_end[s] - e1);
+        const int beg2s2 = (int)(s2 - A.seg_next_exon_beg[s]);
+        if (e12end >= 0 && e12end < read_dist && beg2s2 + kmer < 0) td2intron = (int)(s2 - e1 - 1);
+        if (e12end < 0 || beg2s2 < 0) continue;
+        trans_dist = e12end + beg2s2;
+        if (cabs(trans_dist - read_dist) <= c.P.max_ed) return true;
+    }
+    if (td2intron != -1) {
+        trans_dist = td2intron;
+        return true;
+    }
+    trans_dist = INF_I;
+    return false;
+}
+
+// seeds: ordinal s has qpos s*kmer, hits pos[start[s] .. start[s]+cnt[s]).  Returns #chains.
+CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint32_t *start, const uint32_t *cnt,
+                             ChainWork &w, cm_chain *out) {
+    const int kmer = c.P.kmer;
+    const uint32_t max_best = (uint32_t)c.P.max_chain_len;
+    const uint32_t *POS = c.X.pos;
+    int kc = n_seeds;
+    while (kc >= 1 && cnt[kc - 1] == 0) --kc;
+    if (kc <= 0) return 0;
+    uint32_t base[MAX_SEEDS + 1];
+    base[0] = 0;
+    for (int s = 0; s < kc; ++s) base[s + 1] = base[s] + cnt[s];
+    for (uint32_t x = 0; x < base[kc]; ++x) {
+        w.dp_score[x] = (double)kmer;
+        w.dp_prev[x] = -1;
+    }
+    Event *ev = nullptr;
+    uint32_t n_ev = 0, cap_ev = 0;
+    bool lost = false;
+    uint32_t lb_ind[MAX_SEEDS];
+    uint32_t max_exon_end = 0;
+    int ol = -1;
+
+    for (int ii = kc - 2; ii >= 0; --ii) {
+        const uint32_t read_remain = (uint32_t)(seq_len - ii * kmer - kmer);
+        for (int k = 0; k < kc; ++k) lb_ind[k] = 0;
+        for (uint32_t i = 0; i < cnt[ii]; ++i) {
+            const int32_t cur_info = (int32_t)POS[start[ii] + i];
+            const uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
+            uint32_t max_lpos_lim = MAXUB;
+            double my_score = w.dp_score[base[ii] + i];
+            for (int jj = ii + 1; jj < kc; ++jj) {
+                const uint32_t pcn = cnt[jj];
+                if (pcn == 0 || lb_ind[jj] >= pcn) continue;
+                const uint32_t *pp = POS + start[jj];
+                if (cur_info + c.P.max_intron < (int32_t)pp[lb_ind[jj]]) continue;
+                while (lb_ind[jj] < pcn && (int32_t)pp[lb_ind[jj]] <= cur_info) ++lb_ind[jj];
+                if (lb_ind[jj] >= pcn) continue;
+                if (max_lpos_lim == MAXUB) max_lpos_lim = upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
+                const int distr = (jj - ii) * kmer - kmer;
+                uint32_t j = lb_ind[jj];
+                while (j < pcn && pp[j] <= max_lpos_lim) {
+                    const uint32_t pinfo = pp[j];
+                    int genome_dist, distt, trans_dist;
+                    if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
+                    else genome_dist = INF_I;
+                    if (cabs(genome_dist - distr) <= c.P.max_ed) {
+                        distt = genome_dist;
+                    } else if (check_junction(c, seg_start, pinfo, ol, kmer, distr, trans_dist)) {
+                        distt = trans_dist;
+                    } else {
+                        ++j;
+                        continue;
+                    }
+                    const int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
+                    const double beta = 0.1 * (double)(maxd - mind);
+                    const double alpha = 2e4 * (double)kmer;
+                    const double t1 = w.dp_score[base[jj] + j] + alpha;     // (prev + alpha) - beta, no contraction
+                    const double temp_score = t1 - beta;
+                    if (temp_score > my_score) {
+                        my_score = temp_score;
+                        w.dp_score[base[ii] + i] = temp_score;
+                        w.dp_prev[base[ii] + i] = (int32_t)(((uint32_t)jj << 16) | j);
+                        if (n_ev == cap_ev && !lost) {
+                            const uint32_t ncap = cap_ev ? cap_ev * 4u : 32u;
+                            const unsigned long long bytes = (unsigned long long)ncap * sizeof(Event);
+                            const unsigned long long off = pool_take(w.pool_cursor, bytes);
+                            if (off + bytes > w.pool_bytes) {
+                                lost = true;
+                                flag_err(w.err, ERR_POOL);
+                            } else {
+                                Event *ne = reinterpret_cast<Event *>(w.pool + off);
+                                for (uint32_t q = 0; q < n_ev; ++q) ne[q] = ev[q];
+                                ev = ne;
+                                cap_ev = ncap;
+                            }
+                        }
+                        if (n_ev < cap_ev) {
+                            ev[n_ev].score = temp_score;
+                            ev[n_ev].cell = ((uint32_t)ii << 16) | i;
+                            ++n_ev;
+                        }
+                    }
+                    ++j;
+                }
+            }
+        }
+    }
+
+    // back-tracking, src/chain.cpp:242-281: score groups descending, insertion order inside a group,
+    // at most max_best cells per group (the cap applied at insertion time in the reference).
+    uint32_t best_count = 0;
+    if (n_ev > 0) {
+        double best_score = ev[0].score;
+        for (uint32_t q = 1; q < n_ev; ++q) best_score = ev[q].score > best_score ? ev[q].score : best_score;
+        double cur = best_score;
+        bool have = true;
+        while (have && best_count < max_best) {
+            uint32_t in_group = 0;
+            for (uint32_t q = 0; q < n_ev && best_count < max_best; ++q) {
+                if (ev[q].score != cur) continue;
+                if (in_group >= max_best) break;
+                ++in_group;
+                int bl = (int)(ev[q].cell >> 16);
+                uint32_t bi = ev[q].cell & 0xffffu;
+                const uint32_t spos = POS[start[bl] + bi];
+                if (cur < best_score) {
+                    bool rep = false;     // repeats: rpos of any non-first fragment already emitted
+                    for (uint32_t a = 0; a < best_count && !rep; ++a)
+                        for (uint32_t b = 1; b < out[a].chain_len; ++b)
+                            if (out[a].rpos[b] == spos) { rep = true; break; }
+                    if (rep) continue;
+                }
+                cm_chain &ch = out[best_count++];
+                uint32_t n = 0;
+                while (true) {
+                    ch.rpos[n] = POS[start[bl] + bi];
+                    ch.qpos[n] = bl * kmer;
+                    ++n;
+                    const int32_t pv = w.dp_prev[base[bl] + bi];
+                    if (pv < 0) break;
+                    bl = (int)((uint32_t)pv >> 16);
+                    bi = (uint32_t)pv & 0xffffu;
+                }
+                ch.score = (float)cur;
+                ch.chain_len = n;
+            }
+            // next lower score
+            have = false;
+            double nxt = 0;
+            for (uint32_t q = 0; q < n_ev; ++q)
+                if (ev[q].score < cur && (!have || ev[q].score > nxt)) {
+                    nxt = ev[q].score;
+                    have = true;
+                }
+            cur = nxt;
+        }
+    }
+    if (best_count == 0) {      // singletons, src/chain.cpp:283-298
+        for (int ii = kc - 1; ii >= 0; --ii)
+            for (uint32_t i = 0; i < cnt[ii]; ++i) {
+                if (best_count >= max_best) break;
+                cm_chain &ch = out[best_count++];
+                ch.rpos[0] = POS[start[ii] + i];
+                ch.qpos[0] = ii * kmer;
+                ch.score = (float)w.dp_score[base[ii] + i];
+                ch.chain_len = 1;
+            }
+    }
+    return (int)best_count;
+}
+
+// ------------------------------------------------------------------------------------------
+// alignment (A14, A15)
+// ------------------------------------------------------------------------------------------
+struct AlignRes { uint32_t pos; int ed, sclen, indel, qcovlen, rcovlen, score; };
+CM_HD inline AlignRes ar_init(uint32_t p) { return AlignRes{p, 0, 0, 0, 0, 0, -INF_I}; }
+CM_HD inline void ar_set(AlignRes &a, uint32_t p, int e, int s, int i, int qc, int scr) {
+    a.pos = p; a.ed = e; a.sclen = s; a.indel = i; a.qcovlen = qc; a.rcovlen = qc - i; a.score = scr;
+}
+CM_HD inline void ar_update(AlignRes &a, int e, int s, uint32_t np, int i, int qc, int scr) {
+    a.pos = np; a.ed += e; a.sclen = s; a.indel += i; a.qcovlen += qc; a.rcovlen += qc - i; a.score = scr;
+}
+CM_HD inline bool ar_by_score(AlignRes &b, const AlignRes &r, bool right) {
+    const bool pos_better = right ? (r.pos < b.pos) : (r.pos > b.pos);
+    if (b.score < r.score || (b.score == r.score && pos_better)) {
+        ar_set(b, r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score);
+        return true;
+    }
+    return false;
+}
+CM_HD inline void ar_side(const Core &c, AlignRes &b, const AlignRes &r, bool right) {
+    bool take = false;
+    if (r.qcovlen > b.qcovlen) {
+        take = r.ed <= c.P.max_ed && r.sclen <= c.P.max_sc && 2 * (r.ed - b.ed) < (r.qcovlen - b.qcovlen);
+    } else if (r.qcovlen < b.qcovlen) {
+        take = r.ed <= c.P.max_ed && r.sclen <= c.P.max_sc && 2 * (b.ed - r.ed) >= (b.qcovlen - r.qcovlen);
+    } else {
+        const bool pos_better = right ? (r.pos < b.pos) : (r.pos > b.pos);
+        take = (r.ed < b.ed) || (r.ed == b.ed && r.sclen < b.sclen) || (r.ed == b.ed && r.sclen == b.sclen && pos_better);
+    }
+    if (take) ar_set(b, r.pos, r.ed, r.sclen, r.indel, r.qcovlen, r.score);
+}
+struct Cand { int ed, sclen, indel, score; };
+CM_HD inline bool cand_less(const Cand &a, const Cand &b) {     // AlignCandid::operator<, src/align.h:132-139
+    if (a.score != b.score) return a.score > b.score;
+    if (a.ed != b.ed) return a.ed < b.ed;
+    return cabs(a.indel) < cabs(b.indel);
+}
+
+// full Levenshtein for the tiny fallbacks (n <= 2w or m <= w, or n <= w for the one-sided form);
+// returns dp[i][m] for the rows the caller asks for through `col` (size n+1).
+constexpr int TINY = 4 * MAX_BAND + 4;
+CM_HD inline void tiny_full_dp(const SV &s, int n, const SV &t, int m, bool rev, int *col /* n+1 */) {
+    // column-rolling over j; col[i] = dp[i][j]
+    for (int i = 0; i <= n; ++i) col[i] = i;
+    for (int j = 1; j <= m; ++j) {
+        int diag = col[0];
+        col[0] = j;
+        for (int i = 1; i <= n; ++i) {
+            const int d = rev ? diff_ch(s.at(n - i), t.at(m - j)) : diff_ch(s.at(i - 1), t.at(j - 1));
+            const int v = cmin(cmin(diag + d, col[i - 1] + 1), col[i] + 1);
+            diag = col[i];
+            col[i] = v;
+        }
+    }
+}
+
+// Alignment::global_one_side_banded_alignment, src/align.cpp:219-252 (m == n + w in every call)
+CM_HD inline int one_side_banded(const SV &s, int n, const SV &t, int m, int w) {
+    if (w < 0 || n <= w) {
+        // full DP; here n <= w <= MAX_BAND, but m can be anything: roll over i instead (rows of s)
+        // dp[i][j], keep row over j? m = n + w <= 2*MAX_BAND in every reachable call.
+        int col[TINY];
+        if (n >= TINY) n = TINY - 1;
+        tiny_full_dp(s, n, t, m, false, col);
+        return col[n];
+    }
+    int prev[MAX_BAND + 3], cur[MAX_BAND + 3];     // index c+1, c = j - i in [0,w]; pads at 0 and w+2
+    for (int c = 0; c <= w; ++c) prev[c + 1] = c;  // dp[0][j] = j
+    prev[0] = DPTINF;
+    prev[w + 2] = DPTINF;
+    for (int i = 1; i <= n; ++i) {
+        cur[0] = DPTINF;                           // dp[i][i-1]
+        const uint8_t si = s.at(i - 1);
+        for (int c = 0; c <= w; ++c) {
+            const int j = i + c;
+            const int v = cmin(cmin(prev[c + 1] + diff_ch(si, t.at(j - 1)), prev[c + 2] + 1), cur[c] + 1);
+            cur[c + 1] = v;
+        }
+        cur[w + 2] = DPTINF;
+        for (int c = 0; c <= w + 2; ++c) prev[c] = cur[c];
+    }
+    return prev[(m - n) + 1];
+}
+
+// Alignment::global_banded_alignment[_reverse] + local_alignment_right/left, src/align.cpp:395-600.
+// Returns best.ed; indel / align_score as the reference.
+CM_HD inline int local_alignment_side(const Core &c, const SV &s, int n, const SV &t, int m, bool rev, int &indel, int &align_score) {
+    const int w = c.P.band;
+    const int max_edit = c.P.max_ed;
+    Cand best{max_edit + 1, c.P.max_sc + 1, w + 1, -1 * (c.P.max_sc + 1) - 2 * (max_edit + 1)};
+    if (w < 0 || n <= 2 * w || m <= w) {
+        int col[TINY];
+        int nn = n < TINY ? n : TINY - 1;
+        tiny_full_dp(s, nn, t, m, rev, col);
+        for (int i = cmax(0, m - w); i <= cmin(m + w, nn); ++i)
+            if (col[i] <= max_edit) {
+                Cand x{col[i], 0, m - i, -2 * col[i]};
+                if (cand_less(x, best)) best = x;
+            }
+    } else {
+        // column j holds rows i in [j-w, j+w]; slot k = i - j + w + 1 (pads at 0 and 2w+2)
+        int prev[2 * MAX_BAND + 3], cur[2 * MAX_BAND + 3];
+        for (int k = 0; k <= 2 * w + 2; ++k) prev[k] = DPTINF;
+        for (int i = 0; i <= w; ++i) prev[i + w + 1] = i;          // column 0: dp[i][0] = i
+        for (int j = 1; j <= m; ++j) {
+            const uint8_t tj = rev ? t.at(m - j) : t.at(j - 1);
+            cur[0] = DPTINF;
+            for (int k = 1; k <= 2 * w + 1; ++k) {
+                const int i = j + k - w - 1;
+                int v = DPTINF;
+                if (i == 0) v = (j <= w) ? j : DPTINF;                  // dp[0][j]
+                else if (i > 0 && i <= n) {
+                    const uint8_t si = rev ? s.at(n - i) : s.at(i - 1);
+                    v = cmin(cmin(prev[k] + diff_ch(si, tj), cur[k - 1] + 1), prev[k + 1] + 1);
+                }
+                cur[k] = v;
+            }
+            cur[2 * w + 2] = DPTINF;
+            for (int k = 0; k <= 2 * w + 2; ++k) prev[k] = cur[k];
+        }
+        for (int i = cmax(0, m - w); i <= cmin(m + w, n); ++i) {
+            const int v = prev[i - m + w + 1];
+            if (v <= max_edit) {
+                Cand x{v, 0, m - i, -2 * v};
+                if (cand_less(x, best)) best = x;
+            }
+        }
+    }
+    align_score = -1 * best.ed;
+    indel = best.indel;
+    return best.ed;
+}
+
+// Alignment::global_banded_alignment_drop + DropAlignment::local_alignment_{right,left}_sc,
+// src/align.cpp:254-390, 669-723.  s = reference window (n), t = read residual (m); the caller passes
+// already-reversed views for the left variant.
+CM_HD inline int local_alignment_sc(const Core &c, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
+    const int w = c.P.band;
+    const int W2 = 2 * w + 3;                       // slot = (i - j) + w + 1, pads at 0 and 2w+2
+    int d0[2 * MAX_BAND + 3], d1[2 * MAX_BAND + 3], d2[2 * MAX_BAND + 3];   // anti-diagonals k, k-1, k-2
+    int on_s = 0, on_t = 0, best_score = 0;
+    if (m > 0 && n > 0) {
+        for (int k = 0; k < W2; ++k) { d1[k] = -DPTINF; d2[k] = -DPTINF; }
+        d2[w + 1] = 0;                              // anti-diagonal 0: (0,0)
+        if (w >= 1) {                               // anti-diagonal 1: (1,0) and (0,1)
+            d1[w + 2] = SC_IND;
+            d1[w] = SC_IND;
+        }
+        int pre_optimum = 0, cur_optimum = 0;
+        int lb = 1, ub = 1, pre_ub = 0;
+        for (int k = 2; k <= m + n; ++k) {
+            for (int q = 0; q < W2; ++q) d0[q] = -DPTINF;
+            if (k <= w) {                           // boundary cells (k,0) and (0,k)
+                d0[k + w + 1] = k * SC_IND;
+                d0[w + 1 - k] = k * SC_IND;
+            }
+            int new_ub = -1;
+            for (int i = lb; i <= ub; ++i) {
+                const int j = k - i;
+                const int q = i - j + w + 1;
+                int v = cmax(cmax(d2[q] + score_ch(s.at(i - 1), t.at(j - 1)), d1[q - 1] + SC_IND), d1[q + 1] + SC_IND);
+                cur_optimum = cmax(cur_optimum, v);
+                if (v >= cur_optimum) {
+                    cur_optimum = v;
+                    on_s = i;
+                    on_t = j;
+                    best_score = v;
+                }
+                if (v + SC_XD < pre_optimum) v = -DPTINF;
+                if (v > -DPTINF) new_ub = i;
+                d0[q] = v;
+            }
+            const int lb_t = k - lb;
+            if (lb_t == m || (k > w && ((k - w) % 2 == 0))) ++lb;
+            if (ub < n && (k <= w || (k > w && ((k - w) % 2 == 1)))) ++ub;
+            if ((pre_ub == -1 && new_ub == -1) || lb > ub) break;
+            pre_ub = new_ub;
+            pre_optimum = cmax(pre_optimum, cur_optimum);
+            for (int q = 0; q < W2; ++q) { d2[q] = d1[q]; d1[q] = d0[q]; }
+        }
+    }
+    const int score = best_score;                   // dpx[on_s][on_t]; 0 when the best cell is (0,0)
+    const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
+    Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, w + 1, 0};
+    if (ed <= (uint32_t)c.P.max_ed) {
+        // right: best.update(cand) ; left: best.set(cand).  The X-drop optimum is >= 0 == best.score,
+        // and on a tie (score 0, ed 0) cand wins update() on ed, so both forms select cand.
+        Cand x{(int)ed, m - on_t, on_t - on_s, score};
+        best = x;
+    }
+    align_score = score;
+    sc_len = best.sclen;
+    indel = best.indel;
+    return best.ed;
+}
+
+// GenomeSeeder::pac2char, src/match_read.cpp:288-299
+CM_HD inline bool pac2char(const Core &c, uint32_t start, int len, SV &out) {
+    const int ref_len = (int)c.X.ref_len;
+    if ((int)start < 0 || (int)start + len - 1 > ref_len) return false;
+    if (start == 0) out = SV{c.X.genome, 0, 1, 2};
+    else out = SV{c.X.genome, (int32_t)(start - 1), 1, 0};
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// mates, chains, ordering (A15-A18)
+// ------------------------------------------------------------------------------------------
+struct MM {            // MatchedMate, src/common.h:260-307
+    uint32_t spos, epos, qspos, qepos, matched_len;
+    int right_ed, left_ed, middle_ed, sclen_right, sclen_left, dir, type;
+    int exon_ind_spos, exon_ind_epos, exons_spos, exons_epos;
+    uint16_t junc_num;
+    bool is_concord, left_ok, right_ok, looked_up_spos, looked_up_epos;
+};
+CM_HD inline MM mm_init(const Core &c) {
+    MM m;
+    m.spos = m.epos = m.qspos = m.qepos = m.matched_len = 0;
+    m.right_ed = m.left_ed = m.middle_ed = c.P.max_ed + 1;
+    m.sclen_right = m.sclen_left = 0;
+    m.dir = 0;
+    m.type = CM_ORPHAN;
+    m.exon_ind_spos = m.exon_ind_epos = -1;
+    m.exons_spos = m.exons_epos = -1;
+    m.junc_num = 0;
+    m.is_concord = m.left_ok = m.right_ok = m.looked_up_spos = m.looked_up_epos = false;
+    return m;
+}
+CM_HD inline int mm_ed(const MM &m) { return m.left_ed + m.middle_ed + m.right_ed; }
+
+struct CH {            // read-only view of one stored chain
+    const cm_chain *p;
+    int kmer;
+    CM_HD inline uint32_t len() const { return p->chain_len; }
+    CM_HD inline uint32_t rpos(uint32_t i) const { return p->rpos[i]; }
+    CM_HD inline int32_t qpos(uint32_t i) const { return p->qpos[i]; }
+    CM_HD inline uint32_t rend_excl() const { return p->rpos[p->chain_len - 1] + (uint32_t)kmer; }
+    CM_HD inline int32_t qend_excl() const { return p->qpos[p->chain_len - 1] + kmer; }
+};
+
+CM_HD inline void default_mr(const Core &c, cm_mapped_read &m) {
+    m.spos_r1 = m.spos_r2 = m.epos_r1 = m.epos_r2 = 0;
+    m.qspos_r1 = m.qspos_r2 = m.qepos_r1 = m.qepos_r2 = 0;
+    m.mlen_r1 = m.mlen_r2 = 0;
+    m.ed_r1 = m.ed_r2 = c.P.max_ed + 1;
+    m.type = CM_NOPROC_NOMATCH;
+    m.tlen = INF_I;
+    m.contig_num = 0;
+    m.chr_id = -1;
+    m.junc_num = 0;
+    m.r1_forward = 1;
+    m.r2_forward = 1;
+    m.gm_compatible = 0;
+    m.pad[0] = m.pad[1] = m.pad[2] = 0;
+}
+CM_HD inline bool mapped_type(int t) {
+    return t == CM_CONCRD || t == CM_DISCRD || t == CM_CHIORF || t == CM_CHIBSJ || t == CM_CHI2BSJ || t == CM_CONGNM || t == CM_CONGEN;
+}
+CM_HD inline bool go_for_update(const cm_mapped_read &t, const MM &r1, const MM &r2, int32_t tlen, bool gm, int type) {
+    if (type < t.type) return true;
+    if (type > t.type) return false;
+    if (gm && !t.gm_compatible) return true;
+    if (!gm && t.gm_compatible) return false;
+    const int ed = mm_ed(r1) + mm_ed(r2);
+    const uint32_t ml = r1.matched_len + r2.matched_len;
+    if (type < CM_CHIBSJ) {
+        if ((t.ed_r1 + t.ed_r2) > ed) return true;
+        if ((t.ed_r1 + t.ed_r2) < ed) return false;
+        if (t.tlen > tlen) return true;
+        if (t.tlen < tlen) return false;
+        if ((t.mlen_r1 + t.mlen_r2) < ml) return true;
+        if ((t.mlen_r1 + t.mlen_r2) > ml) return false;
+    } else {
+        if ((t.mlen_r1 + t.mlen_r2) < ml) return true;
+        if ((t.mlen_r1 + t.mlen_r2) > ml) return false;
+        if ((t.ed_r1 + t.ed_r2) > ed) return true;
+        if ((t.ed_r1 + t.ed_r2) < ed) return false;
+    }
+    return false;
+}
+CM_HD inline bool mr_update(const Core &c, cm_mapped_read &t, const MM &r1, const MM &r2, int row, int32_t tlen, int jun_between,
+                            bool gm, int type, bool r1_first) {
+    if (!go_for_update(t, r1, r2, tlen, gm, type)) return false;
+    const uint32_t shift = c.A.chr_shift[row];
+    const MM &a = r1_first ? r1 : r2;
+    const MM &b = r1_first ? r2 : r1;
+    t.type = type;
+    t.chr_id = c.A.chr_id[row];
+    t.spos_r1 = a.spos - shift; t.epos_r1 = a.epos - shift; t.qspos_r1 = a.qspos; t.qepos_r1 = a.qepos;
+    t.mlen_r1 = a.matched_len; t.ed_r1 = mm_ed(a);
+    t.spos_r2 = b.spos - shift; t.epos_r2 = b.epos - shift; t.qspos_r2 = b.qspos; t.qepos_r2 = b.qepos;
+    t.mlen_r2 = b.matched_len; t.ed_r2 = mm_ed(b);
+    t.r1_forward = a.dir > 0;
+    t.r2_forward = b.dir > 0;
+    t.tlen = tlen;
+    t.junc_num = (uint16_t)(jun_between + r1.junc_num + r2.junc_num);
+    t.gm_compatible = gm;
+    t.contig_num = c.X.contig_num;
+    return true;
+}
+CM_HD inline void mr_update_type(cm_mapped_read &t, int type) { if (type < t.type) t.type = type; }
+
+CM_HD inline void update_match_mate_info(const Core &c, bool lok, bool rok, int err, MM &mm) {
+    mm.left_ok = lok && (mm.sclen_left <= c.P.max_sc);
+    mm.right_ok = rok && (mm.sclen_right <= c.P.max_sc);
+    if (lok && rok && (err <= c.P.max_ed) && (mm.sclen_right <= c.P.max_sc) && (mm.sclen_left <= c.P.max_sc)) {
+        mm.is_concord = true;
+        mm.type = CM_CONCRD;
+    } else if (lok || rok) mm.type = CM_CANDID;
+    else mm.type = CM_ORPHAN;
+}
+CM_HD inline int estimate_middle_error(const Core &c, const CH &ch) {
+    int mid = 0;
+    for (uint32_t i = 0; i + 1 < ch.len(); ++i)
+        if (ch.qpos(i + 1) > ch.qpos(i) + ch.kmer) {
+            const int diff = (int)(ch.rpos(i + 1) - ch.rpos(i)) - (ch.qpos(i + 1) - ch.qpos(i));
+            if (diff == 0) ++mid;
+            else if (diff > 0 && diff <= c.P.band) mid += diff;
+            else if (diff < 0 && diff >= -c.P.band) mid -= diff;
+        }
+    return mid;
+}
+CM_HD inline bool is_concord_impl(const CH &a, uint32_t seq_len, MM &mr, bool v2) {
+    if (a.len() < 2) {
+        mr.is_concord = false;
+    } else if ((uint32_t)(a.qend_excl() - a.qpos(0)) >= seq_len) {
+        mr.is_concord = true;
+        mr.type = CM_CONCRD;
+        mr.spos = a.rpos(0);
+        mr.epos = a.rend_excl() - 1;
+        mr.matched_len = (uint32_t)(a.qend_excl() - a.qpos(0));
+        mr.qspos = (uint32_t)a.qpos(0);
+        mr.qepos = (uint32_t)(a.qend_excl() - 1);
+    } else {
+        mr.is_concord = false;
+        if (v2 && (a.qpos(0) == 0 || (uint32_t)a.qend_excl() == seq_len)) mr.type = CM_CANDID;
+    }
+    return mr.is_concord;
+}
+CM_HD inline void overlap_to_epos(const Core &c, MM &m) {
+    if (m.looked_up_epos || m.exons_epos >= 0) return;
+    m.exons_epos = overlap_ind(c, m.epos, m.exon_ind_epos);
+    m.looked_up_epos = true;
+}
+CM_HD inline void overlap_to_spos(const Core &c, MM &m) {
+    if (m.looked_up_spos || m.exons_spos >= 0) return;
+    m.exons_spos = overlap_ind(c, m.spos, m.exon_ind_spos);
+    m.looked_up_spos = true;
+}
+CM_HD inline int calc_tlen(const Core &c, const MM &sm, const MM &lm, int &intron_num) {
+    const cm_annot_view &A = c.A;
+    int min_tlen = INF_I;
+    const uint32_t ns = iv_nseg(A, sm.exons_epos);
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t sg = iv_segid(A, sm.exons_epos, i);
+        for (uint32_t j = A.seg_tid_off[sg]; j < A.seg_tid_off[sg + 1]; ++j) {
+            const uint32_t tid = A.seg_tid[j];
+            const int start_ind = A.trans_start_ind[tid];
+            const uint32_t sti = (uint32_t)(sm.exon_ind_epos - start_ind);
+            const uint32_t eti = (uint32_t)(lm.exon_ind_spos - start_ind);
+            const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
+            const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+            if (lm.exon_ind_spos < start_ind || eti >= tsz || t2s[eti] == 0) continue;
+            int in = 0, tlen;
+            if (sti == eti) {
+                tlen = (int)(lm.spos - sm.epos + 1);
+            } else {
+                bool pre_zero = false;
+                tlen = (int)(A.iv_epos[sm.exons_epos] - sm.epos + 1);
+                int it = sm.exon_ind_epos;
+                for (uint32_t k = sti + 1; k < eti; ++k) {
+                    ++it;
+                    if (t2s[k] != 0) {
+                        tlen += (int)(A.iv_epos[it] - A.iv_spos[it] + 1);
+                        pre_zero = false;
+                    } else {
+                        if (!pre_zero) ++in;
+                        pre_zero = true;
+                    }
+                }
+                tlen += (int)(lm.spos - A.iv_spos[lm.exons_spos] + 1);
+            }
+            if (tlen < min_tlen) {
+                intron_num = in;
+                min_tlen = tlen;
+            }
+        }
+    }
+    return (min_tlen == INF_I) ? -1 : (int)(min_tlen + sm.matched_len - 1 + lm.matched_len - 1);
+}
+CM_HD inline bool same_gene_span(const Core &c, int iv, uint32_t s, uint32_t e) {      // utils.cpp:617-639
+    const cm_annot_view &A = c.A;
+    const uint32_t n = iv_nseg(A, iv);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t g = A.seg_gene_id[iv_segid(A, iv, i)];
+        if (A.gene_start[g] <= s && e <= A.gene_end[g]) return true;
+    }
+    return false;
+}
+CM_HD inline bool share_gene(const Core &c, int a, int b) {
+    const cm_annot_view &A = c.A;
+    const uint32_t na = iv_nseg(A, a), nb = iv_nseg(A, b);
+    for (uint32_t i = 0; i < na; ++i)
+        for (uint32_t j = 0; j < nb; ++j)
+            if (A.seg_gene_id[iv_segid(A, a, i)] == A.seg_gene_id[iv_segid(A, b, j)]) return true;
+    return false;
+}
+// same_transcript + intersect_trans, utils.cpp:322-354; returns count (order of the first list)
+CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, int *err) {
+    if (s < 0 || r < 0) return 0;
+    const cm_annot_view &A = c.A;
+    int n = 0;
+    const uint32_t ns = iv_nseg(A, s), nr = iv_nseg(A, r);
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t g = iv_segid(A, s, i);
+        for (uint32_t k = A.seg_tid_off[g]; k < A.seg_tid_off[g + 1]; ++k) {
+            const uint32_t t1 = A.seg_tid[k];
+            bool found = false;
+            for (uint32_t j = 0; j < nr && !found; ++j) {
+                const uint32_t h = iv_segid(A, r, j);
+                for (uint32_t l = A.seg_tid_off[h]; l < A.seg_tid_off[h + 1]; ++l)
+                    if (A.seg_tid[l] == t1) { found = true; break; }
+            }
+            if (found) {
+                if (n < MAX_TID) out[n++] = t1;
+                else flag_err(err, ERR_TID);
+            }
+        }
+    }
+    return n;
+}
+
+CM_HD inline bool concordant_explanation(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm, int pair_type) {
+    if (sm.spos > lm.spos) return false;
+    const cm_annot_view &A = c.A;
+    int32_t tlen;
+    const bool on_cdna = sm.exons_spos >= 0 && sm.exons_epos >= 0 && lm.exons_spos >= 0 && lm.exons_epos >= 0;
+    const int good = (pair_type == 0) ? CM_CONCRD : CM_CONGEN;
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) {
+        tlen = (int32_t)(lm.spos - sm.epos - 1 + lm.matched_len + sm.matched_len);
+        if (tlen <= c.P.max_tlen || tlen <= MAXDISCRDTLEN) mr_update(c, mr, sm, lm, row, tlen, 0, false, CM_CONGNM, r1_sm);
+    } else {
+        const uint32_t na = iv_nseg(A, sm.exons_spos), nb = iv_nseg(A, lm.exons_spos);
+        for (uint32_t i = 0; i < na; ++i)
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t x = iv_segid(A, sm.exons_spos, i), y = iv_segid(A, lm.exons_spos, j);
+                if (A.seg_start[x] == A.seg_start[y] && A.seg_end[x] == A.seg_end[y]) {
+                    tlen = (int32_t)(lm.spos + lm.matched_len - sm.spos);
+                    mr_update(c, mr, sm, lm, row, tlen, 0, on_cdna, tlen <= c.P.max_tlen ? good : CM_DISCRD, r1_sm);
+                }
+            }
+    }
+    if (sm.exons_epos < 0 || lm.exons_spos < 0) {
+        tlen = (int32_t)(lm.spos - sm.epos - 1 + sm.matched_len + lm.matched_len);
+        if (tlen <= c.P.max_tlen || tlen <= MAXDISCRDTLEN) mr_update(c, mr, sm, lm, row, tlen, 0, false, CM_CONGNM, r1_sm);
+    } else {
+        int intron_num = 0;
+        tlen = calc_tlen(c, sm, lm, intron_num);
+        if (tlen >= 0 && tlen <= c.P.max_tlen) {
+            mr_update(c, mr, sm, lm, row, tlen, intron_num, on_cdna, good, r1_sm);
+        } else {
+            if (tlen < 0) {
+                tlen = (int32_t)(lm.spos - sm.epos - 1 + sm.matched_len + lm.matched_len);
+                intron_num = 0;
+            }
+            mr_update(c, mr, sm, lm, row, tlen, intron_num, on_cdna, CM_DISCRD, r1_sm);
+        }
+    }
+    return mr.type == CM_CONCRD;
+}
+CM_HD inline void check_chimeric(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm) {
+    if (mr.type == CM_CONCRD) return;
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) return;
+    if (sm.spos < lm.spos && share_gene(c, sm.exons_spos, lm.exons_spos))
+        mr_update(c, mr, sm, lm, row, (int32_t)(lm.epos - sm.spos + 1), 0, false, CM_CHIORF, r1_sm);
+}
+CM_HD inline void bsj_tail(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm, int type) {
+    const cm_annot_view &A = c.A;
+    const int32_t tl = (int32_t)(lm.epos - sm.spos + 1);
+    if (sm.exons_spos < 0 || lm.exons_spos < 0) {
+        if ((sm.exons_spos >= 0 && same_gene_span(c, sm.exons_spos, lm.spos, lm.epos)) ||
+            (lm.exons_spos >= 0 && same_gene_span(c, lm.exons_spos, sm.spos, sm.epos))) {
+            mr_update(c, mr, sm, lm, row, tl, 0, false, type, r1_sm);
+            return;
+        }
+        if (bit_at(A.intronic_bits, A.n_bits, sm.spos) && bit_at(A.intronic_bits, A.n_bits, lm.spos) && sm.exon_ind_spos >= 0 &&
+            lm.exon_ind_epos >= 0 && sm.exon_ind_spos == lm.exon_ind_epos &&
+            (uint32_t)(sm.spos - A.iv_epos[sm.exon_ind_spos]) <= LARIAT2BEGTH)
+            mr_update(c, mr, sm, lm, row, tl, 0, false, type, r1_sm);
+        return;
+    }
+    if (share_gene(c, sm.exons_spos, lm.exons_spos)) mr_update(c, mr, sm, lm, row, tl, 0, false, type, r1_sm);
+}
+CM_HD inline void check_bsj(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm) {
+    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD) return;
+    if (!sm.right_ok || !lm.left_ok) return;
+    bsj_tail(c, sm, lm, mr, row, r1_sm, CM_CHIBSJ);
+}
+CM_HD inline void check_2bsj(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm) {
+    if (mr.type < CM_CHI2BSJ) return;
+    if (sm.spos > lm.spos) return;
+    if (sm.right_ok && lm.right_ok && sm.spos != lm.spos) return;
+    if (sm.left_ok && lm.left_ok && sm.epos != lm.epos) return;
+    if (sm.left_ok && lm.right_ok) return;
+    bsj_tail(c, sm, lm, mr, row, r1_sm, CM_CHI2BSJ);
+}
+CM_HD inline bool is_left_chain(const CH &a, const CH &b, int read_length) {
+    const uint32_t a_beg = a.rpos(0), b_beg = b.rpos(0);
+    const uint32_t a_end = a.rend_excl() - 1, b_end = b.rend_excl() - 1;
+    if ((b_beg > a_end) || (a_beg > b_end)) return a_beg < b_beg;
+    uint32_t i = 0, j = 0;
+    int best_d = INF_I, bi = -1, bj = -1;
+    while (i < a.len() && j < b.len()) {
+        const uint32_t bj_beg = b.rpos(j), ai_end = a.rpos(i) + a.kmer - 1;
+        if (ai_end < bj_beg) {
+            const int d = (int)(bj_beg - ai_end);
+            if (d < best_d) { best_d = d; bi = (int)i; bj = (int)j; }
+            ++i;
+            continue;
+        }
+        const uint32_t ai_beg = a.rpos(i), bj_end = b.rpos(j) + b.kmer - 1;
+        if (bj_end < ai_beg) {
+            const int d = (int)(ai_beg - bj_end);
+            if (d < best_d) { best_d = d; bi = (int)i; bj = (int)j; }
+            ++j;
+            continue;
+        }
+        bi = (int)i;
+        bj = (int)j;
+        break;
+    }
+    const uint32_t common_bp = cmax(a.rpos(bi), b.rpos(bj));
+    const int32_t a_ov = a.qpos(bi) + (int32_t)(common_bp - a.rpos(bi));
+    const int32_t b_ov = b.qpos(bj) + (int32_t)(common_bp - b.rpos(bj));
+    if (a_ov < read_length && b_ov < read_length) return a_ov >= b_ov;
+    return a_beg < b_beg;
+}
+
+// ------------------------------------------------------------------------------------------
+// extension (A11-A13, A19)
+// ------------------------------------------------------------------------------------------
+struct MemoKey { uint32_t rspos, rlen, qspos, qlen; };
+struct Memo {
+    MemoKey k[MEMO_N];
+    AlignRes v[MEMO_N];
+    int n;
+};
+CM_HD inline int memo_find(const Memo &m, const MemoKey &k) {
+    for (int i = 0; i < m.n; ++i)
+        if (m.k[i].rspos == k.rspos && m.k[i].rlen == k.rlen && m.k[i].qspos == k.qspos && m.k[i].qlen == k.qlen) return i;
+    return -1;
+}
+// std::map::insert semantics (no overwrite).  A full table just stops memoising: a memo entry is a
+// pure function of its key except for the middle-vs-end key collision described in DESIGN.md §5.
+CM_HD inline void memo_put(Memo &m, const MemoKey &k, const AlignRes &v) {
+    if (m.n < MEMO_N && memo_find(m, k) < 0) {
+        m.k[m.n] = k;
+        m.v[m.n] = v;
+        ++m.n;
+    }
+}
+
+struct Ext {
+    const Core &c;
+    CM_HD explicit Ext(const Core &cc) : c(cc) {}
+
+    CM_HD bool extend_middle(uint32_t pos, uint32_t exon_len, const SV &q, uint32_t qlen, int ed_th, AlignRes &best, AlignRes &curr,
+                             AlignRes &exon_res, bool right) const {
+        SV ref;
+        if (!pac2char(c, right ? pos + 1 : pos - exon_len, (int)exon_len, ref)) return false;
+        int indel, sc;
+        const uint32_t seq_remain = cmin<uint32_t>(exon_len + (uint32_t)c.P.band, qlen);
+        const int ed = local_alignment_side(c, q, (int)seq_remain, ref, (int)exon_len, !right, indel, sc);
+        const uint32_t np = right ? pos + exon_len : pos - exon_len;
+        ar_set(exon_res, np, ed, 0, -indel, (int)exon_len - indel, sc);
+        if (curr.ed + ed <= ed_th) {
+            ar_update(curr, ed, 0, np, -indel, (int)exon_len - indel, sc);
+            ar_side(c, best, curr, right);
+            return true;
+        }
+        return false;
+    }
+    CM_HD void extend_end(uint32_t pos, uint32_t ref_len, const SV &q, int qlen, int ed_th, AlignRes &best, AlignRes &curr,
+                          AlignRes &exon_res, bool right) const {
+        SV ref;
+        if (!pac2char(c, right ? pos + 1 : pos - ref_len, (int)ref_len, ref)) return;
+        int sclen, indel, sc, ed;
+        if (right) ed = local_alignment_sc(c, ref, (int)ref_len, q, qlen, sclen, indel, sc);
+        else ed = local_alignment_sc(c, ref.rev((int)ref_len), (int)ref_len, q.rev(qlen), qlen, sclen, indel, sc);
+        const uint32_t np = right ? pos + qlen - indel : pos - qlen + indel;
+        ar_set(exon_res, np, ed, sclen, indel, qlen, sc);
+        if ((curr.ed + ed <= ed_th) && (sclen <= c.P.max_sc) && (qlen - sclen >= sclen)) {
+            ar_update(curr, ed, sclen, np, indel, qlen, sc);
+            ar_by_score(best, curr, right);
+        }
+    }
+    CM_HD bool middle_step(Memo &memo, const MemoKey &key, uint32_t pos, uint32_t exon_len, const SV &q, uint32_t qlen, int ed_th,
+                           AlignRes &best, AlignRes &curr, AlignRes &exon_res, bool right, int &indel) const {
+        const int f = memo_find(memo, key);
+        if (f >= 0) {
+            const AlignRes &r = memo.v[f];
+            if (curr.ed + r.ed > ed_th) return false;
+            ar_update(curr, r.ed, r.sclen, r.pos, r.indel, r.qcovlen, r.score);
+            ar_side(c, best, curr, right);
+            indel = r.indel;
+            return true;
+        }
+        const bool ok = extend_middle(pos, exon_len, q, qlen, ed_th, best, curr, exon_res, right);
+        memo_put(memo, key, exon_res);
+        if (!ok) return false;
+        indel = exon_res.indel;
+        return true;
+    }
+    CM_HD void end_step(Memo &memo, const MemoKey &key, uint32_t pos, uint32_t ref_len, const SV &q, int qlen, int ed_th, AlignRes &best,
+                        AlignRes &curr, AlignRes &exon_res, bool right) const {
+        const int f = memo_find(memo, key);
+        if (f >= 0) {
+            const AlignRes &r = memo.v[f];
+            if ((curr.ed + r.ed > ed_th) || (r.sclen > c.P.max_sc) || (r.qcovlen - r.sclen < r.sclen)) return;
+            ar_update(curr, r.ed, r.sclen, r.pos, r.indel, r.qcovlen, r.score);
+            ar_by_score(best, curr, right);
+        } else {
+            extend_end(pos, ref_len, q, qlen, ed_th, best, curr, exon_res, right);
+            memo_put(memo, key, exon_res);
+        }
+    }
+
+    CM_HD void right_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t ub, AlignRes &best,
+                           bool &consecutive, Memo &memo) const {
+        const cm_annot_view &A = c.A;
+        consecutive = false;
+        AlignRes curr = ar_init(ub), exon_res = ar_init(ub);
+        int it_ind;
+        int it_seg = overlap_ind(c, pos, it_ind);
+        if (it_seg < 0) return;
+        int covered = 0;
+        const int it_start = A.trans_start_ind[tid];
+        const int rel_ind = it_ind - it_start;
+        const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
+        const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+        uint32_t rspos = pos;
+        int exon_len = (int)(A.iv_epos[it_seg] - pos);
+        int remain_ref_len = ref_len;
+        int indel = 0;
+        for (unsigned int i = (unsigned int)(rel_ind + 1); i < tsz; ++i) {
+            if (exon_len >= qlen - covered) break;
+            const uint8_t st = t2s[i];
+            if (st == 1) {
+                indel = 0;
+                if (exon_len > 0) {
+                    if (rspos + exon_len > ub) return;
+                    const uint32_t rq = (uint32_t)cmin(exon_len + c.P.band, qlen - covered);
+                    const MemoKey key{rspos, (uint32_t)exon_len, (uint32_t)covered, rq};
+                    if (!middle_step(memo, key, rspos, (uint32_t)exon_len, q.sub(covered), rq, ed_th, best, curr, exon_res, true, indel)) return;
+                }
+                remain_ref_len -= exon_len;
+                covered += exon_len + indel;
+                exon_len = 0;
+                rspos = A.iv_spos[(int)i + it_start] - 1;
+            }
+            if (st != 0) {
+                const int iv = (int)i + it_start;
+                exon_len += (int)(A.iv_epos[iv] - A.iv_spos[iv] + 1);
+            }
+        }
+        if ((exon_len > 0) && (exon_len < qlen - covered) && (rspos + exon_len <= ub)) {
+            const uint32_t rq = (uint32_t)cmin(exon_len + c.P.band, qlen - covered);
+            const MemoKey key{rspos, (uint32_t)exon_len, (uint32_t)covered, rq};
+            middle_step(memo, key, rspos, (uint32_t)exon_len, q.sub(covered), rq, ed_th, best, curr, exon_res, true, indel);
+            return;
+        }
+        if (covered >= qlen || (rspos + qlen - covered > ub) || (exon_len < qlen - covered)) return;
+        consecutive = (rspos == pos);
+        remain_ref_len = cmin(remain_ref_len, exon_len);
+        const MemoKey key{rspos, (uint32_t)remain_ref_len, (uint32_t)covered, (uint32_t)(qlen - covered)};
+        end_step(memo, key, rspos, (uint32_t)remain_ref_len, q.sub(covered), qlen - covered, ed_th, best, curr, exon_res, true);
+    }
+
+    CM_HD void left_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t lb, AlignRes &best,
+                          bool &consecutive, Memo &memo) const {
+        const cm_annot_view &A = c.A;
+        consecutive = false;
+        AlignRes curr = ar_init(lb), exon_res = ar_init(lb);
+        int it_ind;
+        int it_seg = overlap_ind(c, pos, it_ind);
+        if (it_seg < 0) return;
+        int covered = 0;
+        const int it_start = A.trans_start_ind[tid];
+        const int rel_ind = it_ind - it_start;
+        const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
+        const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+        uint32_t lepos = pos;
+        int exon_len = 0;
+        int remain_ref_len = ref_len;
+        int indel = 0;
+        bool first_seg = true;
+        for (int i = rel_ind; i >= 0; --i) {
+            const uint8_t st = ((uint32_t)i < tsz) ? t2s[i] : 0;
+            if (st != 0) {
+                const int iv = i + it_start;
+                if (first_seg) {
+                    exon_len = (int)(pos - A.iv_spos[iv]);
+                    first_seg = false;
+                } else {
+                    if (exon_len == 0) lepos = A.iv_epos[iv] + 1;
+                    exon_len += (int)(A.iv_epos[iv] - A.iv_spos[iv] + 1);
+                }
+            }
+            if (exon_len >= qlen - covered) break;
+            if (st == 1) {
+                indel = 0;
+                if (exon_len > 0) {
+                    if (lepos < lb + exon_len) return;
+                    const uint32_t rq = (uint32_t)cmin(exon_len + c.P.band, qlen - covered);
+                    const MemoKey key{lepos, (uint32_t)exon_len, (uint32_t)covered, rq};
+                    if (!middle_step(memo, key, lepos, (uint32_t)exon_len, q.sub(qlen - covered - (int)rq), rq, ed_th, best, curr, exon_res, false, indel)) return;
+                }
+                remain_ref_len -= exon_len;
+                covered += exon_len + indel;
+                exon_len = 0;
+            }
+        }
+        if ((exon_len > 0) && (exon_len < qlen - covered) && (lepos >= lb + exon_len)) {
+            const uint32_t rq = (uint32_t)cmin(exon_len + c.P.band, qlen - covered);
+            const MemoKey key{lepos, (uint32_t)exon_len, (uint32_t)covered, rq};
+            middle_step(memo, key, lepos, (uint32_t)exon_len, q.sub(qlen - covered - (int)rq), rq, ed_th, best, curr, exon_res, false, indel);
+            return;
+        }
+        if (covered >= qlen || (lepos < lb + qlen - covered) || (exon_len < qlen - covered)) return;
+        consecutive = (lepos == pos);
+        remain_ref_len = cmin(remain_ref_len, exon_len);
+        const MemoKey key{lepos, (uint32_t)remain_ref_len, (uint32_t)covered, (uint32_t)(qlen - covered)};
+        end_step(memo, key, lepos, (uint32_t)remain_ref_len, q, qlen - covered, ed_th, best, curr, exon_res, false);
+    }
+
+    // extend_right / extend_left, src/extend.cpp:285-432; q = the residual (len chars)
+    CM_HD bool extend_side(const uint32_t *tids, int n_tid, const SV &q, uint32_t &pos, int len, int ed_th, uint32_t bound, AlignRes &best,
+                           bool right) const {
+        const int seq_len = len, ref_len = len + c.P.band;
+        const uint32_t orig_pos = pos;
+        bool consecutive = false;
+        ar_set(best, pos, ed_th + 1, len + 1, c.P.band + 1, 0, 0);
+        Memo memo;
+        memo.n = 0;
+        for (int i = 0; i < n_tid; ++i) {
+            if (right) right_trans(tids[i], pos, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+            else left_trans(tids[i], pos, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+        }
+        int min_ed = best.ed, sclen_best = best.sclen;
+        if (min_ed <= ed_th) {
+            pos = right ? best.pos - sclen_best : best.pos + sclen_best;
+            if (best.qcovlen >= seq_len && sclen_best <= c.P.max_sc) return true;
+        }
+        SV ref;
+        if (!consecutive && pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) {
+            int indel, sc;
+            if (right) min_ed = local_alignment_sc(c, ref, ref_len, q, seq_len, sclen_best, indel, sc);
+            else min_ed = local_alignment_sc(c, ref.rev(ref_len), ref_len, q.rev(seq_len), seq_len, sclen_best, indel, sc);
+            if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
+                const uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;
+                AlignRes curr = ar_init(bound);
+                ar_set(curr, np, min_ed, sclen_best, indel, seq_len, sc);
+                if (ar_by_score(best, curr, right)) {
+                    pos = right ? np - sclen_best : np + sclen_best;
+                    return true;
+                }
+            }
+        }
+        if (best.qcovlen <= 0) {
+            pos = orig_pos;
+            ar_set(best, pos, 0, 0, 0, 0, -INF_I);
+        }
+        const int qremain = seq_len - best.qcovlen;
+        if (qremain + best.sclen <= c.P.max_sc) {
+            ar_set(best, pos, best.ed, best.sclen + qremain, best.indel, seq_len, best.score);
+            return true;
+        }
+        return (best.qcovlen >= seq_len && best.ed <= ed_th);
+    }
+
+    CM_HD bool chain_right(const uint32_t *tids, int n_tid, const CH &ch, const SV &seq, int seq_len, uint32_t ub, MM &mr, int &err) const {
+        uint32_t rm_pos = ch.rend_excl() - 1;
+        int remain_end = seq_len - ch.qend_excl();
+        bool right_ok = (remain_end <= 0);
+        AlignRes best = ar_init(ub);
+        if (remain_end > 0) right_ok = extend_side(tids, n_tid, seq.sub(seq_len - remain_end), rm_pos, remain_end, c.P.max_ed - err, ub, best, true);
+        const int sclen_right = best.sclen, err_right = best.ed;
+        remain_end -= best.qcovlen;
+        mr.epos = rm_pos;
+        mr.matched_len -= (uint32_t)(right_ok ? sclen_right : remain_end);
+        mr.qepos -= (uint32_t)(right_ok ? sclen_right : remain_end);
+        mr.sclen_right = sclen_right;
+        mr.right_ed = best.ed;
+        err += err_right;
+        return right_ok;
+    }
+    CM_HD bool chain_left(const uint32_t *tids, int n_tid, const CH &ch, const SV &seq, int32_t qspos, uint32_t lb, MM &mr, int &err) const {
+        uint32_t lm_pos = ch.rpos(0);
+        int remain_beg = ch.qpos(0) - qspos;
+        bool left_ok = (remain_beg <= 0);
+        AlignRes best = ar_init(lb);
+        if (remain_beg > 0) left_ok = extend_side(tids, n_tid, seq, lm_pos, remain_beg, c.P.max_ed - err, lb, best, false);
+        const int sclen_left = best.sclen, err_left = best.ed;
+        remain_beg -= best.qcovlen;
+        mr.spos = lm_pos;
+        mr.matched_len -= (uint32_t)(left_ok ? sclen_left : remain_beg);
+        mr.qspos += (uint32_t)(left_ok ? sclen_left : remain_beg);
+        mr.sclen_left = sclen_left;
+        mr.left_ed = best.ed;
+        err += err_left;
+        return left_ok;
+    }
+    CM_HD int calc_middle_ed(const CH &ch, int edth, const SV &q) const {
+        int mid = 0;
+        if (ch.len() == 0) return 0;
+        for (uint32_t i = 0; i + 1 < ch.len(); ++i) {
+            if (ch.qpos(i + 1) > ch.qpos(i) + ch.kmer) {
+                const int diff = (int)(ch.rpos(i + 1) - ch.rpos(i)) - (ch.qpos(i + 1) - ch.qpos(i));
+                const int32_t qspos = ch.qpos(i) + ch.kmer;
+                const int qlen = ch.qpos(i + 1) - qspos;
+                const uint32_t rspos = ch.rpos(i) + (uint32_t)ch.kmer;
+                int rlen = qlen + diff;
+                if (rlen < 0) rlen = 0;
+                if (diff >= -c.P.band && diff <= c.P.band) {
+                    SV ref;
+                    if (!pac2char(c, rspos, rlen, ref)) ref = SV{c.X.genome, 0, 1, 2};    // defined as an all-NUL window
+                    if (diff >= 0) mid += one_side_banded(q.sub(qspos), qlen, ref, rlen, diff);
+                    else mid += one_side_banded(ref, rlen, q.sub(qspos), qlen, -diff);
+                }
+                if (mid > edth) return edth + 1;
+            }
+        }
+        return mid;
+    }
+    CM_HD bool both_mates(const CH &lch, const CH &rch, const uint32_t *tids, int n_tid, const Read &lr, const Read &rr, MM &lmm, MM &rmm) const {
+        const int maxEd = c.P.max_ed;
+        const SV lseq = lr.view(), rseq = rr.view();
+        lmm.middle_ed = calc_middle_ed(lch, maxEd, lseq);
+        rmm.middle_ed = calc_middle_ed(rch, maxEd, rseq);
+        if (lmm.middle_ed <= maxEd) is_concord_impl(lch, (uint32_t)lr.len, lmm, true);
+        if (rmm.middle_ed <= maxEd) is_concord_impl(rch, (uint32_t)rr.len, rmm, true);
+        if (lmm.middle_ed > maxEd || rmm.middle_ed > maxEd) return false;
+        lmm.is_concord = false;
+        rmm.is_concord = false;
+        int lerr = lmm.middle_ed, rerr = rmm.middle_ed;
+        // chain_len is never 0 for a stored chain, so both mates extend (src/extend.cpp:60-74)
+        lmm.matched_len = (uint32_t)lr.len;
+        lmm.qspos = 1;
+        lmm.qepos = (uint32_t)lr.len;
+        const bool llok = chain_left(tids, n_tid, lch, lseq, 0, MINLB, lmm, lerr);
+        rmm.matched_len = (uint32_t)rr.len;
+        rmm.qspos = 1;
+        rmm.qepos = (uint32_t)rr.len;
+        const bool rlok = chain_left(tids, n_tid, rch, rseq, 0, lmm.spos, rmm, rerr);
+        const bool rrok = chain_right(tids, n_tid, rch, rseq, rr.len, MAXUB, rmm, rerr);
+        const bool lrok = chain_right(tids, n_tid, lch, lseq, lr.len, rmm.epos, lmm, lerr);
+        update_match_mate_info(c, llok, lrok, lerr, lmm);
+        update_match_mate_info(c, rlok, rrok, rerr, rmm);
+        return true;
+    }
+    CM_HD int chain_both_sides(const CH &ch, const Read &rd, MM &mr, int dir) const {
+        const int maxEd = c.P.max_ed;
+        const SV seq = rd.view();
+        const int seq_len = rd.len;
+        mr.is_concord = false;
+        mr.middle_ed = estimate_middle_error(c, ch);
+        if (is_concord_impl(ch, (uint32_t)seq_len, mr, false)) {
+            mr.dir = dir;
+            return mr.type;
+        }
+        uint32_t lm_pos = ch.rpos(0);
+        int remain_beg = ch.qpos(0);
+        bool left_ok = (remain_beg <= 0);
+        AlignRes bl = ar_init(MINLB);
+        if (remain_beg > 0) left_ok = extend_side(nullptr, 0, seq, lm_pos, remain_beg, maxEd - mr.middle_ed, MINLB, bl, false);
+        const int err_left = bl.ed, sclen_left = bl.sclen;
+        remain_beg -= bl.qcovlen;
+        uint32_t rm_pos = ch.rend_excl() - 1;
+        int remain_end = seq_len - ch.qend_excl();
+        bool right_ok = (remain_end <= 0);
+        AlignRes br = ar_init(MAXUB);
+        if (remain_end > 0) right_ok = extend_side(nullptr, 0, seq.sub(seq_len - remain_end), rm_pos, remain_end, maxEd - mr.middle_ed - err_left, MAXUB, br, true);
+        const int err_right = br.ed, sclen_right = br.sclen;
+        remain_end -= br.qcovlen;
+        mr.spos = lm_pos;
+        mr.epos = rm_pos;
+        mr.matched_len = (uint32_t)seq_len;
+        mr.matched_len -= (uint32_t)(left_ok ? sclen_left : remain_beg);
+        mr.matched_len -= (uint32_t)(right_ok ? sclen_right : remain_end);
+        mr.qspos = (uint32_t)(1 + (left_ok ? sclen_left : remain_beg));
+        mr.qepos = (uint32_t)(seq_len - (right_ok ? sclen_right : remain_end));
+        mr.right_ed = br.ed;
+        mr.left_ed = bl.ed;
+        mr.dir = dir;
+        if (left_ok && right_ok && (err_left + err_right <= maxEd) && sclen_left <= c.P.max_sc && sclen_right <= c.P.max_sc) {
+            mr.is_concord = true;
+            mr.type = CM_CONCRD;
+        } else if (left_ok || right_ok) mr.type = CM_CANDID;
+        else mr.type = CM_ORPHAN;
+        return mr.type;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// K3 body: pair chains, extend, classify (A8-A10, A20)
+// ------------------------------------------------------------------------------------------
+struct ChainSet {          // chains of one (mate, orientation)
+    const cm_chain *ch;
+    int n;
+};
+
+// FilterRead::process_mates (filter.cpp:244-395) with pair_chains (filter.cpp:484-551) fused in:
+// pass 1 evaluates the pairing predicate for every (i, j) (needed up-front for the *_paired
+// flags), pass 2 walks the accepted pairs in i-major order.
+CM_HD inline int process_mates(const Core &c, const ChainSet &fwd, const Read &frd, const ChainSet &bwd, const Read &brd, cm_mapped_read &mr,
+                               bool r1_forward, int *err) {
+    const Ext ext(c);
+    const int kmer = c.P.kmer;
+    const int saved_type = mr.type;
+    int fe[CM_BESTCHAINLIM], re[CM_BESTCHAINLIM];
+    for (int i = 0; i < fwd.n; ++i) fe[i] = overlap(c, fwd.ch[i].rpos[0]);
+    for (int j = 0; j < bwd.n; ++j) re[j] = overlap(c, bwd.ch[j].rpos[0]);
+    uint32_t ptype[(CM_BESTCHAINLIM * CM_BESTCHAINLIM * 2 + 31) / 32];   // 2 bits per (i,j): 0 none, 1..3 = type+1
+    for (unsigned x = 0; x < sizeof(ptype) / sizeof(ptype[0]); ++x) ptype[x] = 0;
+    uint32_t fpaired = 0, bpaired = 0;
+    uint32_t tids[MAX_TID];
+    for (int i = 0; i < fwd.n; ++i)
+        for (int j = 0; j < bwd.n; ++j) {
+            const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+            const uint32_t fs = F.rpos(0), rs = R.rpos(0), fe_ = F.rend_excl(), re_ = R.rend_excl();
+            const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
+            bool same_tr = false, same_gen = false;
+            if (fe[i] >= 0 && re[j] >= 0) same_tr = common_tids(c, fe[i], re[j], tids, err) > 0;
+            if (!same_tr && fe[i] >= 0 &&
+                ((c.P.scan_level == 0 && saved_type > CM_CONGEN) || (c.P.scan_level > 0 && saved_type >= CM_CONGEN)))
+                same_gen = same_gene_span(c, fe[i], rs, re_);
+            if (!same_gen && re[j] >= 0 && saved_type >= CM_CONGEN) same_gen = same_gene_span(c, re[j], fs, fe_);
+            if (same_tr || same_gen || ((tlen <= MAXDISCRDTLEN) && (saved_type >= CM_CONGNM))) {
+                const uint32_t code = same_tr ? 1u : (same_gen ? 2u : 3u);
+                const int idx = i * CM_BESTCHAINLIM + j;
+                ptype[idx >> 4] |= code << ((idx & 15) * 2);
+                fpaired |= 1u << i;
+                bpaired |= 1u << j;
+            }
+        }
+    int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN;
+    bool r1_genic = false, r2_genic = false;
+    for (int i = 0; i < fwd.n; ++i)
+        for (int j = 0; j < bwd.n; ++j) {
+            const int idx = i * CM_BESTCHAINLIM + j;
+            const uint32_t code = (ptype[idx >> 4] >> ((idx & 15) * 2)) & 3u;
+            if (code == 0) continue;
+            const int pair_type = (int)code - 1;
+            const int n_tid = (code == 1) ? common_tids(c, fe[i], re[j], tids, err) : 0;
+            // (when same_tr is false the reference's common_tid is empty: same_transcript clears it)
+            MM r1 = mm_init(c), r2 = mm_init(c);
+            r1.dir = 1;
+            r2.dir = -1;
+            const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+            if (is_left_chain(F, R, frd.len)) {
+                if (ext.both_mates(F, R, tids, n_tid, frd, brd, r1, r2)) {
+                    const int row = chr_row(c, r1.spos);
+                    overlap_to_epos(c, r1); overlap_to_spos(c, r1);
+                    overlap_to_epos(c, r2); overlap_to_spos(c, r2);
+                    if (r1.type == CM_CONCRD && r2.type == CM_CONCRD) {
+                        if (concordant_explanation(c, r1, r2, mr, row, r1_forward, pair_type) && c.P.scan_level == 0) return CM_CONCRD;
+                    } else if ((r1.type == CM_CANDID && r2.type == CM_CONCRD) || (r1.type == CM_CONCRD && r2.type == CM_CANDID)) {
+                        check_bsj(c, r1, r2, mr, row, r1_forward);
+                    } else if (r1.type == CM_CANDID && r2.type == CM_CANDID) {
+                        check_2bsj(c, r1, r2, mr, row, r1_forward);
+                    }
+                }
+            } else {
+                if (ext.both_mates(R, F, tids, n_tid, brd, frd, r2, r1)) {
+                    const int row = chr_row(c, r2.spos);
+                    overlap_to_epos(c, r1); overlap_to_spos(c, r1);
+                    overlap_to_epos(c, r2); overlap_to_spos(c, r2);
+                    if (r1.type == CM_CONCRD && r2.type == CM_CONCRD) {
+                        check_chimeric(c, r2, r1, mr, row, !r1_forward);
+                    } else if ((r1.type == CM_CANDID && r2.type == CM_CONCRD) || (r1.type == CM_CONCRD && r2.type == CM_CANDID)) {
+                        check_bsj(c, r2, r1, mr, row, !r1_forward);
+                    } else if (r1.type == CM_CANDID && r2.type == CM_CANDID) {
+                        check_2bsj(c, r2, r1, mr, row, !r1_forward);
+                    }
+                }
+            }
+            min_ret1 = cmin(r1.type, min_ret1);
+            min_ret2 = cmin(r2.type, min_ret2);
+            r1_genic = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
+            r2_genic = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
+        }
+    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return mr.type;
+    MM mm1 = mm_init(c);      // deliberately not reset between chains (stale looked_up_* caches, filter.cpp:356-370)
+    if (min_ret1 != CM_CONCRD)
+        for (int i = 0; i < fwd.n; ++i)
+            if (!((fpaired >> i) & 1u)) {
+                const CH F{fwd.ch + i, kmer};
+                const int ex = ext.chain_both_sides(F, frd, mm1, 1);
+                min_ret1 = cmin(ex, min_ret1);
+                overlap_to_spos(c, mm1);
+                overlap_to_epos(c, mm1);
+                r1_genic = (mm1.exons_spos >= 0) || (mm1.exons_epos >= 0);
+            }
+    MM mm2 = mm_init(c);
+    if (min_ret2 != CM_CONCRD)
+        for (int j = 0; j < bwd.n; ++j)
+            if (!((bpaired >> j) & 1u)) {
+                const CH R{bwd.ch + j, kmer};
+                const int ex = ext.chain_both_sides(R, brd, mm2, -1);
+                min_ret2 = cmin(ex, min_ret2);
+                overlap_to_spos(c, mm2);
+                overlap_to_epos(c, mm2);
+                r2_genic = (mm2.exons_spos >= 0) || (mm2.exons_epos >= 0);
+            }
+    const int new_type = (((min_ret1 == CM_ORPHAN) && (min_ret2 == CM_CONCRD)) || ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_ORPHAN))) ? CM_OEANCH
+                       : ((min_ret1 == CM_ORPHAN) || (min_ret2 == CM_ORPHAN)) ? CM_ORPHAN
+                       : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD) && (r1_genic && r2_genic)) ? CM_CHIFUS
+                       : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD)) ? CM_OEA2 : CM_CANDID;
+    mr_update_type(mr, new_type);
+    return mr.type;
+}
+
+// FilterRead::process_read (PE), filter.cpp:124-241, after seeding + chaining.
+// sets[0..3] = chains of (R1 fwd, R1 rc, R2 fwd, R2 rc); high[] = high_hits of each.
+CM_HD inline int process_read(const Core &c, const uint8_t *s1, int len1, const uint8_t *s2, int len2, const ChainSet *sets, const int *high,
+                              cm_mapped_read &mr, int *err) {
+    const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
+    if (n1 + n2 <= 0) {
+        if ((high[0] + high[1] > 0) && (high[2] + high[3] > 0)) {
+            mr_update_type(mr, CM_NOPROC_MANYHIT);
+            return CM_NOPROC_MANYHIT;
+        }
+        mr_update_type(mr, CM_NOPROC_NOMATCH);
+        return CM_NOPROC_NOMATCH;
+    }
+    if (n1 <= 0 || n2 <= 0) {
+        mr_update_type(mr, CM_OEANCH);
+        return CM_OEANCH;
+    }
+    const float fc1 = sets[0].n > 0 ? sets[0].ch[0].score : 0.f, bc1 = sets[1].n > 0 ? sets[1].ch[0].score : 0.f;
+    const float fc2 = sets[2].n > 0 ? sets[2].ch[0].score : 0.f, bc2 = sets[3].n > 0 ? sets[3].ch[0].score : 0.f;
+    const float lhs = fc1 + bc2, rhs = fc2 + bc1;
+    const Read r1f{s1, len1, 0}, r1b{s1, len1, 1}, r2f{s2, len2, 0}, r2b{s2, len2, 1};
+    const bool first = lhs >= rhs;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int a;
+        if ((attempt == 0) == first) a = process_mates(c, sets[0], r1f, sets[3], r2b, mr, true, err);    // forward R1 / backward R2
+        else a = process_mates(c, sets[2], r2f, sets[1], r1b, mr, false, err);                            // forward R2 / backward R1
+        if (c.P.scan_level == 0 && a == CM_CONCRD) return CM_CONCRD;
+    }
+    return mr.type;
+}
+
+// the skip / requeue rule of map_reads (src/circminer.cpp:386-397) plus what the next round's
+// fill_map_info would read back from the remain FASTQ header (fastq_parser.cpp:214-267)
+CM_HD inline void finish_round(const Core &c, int state, int is_last, int len1, int len2, cm_mapped_read &mr, uint8_t &active) {
+    const bool skip = (c.P.scan_level == 0 && state == CM_CONCRD) ||
+                      (c.P.scan_level == 1 && state == CM_CONCRD && mr.gm_compatible && (mr.ed_r1 + mr.ed_r2 == 0) &&
+                       (mr.mlen_r1 + mr.mlen_r2 == (uint32_t)(len1 + len2)));
+    const bool requeue = (!is_last && !skip) || (is_last && (mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ));
+    active = requeue ? 1 : 0;
+    if (requeue && !is_last && !mapped_type(mr.type)) {
+        const int t = mr.type;
+        default_mr(c, mr);
+        mr.type = t;
+    }
+}
+
+}  // namespace cmc

@@ -1,0 +1,722 @@
+// cm_hot.hip — gfx950 kernels + the C-ABI of include/circminer_hot.h.
+//
+// Launch structure of one mapping round (cm_map_round) over the resident read batch, per tile of
+// pairs:  k_seed (one lane per k-mer probe)  ->  k_cells + k_scan (cells per chaining problem,
+// exclusive offsets)  ->  k_chain (one lane per (mate, orientation) problem, DP cells and the
+// improvement log in HBM workspace)  ->  k_pair (one lane per pair: pairing, extension,
+// classification, round bookkeeping).  Index, genome, annotation, reads and per-pair state stay
+// in HBM between rounds; nothing is copied back until cm_reads_download.
+//
+// There is no CPU path in this file: without a HIP device cm_create fails with CM_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "circminer_hot.h"
+#include "cm_core.h"
+
+using cmc::Core;
+
+namespace {
+
+constexpr int MAX_SLOTS = 16;
+constexpr uint32_t TILE_PAIRS = 131072;            // pairs per launch group (workspace sizing)
+constexpr int BLK = 256;
+constexpr int BLK_CHAIN = 64;
+constexpr int BLK_PAIR = 64;
+
+struct ReadsDev {
+    const uint8_t *seq1, *seq2;
+    const uint64_t *off1, *off2;
+};
+
+// ------------------------------------------------------------------ kernels
+__global__ void __launch_bounds__(BLK) k_seed(Core c, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t n_tile, int S,
+                                              uint32_t *sstart, uint32_t *scnt, uint32_t *sraw, unsigned long long *counters) {
+    __shared__ unsigned int sh[3];
+    if (threadIdx.x < 3) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t q = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
+    if (q < total) {
+        const uint32_t s = (uint32_t)(q % (uint64_t)S);
+        const uint64_t r = q / (uint64_t)S;
+        const int orient = (int)(r & 1u), mate = (int)((r >> 1) & 1u);
+        const uint64_t p = pair0 + (r >> 2);
+        uint32_t st = 0, cn = 0, rw = 0;
+        if (active[p]) {
+            const uint64_t o0 = mate ? rd.off2[p] : rd.off1[p], o1 = mate ? rd.off2[p + 1] : rd.off1[p + 1];
+            const int len = (int)(o1 - o0);
+            const int k = c.P.kmer;
+            if ((int)(s + 1) * k <= len) {
+                const cmc::Read R{(mate ? rd.seq2 : rd.seq1) + o0, len, orient};
+                const cmc::Probe pr = cmc::seed_probe(c, R.view(), (int)s * k);
+                st = pr.start;
+                rw = pr.raw;
+                cn = (pr.raw > (uint32_t)c.P.seed_lim) ? 0u : pr.raw;
+                atomicAdd(&sh[0], 1u);
+                atomicAdd(&sh[1], pr.touches);
+                atomicAdd(&sh[2], cn);
+            }
+        }
+        sstart[q] = st;
+        scnt[q] = cn;
+        sraw[q] = rw;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && sh[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(BLK) k_cells(const uint32_t *scnt, int S, uint32_t n_prob, uint32_t *cells) {
+    const uint32_t r = blockIdx.x * BLK + threadIdx.x;
+    if (r >= n_prob) return;
+    uint32_t t = 0;
+    for (int s = 0; s < S; ++s) t += scnt[(uint64_t)r * S + s];
+    cells[r] = t;
+}
+
+// single-workgroup exclusive scan (n <= a few million); out[n] = total
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t *in, uint32_t n, unsigned long long *out) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t a = t * chunk, b = (a + chunk < n) ? a + chunk : n;
+    unsigned long long s = 0;
+    for (uint32_t i = a; i < b; ++i) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        unsigned long long v = (t >= d) ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+    for (uint32_t i = a; i < b; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(BLK_CHAIN) k_chain(Core c, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
+                                                     const uint32_t *sstart, const uint32_t *scnt, const uint32_t *sraw,
+                                                     const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
+                                                     int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
+                                                     unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err) {
+    const uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
+    if (r >= r1) return;
+    const uint64_t p = pair0 + (r >> 2);
+    int n = 0, hh = 0;
+    if (active[p]) {
+        const int mate = (int)((r >> 1) & 1u);
+        const uint64_t o0 = mate ? rd.off2[p] : rd.off1[p], o1 = mate ? rd.off2[p + 1] : rd.off1[p + 1];
+        const int len = (int)(o1 - o0);
+        uint32_t st[cmc::MAX_SEEDS], cn[cmc::MAX_SEEDS];
+        for (int s = 0; s < S; ++s) {
+            st[s] = sstart[(uint64_t)r * S + s];
+            cn[s] = scnt[(uint64_t)r * S + s];
+            if (sraw[(uint64_t)r * S + s] > 0 && cn[s] == 0) ++hh;       // get_best_chains high_hits
+        }
+        cmc::ChainWork w;
+        w.dp_score = dp_score + (celloff[r] - cellbase);
+        w.dp_prev = dp_prev + (celloff[r] - cellbase);
+        w.pool = pool;
+        w.pool_bytes = pool_bytes;
+        w.pool_cursor = pool_cursor;
+        w.err = err;
+        n = cmc::chain_kbest(c, len, S, st, cn, w, chains + (uint64_t)r * CM_BESTCHAINLIM);
+    }
+    nchain[r] = n;
+    high[r] = hh;
+}
+
+__global__ void __launch_bounds__(BLK_PAIR) k_pair(Core c, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+                                                   const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
+                                                   int *err, unsigned long long *counters) {
+    const uint32_t t = blockIdx.x * BLK_PAIR + threadIdx.x;
+    if (t >= n_tile) return;
+    const uint64_t p = pair0 + t;
+    if (!active[p]) {
+        cat[p] = -1;
+        return;
+    }
+    const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
+    cmc::ChainSet sets[4];
+    int hh[4];
+    for (int x = 0; x < 4; ++x) {
+        const uint64_t r = (uint64_t)t * 4 + x;
+        sets[x].ch = chains + r * CM_BESTCHAINLIM;
+        sets[x].n = nchain[r];
+        hh[x] = high[r];
+    }
+    cm_mapped_read mr = state[p];
+    const int st = cmc::process_read(c, rd.seq1 + a0, (int)(a1 - a0), rd.seq2 + b0, (int)(b1 - b0), sets, hh, mr, err);
+    uint8_t act = 1;
+    cmc::finish_round(c, st, is_last, (int)(a1 - a0), (int)(b1 - b0), mr, act);
+    state[p] = mr;
+    active[p] = act;
+    cat[p] = st;
+    atomicAdd(&counters[3], 1ull);
+}
+
+__global__ void k_init_state(Core c, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    cmc::default_mr(c, state[i]);
+    active[i] = 1;
+    cat[i] = -1;
+}
+
+// ------------------------------------------------------------------ host side
+struct Slot {
+    bool loaded = false, has_annot = false;
+    cm_index_view X{};
+    cm_annot_view A{};
+    std::vector<void *> idx_allocs, ann_allocs;
+};
+
+struct ProfRec { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct cm_ctx {
+    cm_params P{};
+    hipStream_t stream = nullptr;
+    std::string err = "";
+    Slot slots[MAX_SLOTS];
+    // reads
+    uint64_t n_pairs = 0;
+    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
+    uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
+    cm_mapped_read *d_state = nullptr;
+    uint8_t *d_active = nullptr;
+    int32_t *d_cat = nullptr;
+    int n_seeds = 0;
+    // workspace
+    uint32_t tile = 0;
+    uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
+    unsigned long long *d_celloff = nullptr;
+    double *d_dpscore = nullptr;
+    int32_t *d_dpprev = nullptr;
+    unsigned long long cells_cap = 0;
+    cm_chain *d_chains = nullptr;
+    int32_t *d_nchain = nullptr, *d_high = nullptr;
+    uint8_t *d_pool = nullptr;
+    unsigned long long pool_bytes = 0;
+    unsigned long long *d_pool_cursor = nullptr;
+    int *d_err = nullptr;
+    unsigned long long *d_counters = nullptr;
+    std::vector<unsigned long long> h_celloff;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(cm_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(ctx, (e_ == hipErrorOutOfMemory) ? CM_ENOMEM : CM_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int up(cm_ctx *ctx, std::vector<void *> &allocs, const T *host, size_t n, const T **dev) {
+    void *d = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(ctx, hipMalloc(&d, bytes));
+    allocs.push_back(d);
+    if (n) HIPCHK(ctx, hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *dev = (const T *)d;
+    return CM_OK;
+}
+void free_all(std::vector<void *> &v) {
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+template <class T>
+void dfree(T *&p) {
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+void free_reads(cm_ctx *c) {
+    dfree(c->d_seq1); dfree(c->d_seq2); dfree(c->d_off1); dfree(c->d_off2);
+    dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
+    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff);
+    dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
+    dfree(c->d_pool);
+    c->n_pairs = 0;
+    c->tile = 0;
+}
+
+struct Timer {
+    cm_ctx *c;
+    int cls;
+    ProfRec r{};
+    bool on;
+    Timer(cm_ctx *ctx, int k) : c(ctx), cls(k), on(ctx->prof) {
+        if (on) {
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+            r.cls = cls;
+            (void)hipEventRecord(r.a, c->stream);
+        }
+    }
+    ~Timer() {
+        if (on) {
+            (void)hipEventRecord(r.b, c->stream);
+            c->recs.push_back(r);
+        }
+    }
+};
+
+Core make_core(const cm_ctx *c, const Slot &s) {
+    Core k;
+    k.P = c->P;
+    k.X = s.X;
+    k.A = s.A;
+    return k;
+}
+
+int check_slot(cm_ctx *ctx, int slot, bool need_annot) {
+    if (slot < 0 || slot >= MAX_SLOTS) return fail(ctx, CM_EINVAL, "slot %d out of range", slot);
+    if (!ctx->slots[slot].loaded) return fail(ctx, CM_ESTATE, "contig slot %d not loaded", slot);
+    if (need_annot && !ctx->slots[slot].has_annot) return fail(ctx, CM_ESTATE, "annotation of slot %d not loaded", slot);
+    return CM_OK;
+}
+
+// seeds (+ optionally chains) of one tile; leaves results in the workspace
+int run_seed_tile(cm_ctx *ctx, const Core &core, uint64_t pair0, uint32_t n_tile) {
+    const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
+    const int S = ctx->n_seeds;
+    const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
+    if (total == 0) return CM_OK;
+    Timer t(ctx, 0);
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_active, pair0, n_tile, S,
+                       ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_counters);
+    ++ctx->launches[0];
+    HIPCHK(ctx, hipGetLastError());
+    return CM_OK;
+}
+
+int run_chain_tile(cm_ctx *ctx, const Core &core, uint64_t pair0, uint32_t n_tile) {
+    const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
+    const int S = ctx->n_seeds;
+    const uint32_t n_prob = n_tile * 4u;
+    if (n_prob == 0 || S == 0) return CM_OK;
+    {
+        Timer t(ctx, 3);
+        hipLaunchKernelGGL(k_cells, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_cells);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cells, n_prob, ctx->d_celloff);
+        ctx->launches[3] += 2;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
+    }
+    unsigned long long total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_celloff + n_prob, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // problem ranges whose DP cells fit the workspace
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    if (total <= ctx->cells_cap) {
+        ranges.push_back({0u, n_prob});
+    } else {
+        ctx->h_celloff.resize((size_t)n_prob + 1);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_celloff.data(), ctx->d_celloff, ((size_t)n_prob + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t a = 0;
+        while (a < n_prob) {
+            uint32_t b = a;
+            while (b < n_prob && ctx->h_celloff[b + 1] - ctx->h_celloff[a] <= ctx->cells_cap) ++b;
+            if (b == a) return fail(ctx, CM_ELIMIT, "one chaining problem needs %llu DP cells (> workspace %llu)",
+                                    ctx->h_celloff[a + 1] - ctx->h_celloff[a], ctx->cells_cap);
+            ranges.push_back({a, b});
+            a = b;
+        }
+    }
+    for (auto &rg : ranges) {
+        unsigned long long base = 0;
+        if (rg.first != 0) base = ctx->h_celloff[rg.first];
+        Timer t(ctx, 1);
+        const uint32_t n = rg.second - rg.first;
+        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
+                           rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
+                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err);
+        ++ctx->launches[1];
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return CM_OK;
+}
+
+int check_dev_err(cm_ctx *ctx) {
+    int e = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&e, ctx->d_err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (e) {
+        return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
+                    (e & cmc::ERR_TID) ? " more than 64 common transcripts for one mate pair;" : "", (e & ~3) ? " other" : "");
+    }
+    return CM_OK;
+}
+
+}  // namespace
+
+// ================================================================== C-ABI
+extern "C" {
+
+int cm_create(const cm_params *p, cm_ctx **out) {
+    if (!p || !out) return CM_EINVAL;
+    *out = nullptr;
+    const int c = p->kmer - CM_WINDOW_SIZE;
+    if (p->kmer < CM_WINDOW_SIZE || c > 8) return CM_EINVAL;
+    if (p->max_chain_len < 1 || p->max_chain_len > CM_BESTCHAINLIM) return CM_EINVAL;   // chain.h:14-17 fixed array
+    if (p->band < 0 || p->band > cmc::MAX_BAND) return CM_EINVAL;
+    if (p->seed_lim < 1 || p->seed_lim > 65535) return CM_EINVAL;
+    if (p->max_ed < 0 || p->max_sc < 0 || p->max_read_len < p->kmer) return CM_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CM_ENODEV;
+    if (p->device < 0 || p->device >= ndev) return CM_ENODEV;
+    if (hipSetDevice(p->device) != hipSuccess) return CM_ENODEV;
+    cm_ctx *ctx = new cm_ctx();
+    ctx->P = *p;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return CM_EHIP;
+    }
+    if (hipMalloc((void **)&ctx->d_pool_cursor, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        delete ctx;
+        return CM_ENOMEM;
+    }
+    (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);
+    (void)hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    *out = ctx;
+    return CM_OK;
+}
+
+void cm_destroy(cm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->P.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    free_reads(ctx);
+    for (auto &s : ctx->slots) {
+        free_all(s.idx_allocs);
+        free_all(s.ann_allocs);
+    }
+    dfree(ctx->d_pool_cursor);
+    dfree(ctx->d_err);
+    dfree(ctx->d_counters);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *cm_last_error(const cm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
+    if (!ctx || !iv) return CM_EINVAL;
+    if (slot < 0 || slot >= MAX_SLOTS) return fail(ctx, CM_EINVAL, "slot %d out of range", slot);
+    if (!iv->genome || !iv->bucket_off || !iv->checksum || !iv->pos) return fail(ctx, CM_EINVAL, "null index array");
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    Slot &s = ctx->slots[slot];
+    free_all(s.idx_allocs);
+    s.loaded = false;
+    const size_t nb = ((size_t)1 << (2 * CM_WINDOW_SIZE)) + 1;
+    s.X = *iv;
+    int rc;
+    if ((rc = up(ctx, s.idx_allocs, iv->genome, (size_t)iv->ref_len, &s.X.genome))) return rc;
+    if ((rc = up(ctx, s.idx_allocs, iv->bucket_off, nb, &s.X.bucket_off))) return rc;
+    if ((rc = up(ctx, s.idx_allocs, iv->checksum, (size_t)iv->n_entries, &s.X.checksum))) return rc;
+    if ((rc = up(ctx, s.idx_allocs, iv->pos, (size_t)iv->n_entries, &s.X.pos))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    s.loaded = true;
+    return CM_OK;
+}
+
+int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
+    if (!ctx || !av) return CM_EINVAL;
+    if (slot < 0 || slot >= MAX_SLOTS) return fail(ctx, CM_EINVAL, "slot %d out of range", slot);
+    if (av->n_iv == 0 || av->n_chr == 0) return fail(ctx, CM_EINVAL, "annotation needs >= 1 interval and >= 1 chromosome");
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    Slot &s = ctx->slots[slot];
+    free_all(s.ann_allocs);
+    s.has_annot = false;
+    s.A = *av;
+    cm_annot_view &A = s.A;
+    int rc;
+    auto &al = s.ann_allocs;
+    const size_t niv = av->n_iv, nseg = av->n_seg, nt = av->n_trans;
+    if ((rc = up(ctx, al, av->iv_spos, niv, &A.iv_spos))) return rc;
+    if ((rc = up(ctx, al, av->iv_epos, niv, &A.iv_epos))) return rc;
+    if ((rc = up(ctx, al, av->iv_max_end, niv, &A.iv_max_end))) return rc;
+    if ((rc = up(ctx, al, av->iv_min_end, niv, &A.iv_min_end))) return rc;
+    if ((rc = up(ctx, al, av->iv_max_next_exon, niv, &A.iv_max_next_exon))) return rc;
+    if ((rc = up(ctx, al, av->iv_seg_off, niv + 1, &A.iv_seg_off))) return rc;
+    if ((rc = up(ctx, al, av->iv_seg, (size_t)av->iv_seg_off[niv], &A.iv_seg))) return rc;
+    if ((rc = up(ctx, al, av->seg_start, nseg, &A.seg_start))) return rc;
+    if ((rc = up(ctx, al, av->seg_end, nseg, &A.seg_end))) return rc;
+    if ((rc = up(ctx, al, av->seg_next_exon_beg, nseg, &A.seg_next_exon_beg))) return rc;
+    if ((rc = up(ctx, al, av->seg_gene_id, nseg, &A.seg_gene_id))) return rc;
+    if ((rc = up(ctx, al, av->seg_tid_off, nseg + 1, &A.seg_tid_off))) return rc;
+    if ((rc = up(ctx, al, av->seg_tid, (size_t)av->seg_tid_off[nseg], &A.seg_tid))) return rc;
+    if ((rc = up(ctx, al, av->trans_start_ind, nt, &A.trans_start_ind))) return rc;
+    if ((rc = up(ctx, al, av->t2s_off, nt + 1, &A.t2s_off))) return rc;
+    if ((rc = up(ctx, al, av->t2s, (size_t)av->t2s_off[nt], &A.t2s))) return rc;
+    if ((rc = up(ctx, al, av->gene_start, (size_t)av->n_gene, &A.gene_start))) return rc;
+    if ((rc = up(ctx, al, av->gene_end, (size_t)av->n_gene, &A.gene_end))) return rc;
+    if ((rc = up(ctx, al, av->near_border_bits, (size_t)(av->n_bits / 64), &A.near_border_bits))) return rc;
+    if ((rc = up(ctx, al, av->intronic_bits, (size_t)(av->n_bits / 64), &A.intronic_bits))) return rc;
+    if ((rc = up(ctx, al, av->chr_shift, (size_t)av->n_chr, &A.chr_shift))) return rc;
+    if ((rc = up(ctx, al, av->chr_id, (size_t)av->n_chr, &A.chr_id))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    s.has_annot = true;
+    return CM_OK;
+}
+
+int cm_unload_contig(cm_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= MAX_SLOTS) return CM_EINVAL;
+    (void)hipSetDevice(ctx->P.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx->slots[slot].idx_allocs);
+    free_all(ctx->slots[slot].ann_allocs);
+    ctx->slots[slot].loaded = ctx->slots[slot].has_annot = false;
+    return CM_OK;
+}
+
+int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior) {
+    if (!ctx || !rd) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_reads(ctx);
+    const uint64_t n = rd->n_pairs;
+    if (n == 0) return CM_OK;
+    if (n > 0x3fffffffull) return fail(ctx, CM_ELIMIT, "more than 2^30 pairs in one batch");
+    if (!rd->seq1 || !rd->seq2 || !rd->off1 || !rd->off2) return fail(ctx, CM_EINVAL, "null read arrays");
+    int max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (rd->off1[i + 1] < rd->off1[i] || rd->off2[i + 1] < rd->off2[i]) return fail(ctx, CM_EINVAL, "read offsets not monotone at pair %llu", (unsigned long long)i);
+        const uint64_t l1 = rd->off1[i + 1] - rd->off1[i], l2 = rd->off2[i + 1] - rd->off2[i];
+        if (l1 > (uint64_t)ctx->P.max_read_len || l2 > (uint64_t)ctx->P.max_read_len)
+            return fail(ctx, CM_EINVAL, "pair %llu longer than max_read_len %d", (unsigned long long)i, ctx->P.max_read_len);
+        if ((int)l1 > max_len) max_len = (int)l1;
+        if ((int)l2 > max_len) max_len = (int)l2;
+    }
+    ctx->n_seeds = max_len / ctx->P.kmer;
+    if (ctx->n_seeds > cmc::MAX_SEEDS) return fail(ctx, CM_ELIMIT, "%d seeds per read > %d supported", ctx->n_seeds, cmc::MAX_SEEDS);
+    const size_t b1 = (size_t)rd->off1[n], b2 = (size_t)rd->off2[n];
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq1, b1 ? b1 : 1));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq2, b2 ? b2 : 1));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_off1, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_off2, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_state, n * sizeof(cm_mapped_read)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_active, n));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cat, n * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq1, rd->seq1, b1, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq2, rd->seq2, b2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_off1, rd->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_off2, rd->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_pairs = n;
+    Core k{};
+    k.P = ctx->P;
+    hipLaunchKernelGGL(k_init_state, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active, ctx->d_cat, n);
+    if (prior) {
+        // carried state of an earlier round: a pair is active unless the caller marks it retired
+        // by type < 0 (never produced by this library); active flags are otherwise all 1.
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, prior, n * sizeof(cm_mapped_read), hipMemcpyHostToDevice, ctx->stream));
+    }
+    // workspace for one tile
+    const uint32_t tile = (uint32_t)(n < TILE_PAIRS ? n : TILE_PAIRS);
+    ctx->tile = tile;
+    const size_t nprob = (size_t)tile * 4, nprobe = nprob * (size_t)(ctx->n_seeds ? ctx->n_seeds : 1);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sstart, nprobe * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scnt, nprobe * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sraw, nprobe * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cells, nprob * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_celloff, (nprob + 1) * 8));
+    // DP cells: room for 64 cells per problem on average, at least 8M (one worst-case problem is
+    // n_seeds * seed_lim cells); larger tiles are split into ranges by run_chain_tile.
+    unsigned long long cap = (unsigned long long)nprob * 64ull;
+    const unsigned long long worst = (unsigned long long)ctx->P.seed_lim * (unsigned long long)(ctx->n_seeds ? ctx->n_seeds : 1);
+    if (cap < (8ull << 20)) cap = 8ull << 20;
+    if (cap < worst) cap = worst;
+    ctx->cells_cap = cap;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_dpscore, cap * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_dpprev, cap * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
+    unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
+    if (pool < (256ull << 20)) pool = 256ull << 20;
+    if (pool > (8ull << 30)) pool = 8ull << 30;
+    ctx->pool_bytes = pool;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pool, pool));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CM_OK;
+}
+
+int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
+    if (!ctx) return CM_EINVAL;
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (ctx->n_pairs == 0) return CM_OK;
+    const Core core = make_core(ctx, ctx->slots[slot]);
+    const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
+    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
+        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
+        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
+        if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
+        {
+            Timer t(ctx, 2);
+            hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), 0, ctx->stream, core, rd, p0, nt, ctx->d_chains,
+                               ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters);
+            ++ctx->launches[2];
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    return CM_OK;
+}
+
+int cm_sync(cm_ctx *ctx) {
+    if (!ctx) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return check_dev_err(ctx);
+}
+
+int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active) {
+    if (!ctx) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    const uint64_t n = ctx->n_pairs;
+    if (n) {
+        if (out_state) HIPCHK(ctx, hipMemcpyAsync(out_state, ctx->d_state, n * sizeof(cm_mapped_read), hipMemcpyDeviceToHost, ctx->stream));
+        if (out_category) HIPCHK(ctx, hipMemcpyAsync(out_category, ctx->d_cat, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (out_active) HIPCHK(ctx, hipMemcpyAsync(out_active, ctx->d_active, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return check_dev_err(ctx);
+}
+
+int cm_map_batch(cm_ctx *ctx, int slot, int is_last_round, const cm_reads *reads, const cm_mapped_read *prior, cm_mapped_read *out_state,
+                 int32_t *out_category) {
+    int rc = cm_reads_upload(ctx, reads, prior);
+    if (rc) return rc;
+    if ((rc = cm_map_round(ctx, slot, is_last_round))) return rc;
+    return cm_reads_download(ctx, out_state, out_category, nullptr);
+}
+
+int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt, uint32_t *out_raw, uint32_t cap_probes, uint32_t *out_n_slots) {
+    if (!ctx || !out_start || !out_cnt || !out_raw || !out_n_slots) return CM_EINVAL;
+    int rc = check_slot(ctx, slot, false);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    *out_n_slots = (uint32_t)ctx->n_seeds;
+    const uint64_t need = ctx->n_pairs * 4ull * (uint64_t)ctx->n_seeds;
+    if (need > cap_probes) return fail(ctx, CM_EINVAL, "cm_seed_batch: need room for %llu probes", (unsigned long long)need);
+    const Core core = make_core(ctx, ctx->slots[slot]);
+    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
+        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
+        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
+        const size_t cnt = (size_t)nt * 4 * ctx->n_seeds, o = (size_t)p0 * 4 * ctx->n_seeds;
+        HIPCHK(ctx, hipMemcpyAsync(out_start + o, ctx->d_sstart, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_cnt + o, ctx->d_scnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_raw + o, ctx->d_sraw, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CM_OK;
+}
+
+int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nchain, int32_t *out_high) {
+    if (!ctx || !out_chains || !out_nchain || !out_high) return CM_EINVAL;
+    int rc = check_slot(ctx, slot, true);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    const Core core = make_core(ctx, ctx->slots[slot]);
+    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
+        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
+        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_chains, 0, (size_t)nt * 4 * CM_BESTCHAINLIM * sizeof(cm_chain), ctx->stream));
+        if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
+        const size_t np = (size_t)nt * 4, o = (size_t)p0 * 4;
+        HIPCHK(ctx, hipMemcpyAsync(out_chains + o * CM_BESTCHAINLIM, ctx->d_chains, np * CM_BESTCHAINLIM * sizeof(cm_chain), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_nchain + o, ctx->d_nchain, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_high + o, ctx->d_high, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return check_dev_err(ctx);
+}
+
+int cm_prof_enable(cm_ctx *ctx, int on) {
+    if (!ctx) return CM_EINVAL;
+    ctx->prof = on != 0;
+    return CM_OK;
+}
+
+int cm_prof_reset(cm_ctx *ctx) {
+    if (!ctx) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->recs.clear();
+    for (int i = 0; i < 4; ++i) {
+        ctx->ms[i] = 0;
+        ctx->launches[i] = 0;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CM_OK;
+}
+
+int cm_prof_get(cm_ctx *ctx, double ms[4], uint64_t launches[4]) {
+    if (!ctx || !ms || !launches) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->recs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ctx->ms[r.cls] += (double)t;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->recs.clear();
+    for (int i = 0; i < 4; ++i) {
+        ms[i] = ctx->ms[i];
+        launches[i] = ctx->launches[i];
+    }
+    return CM_OK;
+}
+
+int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]) {
+    if (!ctx || !c) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) c[i] = h[i];
+    return CM_OK;
+}
+
+}  // extern "C"

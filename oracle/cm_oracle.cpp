@@ -1190,7 +1190,7 @@ struct Ext {
     }
     // calc_middle_ed, extend.cpp:878-920
     int calc_middle_ed(const Chain &ch, int edth, const uint8_t *qseq, int qseq_len) {
-        std::vector<uint8_t> rseq((size_t)qseq_len + 4 * band() + 1, 0), tmp;   // stack buffer in the reference
+        std::vector<uint8_t> tmp;
         int mid_err = 0;
         if (ch.chain_len == 0) return 0;
         for (uint32_t i = 0; i + 1 < ch.chain_len; i++) {
@@ -1202,9 +1202,12 @@ struct Ext {
                 int rlen = qlen + diff;
                 if (rlen < 0) rlen = 0;
                 if ((diff >= 0 && diff <= band()) || (diff < 0 && diff >= -band())) {
-                    if (pac2char(c, rspos, rlen, tmp)) std::copy(tmp.begin(), tmp.end(), rseq.begin());   // failure ignored: stale buffer
-                    if (diff >= 0) mid_err += global_one_side_banded_alignment(qseq + qspos, qlen, rseq.data(), rlen, diff);
-                    else mid_err += global_one_side_banded_alignment(rseq.data(), rlen, qseq + qspos, qlen, -diff);
+                    // The reference ignores a pac2char failure here and aligns against whatever its
+                    // uninitialised stack buffer holds; this restatement defines that case as an all-NUL
+                    // window (only reachable for chains that run off the contig end).
+                    if (!pac2char(c, rspos, rlen, tmp)) tmp.assign((size_t)rlen + 1, 0);
+                    if (diff >= 0) mid_err += global_one_side_banded_alignment(qseq + qspos, qlen, tmp.data(), rlen, diff);
+                    else mid_err += global_one_side_banded_alignment(tmp.data(), rlen, qseq + qspos, qlen, -diff);
                 }
                 if (mid_err > edth) return edth + 1;
             }

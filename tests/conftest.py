@@ -1,0 +1,87 @@
+"""Shared fixtures.  `-m "not gpu"` runs on the build box (no GPU): oracle, host builders, the
+host emulation of the kernel bodies, C-ABI surface.  `-m gpu` are the parity tests proper: the
+HIP path through the C-ABI against the oracle."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from circminer_amd import _build, lib as cl, synth  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    _build.build()
+    from oracle import oracle_py
+    oracle_py.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def emu(built):
+    """Host emulation of the kernel bodies (tests/hostemu.cpp) — test infrastructure only."""
+    out_dir = os.path.join(ROOT, "tests", "_hostemu")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libcmemu.so")
+    srcs = [os.path.join(ROOT, "tests", "hostemu.cpp"), os.path.join(ROOT, "circminer_amd", "csrc", "cm_core.h"),
+            os.path.join(ROOT, "include", "circminer_hot.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(ROOT, "circminer_amd", "csrc"), srcs[0], "-o", so])
+    E = C.CDLL(so)
+    vp, pp = C.c_void_p, C.POINTER
+    E.emu_seed_batch.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.Reads), C.c_uint32, vp, vp, vp]
+    E.emu_chain_batch.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.AnnotView), pp(cl.Reads), vp, vp, vp]
+    E.emu_map_round.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.AnnotView), pp(cl.Reads), C.c_int, vp, vp, vp]
+    E.emu_edit_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int)]
+    E.emu_drop_sc.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int), pp(C.c_int)]
+    E.emu_one_side.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+    return E
+
+
+class DataSet:
+    def __init__(self, tmpdir, preset, n_pairs, seed, kmer=20, **kw):
+        self.d = synth.generate(preset, n_pairs=n_pairs, seed=seed, **kw)
+        self.gtf = os.path.join(str(tmpdir), f"{preset}_{seed}.gtf")
+        with open(self.gtf, "w") as f:
+            f.write(self.d.gtf_text)
+        self.hi = cl.HostIndex(self.d.contigs, self.d.chr_table, self.gtf, kmer=kmer)
+        self.batch = cl.ReadBatch(self.d.seq1, self.d.seq2)
+        self.kmer = kmer
+
+
+@pytest.fixture(scope="session")
+def ds_tiny(tmp_path_factory, built):
+    return DataSet(tmp_path_factory.mktemp("tiny"), "tiny", 1500, 21)
+
+
+@pytest.fixture(scope="session")
+def ds_tiny2r(tmp_path_factory, built):
+    return DataSet(tmp_path_factory.mktemp("tiny2r"), "tiny2r", 1200, 22)
+
+
+@pytest.fixture(scope="session")
+def ds_small(tmp_path_factory, built):
+    return DataSet(tmp_path_factory.mktemp("small"), "small", 20000, 23)
+
+
+def states_equal(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+def first_diff(a, b):
+    for i in range(len(a)):
+        if a[i].tobytes() != b[i].tobytes():
+            return i, a[i], b[i]
+    return None

@@ -1,0 +1,176 @@
+// hostemu.cpp — TEST-ONLY harness that runs the device bodies of circminer_amd/csrc/cm_core.h
+// lane-by-lane on the host CPU, so the kernel logic can be stepped through and compared with
+// the oracle on the build box (which has no GPU).  It mirrors the launch structure of
+// cm_hot.hip (seed -> cells/scan -> chain -> pair) but is never linked into libcmhot.so, never
+// shipped, and is not a fallback: the product C-ABI has no CPU path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "circminer_hot.h"
+#include "cm_core.h"
+
+using cmc::Core;
+
+namespace {
+struct Emu {
+    Core core;
+    const cm_reads *R;
+    int S;
+    std::vector<uint32_t> sstart, scnt, sraw;
+    std::vector<cm_chain> chains;
+    std::vector<int32_t> nchain, high;
+    std::vector<uint8_t> pool;
+    unsigned long long cursor = 0;
+    int err = 0;
+};
+
+int n_seeds_of(const cm_params *P, const cm_reads *R) {
+    uint64_t mx = 0;
+    for (uint64_t i = 0; i < R->n_pairs; ++i) {
+        mx = std::max<uint64_t>(mx, R->off1[i + 1] - R->off1[i]);
+        mx = std::max<uint64_t>(mx, R->off2[i + 1] - R->off2[i]);
+    }
+    return (int)(mx / (uint64_t)P->kmer);
+}
+
+void seed_all(Emu &e, const uint8_t *active) {
+    const uint64_t n = e.R->n_pairs;
+    const int S = e.S;
+    e.sstart.assign(n * 4 * S + 1, 0);
+    e.scnt.assign(n * 4 * S + 1, 0);
+    e.sraw.assign(n * 4 * S + 1, 0);
+    for (uint64_t q = 0; q < n * 4 * (uint64_t)S; ++q) {
+        const uint32_t s = (uint32_t)(q % S);
+        const uint64_t r = q / S;
+        const int orient = r & 1, mate = (r >> 1) & 1;
+        const uint64_t p = r >> 2;
+        if (active && !active[p]) continue;
+        const uint64_t o0 = mate ? e.R->off2[p] : e.R->off1[p], o1 = mate ? e.R->off2[p + 1] : e.R->off1[p + 1];
+        const int len = (int)(o1 - o0), k = e.core.P.kmer;
+        if ((int)(s + 1) * k > len) continue;
+        const cmc::Read rd{(mate ? e.R->seq2 : e.R->seq1) + o0, len, orient};
+        const cmc::Probe pr = cmc::seed_probe(e.core, rd.view(), (int)s * k);
+        e.sstart[q] = pr.start;
+        e.sraw[q] = pr.raw;
+        e.scnt[q] = pr.raw > (uint32_t)e.core.P.seed_lim ? 0u : pr.raw;
+    }
+}
+
+void chain_all(Emu &e, const uint8_t *active) {
+    const uint64_t n = e.R->n_pairs;
+    const int S = e.S;
+    e.chains.assign(n * 4 * CM_BESTCHAINLIM + 1, cm_chain{});
+    e.nchain.assign(n * 4 + 1, 0);
+    e.high.assign(n * 4 + 1, 0);
+    e.pool.resize(64u << 20);
+    std::vector<double> dps;
+    std::vector<int32_t> dpp;
+    for (uint64_t r = 0; r < n * 4; ++r) {
+        const uint64_t p = r >> 2;
+        if (active && !active[p]) continue;
+        const int mate = (r >> 1) & 1;
+        const int len = (int)(mate ? e.R->off2[p + 1] - e.R->off2[p] : e.R->off1[p + 1] - e.R->off1[p]);
+        uint32_t st[cmc::MAX_SEEDS], cn[cmc::MAX_SEEDS];
+        size_t cells = 0;
+        int hh = 0;
+        for (int s = 0; s < S; ++s) {
+            st[s] = e.sstart[r * S + s];
+            cn[s] = e.scnt[r * S + s];
+            cells += cn[s];
+            if (e.sraw[r * S + s] > 0 && cn[s] == 0) ++hh;
+        }
+        dps.assign(cells + 1, 0);
+        dpp.assign(cells + 1, 0);
+        e.cursor = 0;
+        cmc::ChainWork w{dps.data(), dpp.data(), e.pool.data(), (unsigned long long)e.pool.size(), &e.cursor, &e.err};
+        e.nchain[r] = cmc::chain_kbest(e.core, len, S, st, cn, w, e.chains.data() + r * CM_BESTCHAINLIM);
+        e.high[r] = hh;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int emu_seed_batch(const cm_params *P, const cm_index_view *X, const cm_reads *R, uint32_t n_slots, uint32_t *out_start, uint32_t *out_cnt,
+                   uint32_t *out_raw) {
+    Emu e;
+    e.core.P = *P;
+    e.core.X = *X;
+    memset(&e.core.A, 0, sizeof e.core.A);
+    e.R = R;
+    e.S = n_seeds_of(P, R);
+    if ((uint32_t)e.S != n_slots) return -100;
+    seed_all(e, nullptr);
+    const size_t k = (size_t)R->n_pairs * 4 * e.S;
+    memcpy(out_start, e.sstart.data(), k * 4);
+    memcpy(out_cnt, e.scnt.data(), k * 4);
+    memcpy(out_raw, e.sraw.data(), k * 4);
+    return 0;
+}
+
+int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, cm_chain *out_chains,
+                    int32_t *out_nchain, int32_t *out_high) {
+    Emu e;
+    e.core.P = *P;
+    e.core.X = *X;
+    e.core.A = *A;
+    e.R = R;
+    e.S = n_seeds_of(P, R);
+    seed_all(e, nullptr);
+    chain_all(e, nullptr);
+    const size_t np = (size_t)R->n_pairs * 4;
+    memcpy(out_chains, e.chains.data(), np * CM_BESTCHAINLIM * sizeof(cm_chain));
+    memcpy(out_nchain, e.nchain.data(), np * 4);
+    memcpy(out_high, e.high.data(), np * 4);
+    return e.err;
+}
+
+int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last, cm_mapped_read *state,
+                  uint8_t *active, int32_t *category) {
+    Emu e;
+    e.core.P = *P;
+    e.core.X = *X;
+    e.core.A = *A;
+    e.R = R;
+    e.S = n_seeds_of(P, R);
+    seed_all(e, active);
+    chain_all(e, active);
+    for (uint64_t p = 0; p < R->n_pairs; ++p) {
+        if (!active[p]) {
+            category[p] = -1;
+            continue;
+        }
+        cmc::ChainSet sets[4];
+        int hh[4];
+        for (int x = 0; x < 4; ++x) {
+            sets[x].ch = e.chains.data() + (p * 4 + x) * CM_BESTCHAINLIM;
+            sets[x].n = e.nchain[p * 4 + x];
+            hh[x] = e.high[p * 4 + x];
+        }
+        const int l1 = (int)(R->off1[p + 1] - R->off1[p]), l2 = (int)(R->off2[p + 1] - R->off2[p]);
+        const int st = cmc::process_read(e.core, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);
+        cmc::finish_round(e.core, st, is_last, l1, l2, state[p], active[p]);
+        category[p] = st;
+    }
+    return e.err;
+}
+
+// stand-alone DP bodies for the property tests of A14
+int emu_edit_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *indel, int *score) {
+    Core c{};
+    c.P = *P;
+    return cmc::local_alignment_side(c, cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, left != 0, *indel, *score);
+}
+int emu_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *sclen, int *indel, int *score) {
+    Core c{};
+    c.P = *P;
+    cmc::SV a{s, 0, 1, 0}, b{t, 0, 1, 0};
+    if (left) return cmc::local_alignment_sc(c, a.rev(n), n, b.rev(m), m, *sclen, *indel, *score);
+    return cmc::local_alignment_sc(c, a, n, b, m, *sclen, *indel, *score);
+}
+int emu_one_side(const uint8_t *s, int n, const uint8_t *t, int m, int w) {
+    return cmc::one_side_banded(cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, w);
+}
+}

@@ -1,0 +1,99 @@
+"""GPU parity tests proper: HIP path through the C-ABI vs the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+from circminer_amd import lib as cl
+from oracle import oracle_py as op
+from conftest import first_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _chains_equal(c0, n0, c1, n1):
+    assert (n0 == n1).all()
+    a, b = c0.reshape(-1, cl.CM_BESTCHAINLIM), c1.reshape(-1, cl.CM_BESTCHAINLIM)
+    for r in np.nonzero(n0)[0]:
+        for k in range(n0[r]):
+            x, y = a[r, k], b[r, k]
+            L = int(x["chain_len"])
+            assert L == int(y["chain_len"]), (r, k)
+            assert x["score"] == y["score"], (r, k, x["score"], y["score"])      # fp32 of the fp64 sum, exact
+            assert (x["rpos"][:L] == y["rpos"][:L]).all() and (x["qpos"][:L] == y["qpos"][:L]).all(), (r, k)
+
+
+def _run_all_rounds(ds, P):
+    hp = cl.HotPath(P)
+    st0, act0 = op.default_state(P, ds.batch.n)
+    hp.upload(ds.batch)
+    for ci in range(ds.hi.n_contigs):
+        last = ci == ds.hi.n_contigs - 1
+        hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
+        cat0 = op.map_round(P, ds.hi.views[ci], ds.hi.annots[ci], ds.batch, last, st0, act0)
+        hp.map_round(ci, last)
+        st1, cat1, act1 = hp.download()
+        assert (cat0 == cat1).all(), np.nonzero(cat0 != cat1)[0][:10]
+        assert (act0 == act1).all()
+        assert st0.tobytes() == st1.tobytes(), first_diff(st0, st1)
+    hp.close()
+    return st0
+
+
+@pytest.mark.parametrize("name", ["ds_tiny", "ds_small"])
+def test_seed_parity(name, request):
+    ds = request.getfixturevalue(name)
+    P = cl.default_params(kmer=ds.kmer)
+    hp = cl.HotPath(P)
+    hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
+    hp.upload(ds.batch)
+    a1, b1, c1, S = hp.seeds(0)
+    a0, b0, c0 = op.seeds(P, ds.hi.views[0], ds.batch, S)
+    assert (c0 == c1).all() and (b0 == b1).all()
+    m = c0 > 0
+    assert (a0[m] == a1[m]).all()
+    hp.close()
+
+
+@pytest.mark.parametrize("name", ["ds_tiny", "ds_small"])
+def test_chain_parity(name, request):
+    ds = request.getfixturevalue(name)
+    P = cl.default_params(kmer=ds.kmer)
+    hp = cl.HotPath(P)
+    hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
+    hp.upload(ds.batch)
+    c1, n1, h1 = hp.chains(0)
+    c0, n0, h0 = op.chains(P, ds.hi.views[0], ds.hi.annots[0], ds.batch)
+    assert (h0 == h1).all()
+    _chains_equal(c0, n0, c1, n1)
+    hp.close()
+
+
+@pytest.mark.parametrize("name", ["ds_tiny", "ds_tiny2r", "ds_small"])
+def test_map_parity_all_rounds(name, request):
+    ds = request.getfixturevalue(name)
+    st = _run_all_rounds(ds, cl.default_params(kmer=ds.kmer))
+    # planted truth: most transcriptomic pairs come back concordant at the planted coordinates
+    m = (ds.d.src == 0)
+    assert (st["type"][m] == cl.CAT["CONCRD"]).mean() > 0.9
+
+
+@pytest.mark.parametrize("kw", [dict(scan_level=1), dict(scan_level=2, max_ed=8, seed_lim=1000), dict(max_chain_len=5, max_tlen=300)])
+def test_map_parity_param_variants(ds_tiny2r, kw):
+    _run_all_rounds(ds_tiny2r, cl.default_params(kmer=ds_tiny2r.kmer, **kw))
+
+
+def test_map_batch_wrapper_and_errors(ds_tiny):
+    P = cl.default_params()
+    hp = cl.HotPath(P)
+    with pytest.raises(RuntimeError):
+        hp.upload(ds_tiny.batch)
+        hp.map_round(3, True)           # slot not loaded -> CM_ESTATE, never a crash
+    hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
+    st = np.zeros(ds_tiny.batch.n, dtype=cl.MAPPED_DTYPE)
+    cat = np.zeros(ds_tiny.batch.n, dtype=np.int32)
+    import ctypes as C
+    rc = hp.L.cm_map_batch(hp.h, 0, 1, C.byref(ds_tiny.batch.c), None, st.ctypes.data, cat.ctypes.data)
+    assert rc == 0
+    st0, act0 = op.default_state(P, ds_tiny.batch.n)
+    cat0 = op.map_round(P, ds_tiny.hi.views[0], ds_tiny.hi.annots[0], ds_tiny.batch, True, st0, act0)
+    assert (cat0 == cat).all() and st0.tobytes() == st.tobytes()
+    hp.close()

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X mapping hot path (BASELINE.json metric: paired reads/s).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pass of the hot path — every mapping round (one per packed contig) — over one
+resident batch of synthetic read pairs, plus (N > 1) the RCCL gather of the back-splice-junction
+records to rank 0.  The index, genome, annotation and the reads are staged into HBM before the
+timed region; each step starts from the first-round state (cm_reads_reset, no host traffic).
+Default workload = BASELINE.json configs[1]: chr21-like 46.7 Mbp contig, k=20, 1 M 2x150 bp pairs.
+
+Weak scaling: every rank maps its own shard of `--pairs` pairs against its own replica of the
+index; value = (pairs of all ranks x steps) / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+KERNELS = ["k_seed", "k_chain", "k_pair", "k_cells+k_scan"]
+
+
+def algorithmic_bytes(counters):
+    """SURVEY.md §8(d) per-pair-round figure, split by the kernel that moves the bytes
+    (DESIGN.md §6): probes pay 16 B (bucket offset + count header) + 8 B per binary-search touch
+    and the two reads come in once (300 B); chaining consumes 8 B per retained hit; pairing /
+    extension is charged the survey's upper bound of four 170-byte reference windows (1360 B)
+    plus the 96-byte result record."""
+    probes, touches, hits, pair_rounds = counters
+    return [16 * probes + 8 * touches + 300 * pair_rounds, 8 * hits, (1360 + 96) * pair_rounds, 0]
+
+
+def cpu_baseline(P, hi, batch, target_s=15.0):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host
+    cores of this box (ctypes releases the GIL).  Reported, not the target."""
+    from oracle import oracle_py as op
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    probe_n = min(batch.n, 4000)
+    st, act = op.default_state(P, batch.n)
+    t = time.time()
+    for ci in range(hi.n_contigs):
+        op.map_round(P, hi.views[ci], hi.annots[ci], batch, ci == hi.n_contigs - 1, st, act, 0, probe_n)
+    rate1 = probe_n / max(time.time() - t, 1e-6)
+    n = int(min(batch.n, max(probe_n, rate1 * cores * target_s * 0.6)))
+    st, act = op.default_state(P, batch.n)
+    bounds = [(n * i) // cores for i in range(cores + 1)]
+
+    def work(a, b):
+        for ci in range(hi.n_contigs):
+            op.map_round(P, hi.views[ci], hi.annots[ci], batch, ci == hi.n_contigs - 1, st, act, a, b)
+
+    th = [threading.Thread(target=work, args=(bounds[i], bounds[i + 1])) for i in range(cores)]
+    t = time.time()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.time() - t
+    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} pairs of the same workload, all rounds, oracle/cm_oracle.cpp on {cores} threads, {dt:.1f}s",
+            "single_thread_value": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="chr21")
+    ap.add_argument("--pairs", type=int, default=1_000_000)
+    ap.add_argument("--seed", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if collected")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from circminer_amd import dist as cdist, lib as cl, synth
+
+    # ---- synthetic workload (same genome + annotation on every rank, own shard of reads) ----
+    t0 = time.time()
+    d = synth.generate(args.workload, n_pairs=args.pairs, seed=args.seed, read_seed=rank)
+    with tempfile.TemporaryDirectory() as td:
+        gtf = os.path.join(td, "ref.gtf")
+        with open(gtf, "w") as f:
+            f.write(d.gtf_text)
+        hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, n_threads=max(1, (os.cpu_count() or 8) // max(world, 1)))
+    P = cl.default_params(device=local_rank)
+    batch = cl.ReadBatch(d.seq1, d.seq2)
+    prep_s = time.time() - t0
+
+    hp = cl.HotPath(P)
+    for ci in range(hi.n_contigs):
+        hp.load_contig(ci, hi.views[ci], hi.annots[ci])
+    hp.upload(batch)
+    base = rank * args.pairs
+
+    def step():
+        hp.reset()
+        for ci in range(hi.n_contigs):
+            hp.map_round(ci, ci == hi.n_contigs - 1)
+        idx, st = hp.collect_active()          # BSJ hand-off to stage 2 (small D2H; syncs the stream)
+        if world > 1:
+            return cdist.gather_bsj(cdist.pack_records(idx + base, st), device=dev)
+        return cdist.pack_records(idx + base, st)
+
+    def fence():
+        hp.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    hp.prof(True)
+    hp.prof_reset()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    fence()
+    dt = time.perf_counter() - t
+    ms, launches, counters = hp.prof_get()
+    hp.prof(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_pairs = args.pairs * world * args.steps
+        value = total_pairs / dt
+        ab = algorithmic_bytes(counters)
+        dom = int(np.argmax(ms[:3]))
+        avg_ms = ms[dom] / max(launches[dom], 1)
+        achieved = (ab[dom] / max(launches[dom], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(args.traffic) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload and tj.get("pairs") == args.pairs:
+                traffic = tj.get("bytes_per_launch", {}).get(KERNELS[dom])
+        except Exception:
+            traffic = None
+        out = {
+            "metric": "paired reads/sec (whole node), hg38 k=20, 2x150 bp; circ_report bit-exact",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32/u8 (chain scores f64)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-like synthetic contig ({sum(len(c) for c in d.contigs)} bp, "
+                                   f"{len(d.genes)} genes), k=20, {args.pairs} 2x150 bp pairs per GPU, "
+                                   f"{hi.n_contigs} round(s), defaults (BASELINE.json configs[1])",
+                       "pairs_per_gpu": args.pairs, "rounds": hi.n_contigs, "bsj_records": int(len(rec)),
+                       "prep_seconds": round(prep_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": launches[dom],
+                         "algorithmic_bytes_per_launch": ab[dom] / max(launches[dom], 1)},
+            "kernels": {KERNELS[i]: {"ms_total": ms[i], "launches": launches[i], "algorithmic_bytes": ab[i]} for i in range(4)},
+            "counters": {"probes": counters[0], "search_touches": counters[1], "hits_consumed": counters[2], "pair_rounds": counters[3]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, hi, batch)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    hp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,11 +21,87 @@
 
 #if defined(__HIPCC__)
 #define CM_HD __host__ __device__
+#define CM_NOINLINE inline
 #else
 #define CM_HD
+#define CM_NOINLINE
+#endif
+
+// test-only work counters (defined by tests/hostemu.cpp when it wants them)
+#if defined(CM_STATS) && !defined(__HIPCC__)
+extern "C" unsigned long long cm_stats[16];
+#define CM_STAT(i, n) (cm_stats[i] += (unsigned long long)(n))
+#else
+#define CM_STAT(i, n) ((void)0)
+#endif
+
+// Explicit address spaces for the device build.  Pointers travel through structs and private
+// arrays here; without the qualifiers the compiler loses their provenance and emits flat_load /
+// flat_store (no ds_*, no global_* with scalar bases), which is several times slower.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_G __attribute__((address_space(1)))
+#define CM_L __attribute__((address_space(3)))
+#else
+#define CM_G
+#define CM_L
 #endif
 
 namespace cmc {
+
+typedef const CM_G uint8_t *g_u8;
+typedef const CM_G uint16_t *g_u16;
+typedef const CM_G uint32_t *g_u32;
+typedef const CM_G int32_t *g_i32;
+typedef const CM_G uint64_t *g_u64;
+typedef const CM_G cm_chain *g_chain;
+typedef CM_G int *g_err;
+
+// device mirrors of cm_index_view / cm_annot_view (same fields, global-qualified pointers)
+struct IndexV {
+    int32_t contig_num;
+    uint32_t ref_len;
+    g_u8 genome;
+    g_u32 bucket_off;
+    g_u16 checksum;
+    g_u32 pos;
+    uint64_t n_entries;
+};
+struct AnnotV {
+    uint32_t n_iv;
+    g_u32 iv_spos, iv_epos, iv_max_end, iv_min_end, iv_max_next_exon, iv_seg_off, iv_seg;
+    uint32_t n_seg;
+    g_u32 seg_start, seg_end, seg_next_exon_beg, seg_gene_id, seg_tid_off, seg_tid;
+    uint32_t n_trans;
+    g_i32 trans_start_ind;
+    g_u32 t2s_off;
+    g_u8 t2s;
+    uint32_t n_gene;
+    g_u32 gene_start, gene_end;
+    uint64_t n_bits;
+    g_u64 near_border_bits, intronic_bits;
+    uint32_t n_chr;
+    g_u32 chr_shift;
+    g_i32 chr_id;
+};
+CM_HD inline IndexV to_dev(const cm_index_view &v) {
+    IndexV d;
+    d.contig_num = v.contig_num; d.ref_len = v.ref_len; d.n_entries = v.n_entries;
+    d.genome = (g_u8)v.genome; d.bucket_off = (g_u32)v.bucket_off; d.checksum = (g_u16)v.checksum; d.pos = (g_u32)v.pos;
+    return d;
+}
+CM_HD inline AnnotV to_dev(const cm_annot_view &v) {
+    AnnotV d;
+    d.n_iv = v.n_iv; d.n_seg = v.n_seg; d.n_trans = v.n_trans; d.n_gene = v.n_gene; d.n_bits = v.n_bits; d.n_chr = v.n_chr;
+    d.iv_spos = (g_u32)v.iv_spos; d.iv_epos = (g_u32)v.iv_epos; d.iv_max_end = (g_u32)v.iv_max_end; d.iv_min_end = (g_u32)v.iv_min_end;
+    d.iv_max_next_exon = (g_u32)v.iv_max_next_exon; d.iv_seg_off = (g_u32)v.iv_seg_off; d.iv_seg = (g_u32)v.iv_seg;
+    d.seg_start = (g_u32)v.seg_start; d.seg_end = (g_u32)v.seg_end; d.seg_next_exon_beg = (g_u32)v.seg_next_exon_beg;
+    d.seg_gene_id = (g_u32)v.seg_gene_id; d.seg_tid_off = (g_u32)v.seg_tid_off; d.seg_tid = (g_u32)v.seg_tid;
+    d.trans_start_ind = (g_i32)v.trans_start_ind; d.t2s_off = (g_u32)v.t2s_off; d.t2s = (g_u8)v.t2s;
+    d.gene_start = (g_u32)v.gene_start; d.gene_end = (g_u32)v.gene_end;
+    d.near_border_bits = (g_u64)v.near_border_bits; d.intronic_bits = (g_u64)v.intronic_bits;
+    d.chr_shift = (g_u32)v.chr_shift; d.chr_id = (g_i32)v.chr_id;
+    return d;
+}
 
 constexpr int INF_I = 1000000000;          // (int)INF, src/common.h:34
 constexpr uint32_t MINLB = 0u;
@@ -41,11 +117,23 @@ constexpr int MEMO_N = 8;                   // memoised exon alignments per exte
 
 enum { ERR_POOL = 1, ERR_TID = 2, ERR_SEEDS = 4, ERR_BAND = 8 };
 
+struct KCore {          // what the host passes as a kernel argument (plain C views, device pointers)
+    cm_params P;
+    cm_index_view X;
+    cm_annot_view A;
+};
 struct Core {
     cm_params P;
-    cm_index_view X;    // device pointers
-    cm_annot_view A;    // device pointers
+    IndexV X;
+    AnnotV A;
 };
+CM_HD inline Core to_core(const KCore &k) {
+    Core c;
+    c.P = k.P;
+    c.X = to_dev(k.X);
+    c.A = to_dev(k.A);
+    return c;
+}
 
 template <class T> CM_HD inline T cmin(T a, T b) { return a < b ? a : b; }
 template <class T> CM_HD inline T cmax(T a, T b) { return a > b ? a : b; }
@@ -66,7 +154,7 @@ CM_HD inline uint8_t comp_base(uint8_t ch) {      // FASTQParser::set_comp, src/
     }
 }
 struct SV {
-    const uint8_t *p;
+    g_u8 p;
     int32_t off;
     int32_t step;     // +1 / -1
     int32_t mode;     // 0 plain, 1 complemented, 2 all-NUL
@@ -79,7 +167,7 @@ struct SV {
     CM_HD inline SV rev(int m) const { return SV{p, off + (m - 1) * step, -step, mode}; }   // first m chars reversed
 };
 struct Read {             // one mate in one orientation
-    const uint8_t *p;
+    g_u8 p;
     int32_t len;
     int32_t rc;
     CM_HD inline SV view() const { return rc ? SV{p, len - 1, -1, 1} : SV{p, 0, 1, 0}; }
@@ -134,7 +222,7 @@ CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
     }
     const uint32_t b0 = c.X.bucket_off[hv], b1 = c.X.bucket_off[hv + 1];
     if (b1 == b0) return r;
-    const uint16_t *it = c.X.checksum + b0;
+    const g_u16 it = c.X.checksum + b0;
     const int target = (int)(int16_t)cv;     // int16 quirk, src/match_read.cpp:77
     uint32_t lb = 1, ub = b1 - b0, mid;
     while (lb < ub) {
@@ -164,11 +252,11 @@ CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
 // ------------------------------------------------------------------------------------------
 // annotation queries (A7)
 // ------------------------------------------------------------------------------------------
-CM_HD inline bool bit_at(const uint64_t *b, uint64_t n, uint64_t p) { return p < n && ((b[p >> 6] >> (p & 63)) & 1ull); }
-CM_HD inline uint32_t iv_nseg(const cm_annot_view &A, int iv) { return A.iv_seg_off[iv + 1] - A.iv_seg_off[iv]; }
-CM_HD inline uint32_t iv_segid(const cm_annot_view &A, int iv, uint32_t i) { return A.iv_seg[A.iv_seg_off[iv] + i]; }
+CM_HD inline bool bit_at(g_u64 b, uint64_t n, uint64_t p) { return p < n && ((b[p >> 6] >> (p & 63)) & 1ull); }
+CM_HD inline uint32_t iv_nseg(const AnnotV &A, int iv) { return A.iv_seg_off[iv + 1] - A.iv_seg_off[iv]; }
+CM_HD inline uint32_t iv_segid(const AnnotV &A, int iv, uint32_t i) { return A.iv_seg[A.iv_seg_off[iv] + i]; }
 
-CM_HD inline int iv_find_ind(const cm_annot_view &A, uint32_t pos, int &ind) {   // interval_tree_impl.h:136-175
+CM_HD inline int iv_find_ind(const AnnotV &A, uint32_t pos, int &ind) {   // interval_tree_impl.h:136-175
     ind = -1;
     if (pos < A.iv_spos[0]) return -1;
     int beg = 0, end = (int)A.n_iv;
@@ -189,7 +277,7 @@ CM_HD inline int overlap_ind(const Core &c, uint32_t loc, int &ind) {           
 CM_HD inline int overlap(const Core &c, uint32_t loc) { int ind; return overlap_ind(c, loc, ind); }
 
 CM_HD inline uint32_t upper_bound_lookup(const Core &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end, int &ol) {
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     max_end = 0;
     int it_ind = -1;
     int ov = iv_find_ind(A, spos, it_ind);
@@ -246,17 +334,17 @@ CM_HD inline int chr_row(const Core &c, uint32_t loc) {      // GTFParser::get_s
 // ------------------------------------------------------------------------------------------
 struct Event { double score; uint32_t cell; uint32_t pad; };
 struct ChainWork {
-    double *dp_score;                 // this problem's cells
-    int32_t *dp_prev;                 // (list << 16 | ind) or -1
-    uint8_t *pool;                    // event pool shared by the launch
+    CM_G double *dp_score;            // this problem's cells
+    CM_G int32_t *dp_prev;            // (list << 16 | ind) or -1
+    CM_G uint8_t *pool;               // event pool shared by the launch
     unsigned long long pool_bytes;
-    unsigned long long *pool_cursor;
-    int *err;
+    CM_G unsigned long long *pool_cursor;
+    g_err err;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-CM_HD inline unsigned long long pool_take(unsigned long long *cur, unsigned long long n) { return atomicAdd(cur, n); }
-CM_HD inline void flag_err(int *e, int bits) { atomicOr(e, bits); }
+CM_HD inline unsigned long long pool_take(CM_G unsigned long long *cur, unsigned long long n) { return atomicAdd((unsigned long long *)cur, n); }
+CM_HD inline void flag_err(g_err e, int bits) { atomicOr((int *)e, bits); }
 #else
 inline unsigned long long pool_take(unsigned long long *cur, unsigned long long n) { return __sync_fetch_and_add(cur, n); }
 inline void flag_err(int *e, int bits) { __sync_fetch_and_or(e, bits); }
@@ -268,7 +356,7 @@ CM_HD inline bool check_junction(const Core &c, uint32_t s1, uint32_t s2, int ol
     const uint32_t e1 = s1 + kmer - 1;
     if (s2 <= e1) return false;
     int td2intron = -1;
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     const uint32_t n = iv_nseg(A, ol);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t s = iv_segid(A, ol, i);
@@ -289,10 +377,10 @@ CM_HD inline bool check_junction(const Core &c, uint32_t s1, uint32_t s2, int ol
 
 // seeds: ordinal s has qpos s*kmer, hits pos[start[s] .. start[s]+cnt[s]).  Returns #chains.
 CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint32_t *start, const uint32_t *cnt,
-                             ChainWork &w, cm_chain *out) {
+                             ChainWork &w, CM_G cm_chain *out) {
     const int kmer = c.P.kmer;
     const uint32_t max_best = (uint32_t)c.P.max_chain_len;
-    const uint32_t *POS = c.X.pos;
+    const g_u32 POS = c.X.pos;
     int kc = n_seeds;
     while (kc >= 1 && cnt[kc - 1] == 0) --kc;
     if (kc <= 0) return 0;
@@ -303,7 +391,7 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
         w.dp_score[x] = (double)kmer;
         w.dp_prev[x] = -1;
     }
-    Event *ev = nullptr;
+    CM_G Event *ev = nullptr;
     uint32_t n_ev = 0, cap_ev = 0;
     bool lost = false;
     uint32_t lb_ind[MAX_SEEDS];
@@ -321,7 +409,7 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
             for (int jj = ii + 1; jj < kc; ++jj) {
                 const uint32_t pcn = cnt[jj];
                 if (pcn == 0 || lb_ind[jj] >= pcn) continue;
-                const uint32_t *pp = POS + start[jj];
+                const g_u32 pp = POS + start[jj];
                 if (cur_info + c.P.max_intron < (int32_t)pp[lb_ind[jj]]) continue;
                 while (lb_ind[jj] < pcn && (int32_t)pp[lb_ind[jj]] <= cur_info) ++lb_ind[jj];
                 if (lb_ind[jj] >= pcn) continue;
@@ -358,7 +446,7 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
                                 lost = true;
                                 flag_err(w.err, ERR_POOL);
                             } else {
-                                Event *ne = reinterpret_cast<Event *>(w.pool + off);
+                                CM_G Event *ne = (CM_G Event *)(w.pool + off);
                                 for (uint32_t q = 0; q < n_ev; ++q) ne[q] = ev[q];
                                 ev = ne;
                                 cap_ev = ncap;
@@ -400,7 +488,7 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
                             if (out[a].rpos[b] == spos) { rep = true; break; }
                     if (rep) continue;
                 }
-                cm_chain &ch = out[best_count++];
+                CM_G cm_chain &ch = out[best_count++];
                 uint32_t n = 0;
                 while (true) {
                     ch.rpos[n] = POS[start[bl] + bi];
@@ -429,7 +517,7 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
         for (int ii = kc - 1; ii >= 0; --ii)
             for (uint32_t i = 0; i < cnt[ii]; ++i) {
                 if (best_count >= max_best) break;
-                cm_chain &ch = out[best_count++];
+                CM_G cm_chain &ch = out[best_count++];
                 ch.rpos[0] = POS[start[ii] + i];
                 ch.qpos[0] = ii * kmer;
                 ch.score = (float)w.dp_score[base[ii] + i];
@@ -477,62 +565,138 @@ CM_HD inline bool cand_less(const Cand &a, const Cand &b) {     // AlignCandid::
     return cabs(a.indel) < cabs(b.indel);
 }
 
-// full Levenshtein for the tiny fallbacks (n <= 2w or m <= w, or n <= w for the one-sided form);
-// returns dp[i][m] for the rows the caller asks for through `col` (size n+1).
+// ---- per-lane staged strings -------------------------------------------------------------
+// Every DP first stages its two strings as base codes (A0 C1 G2 T3 case-insensitive, anything
+// else 4 in the first string and 5 in the second, so "other" never matches anything — N vs N
+// included, src/align.cpp:745-759) into a private buffer, already in the order the DP walks them
+// (the left-hand variants stage reversed views).  On the GPU the buffer is LDS, word-interleaved
+// across the 64 lanes of the wave (byte i of lane l lives in word (i/4)*64 + l), so concurrent
+// per-lane accesses fall in distinct banks; on the host build it is a plain array.
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int LSTRIDE = 64;
+#else
+constexpr int LSTRIDE = 1;
+#endif
+struct LBuf {
+    CM_L uint8_t *b;
+    int cap;
+    CM_HD inline uint8_t get(int i) const { return b[(i >> 2) * (4 * LSTRIDE) + (i & 3)]; }
+    CM_HD inline void put(int i, uint8_t v) const { b[(i >> 2) * (4 * LSTRIDE) + (i & 3)] = v; }
+};
+// 4 ASCII bases -> 4 one-byte codes (SWAR).  A/a 0, C/c 1, T/t 2, G/g 3 (= (ch >> 1) & 3 of the
+// upper-cased byte; only equality of codes matters to the DPs), complement = code ^ 2, any other
+// byte -> `other`.
+CM_HD inline uint32_t swar_zero_bytes(uint32_t t) { return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu); }   // 0x80 where byte == 0
+CM_HD inline uint32_t code4(uint32_t w, bool comp, uint8_t other) {
+    const uint32_t x = w & 0xDFDFDFDFu;
+    const uint32_t valid = swar_zero_bytes(x ^ 0x41414141u) | swar_zero_bytes(x ^ 0x43434343u) | swar_zero_bytes(x ^ 0x47474747u) |
+                           swar_zero_bytes(x ^ 0x54545454u);
+    const uint32_t m = (valid >> 7) * 0xFFu;                  // 0xFF in valid bytes
+    uint32_t code = (x >> 1) & 0x03030303u;
+    if (comp) code ^= 0x02020202u;
+    return (code & m) | ((0x01010101u * other) & ~m);
+}
+CM_HD inline uint8_t code1(uint8_t ch, bool comp, uint8_t other) { return (uint8_t)(code4(ch, comp, other) & 0xFFu); }
+
+// Copy the first n characters of view v into the staging buffer as codes.
+// Device build: 16-byte global loads (the caller guarantees CM_STAGE_PAD readable bytes on both
+// sides of every global string, see cm_hot.hip) + whole-word LDS stores.
+constexpr int CM_STAGE_PAD = 64;
+CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    CM_L uint32_t *dw = (CM_L uint32_t *)d.b;
+    const int nw = (n + 3) >> 2;
+    if (v.mode == 2) {
+        for (int w = 0; w < nw; ++w) dw[w * LSTRIDE] = 0x01010101u * other;
+        return;
+    }
+    const bool comp = v.mode == 1;
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+        uint32_t q[4];
+        if (v.step > 0) {
+            __builtin_memcpy(q, (const CM_G uint8_t *)(v.p + v.off + 4 * w0), 16);
+        } else {
+            uint32_t r[4];                                     // chars 4*w0 .. 4*w0+15 live at p[off - i]
+            __builtin_memcpy(r, (const CM_G uint8_t *)(v.p + v.off - 4 * w0 - 15), 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = __builtin_bswap32(r[3 - k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (w0 + k < nw) dw[(w0 + k) * LSTRIDE] = code4(q[k], comp, other);
+    }
+#else
+    for (int i = 0; i < n; ++i) d.put(i, v.mode == 2 ? other : code1(v.p[v.off + i * v.step], v.mode == 1, other));
+#endif
+}
+CM_HD inline int ldiff(uint8_t a, uint8_t b) { return a == b ? 0 : 1; }
+CM_HD inline int lscore(uint8_t a, uint8_t b) { return a == b ? SC_MAT : SC_MIS; }
+
+// full Levenshtein for the tiny fallbacks (n <= 2w or m <= w, or n <= w for the one-sided form)
 constexpr int TINY = 4 * MAX_BAND + 4;
-CM_HD inline void tiny_full_dp(const SV &s, int n, const SV &t, int m, bool rev, int *col /* n+1 */) {
-    // column-rolling over j; col[i] = dp[i][j]
+CM_HD inline void tiny_full_dp(const LBuf &s, int n, const LBuf &t, int m, int *col /* n+1 */) {
     for (int i = 0; i <= n; ++i) col[i] = i;
     for (int j = 1; j <= m; ++j) {
         int diag = col[0];
         col[0] = j;
+        const uint8_t tj = t.get(j - 1);
         for (int i = 1; i <= n; ++i) {
-            const int d = rev ? diff_ch(s.at(n - i), t.at(m - j)) : diff_ch(s.at(i - 1), t.at(j - 1));
-            const int v = cmin(cmin(diag + d, col[i - 1] + 1), col[i] + 1);
+            const int v = cmin(cmin(diag + ldiff(s.get(i - 1), tj), col[i - 1] + 1), col[i] + 1);
             diag = col[i];
             col[i] = v;
         }
     }
 }
 
+// WT > 0: band known at compile time (rows live in registers, loops fully unrolled);
+// WT == 0: run-time band up to MAX_BAND.
+template <int WT> struct BandC { static constexpr int WC = WT > 0 ? WT : MAX_BAND; };
+
 // Alignment::global_one_side_banded_alignment, src/align.cpp:219-252 (m == n + w in every call)
-CM_HD inline int one_side_banded(const SV &s, int n, const SV &t, int m, int w) {
+template <int WT>
+CM_HD CM_NOINLINE int one_side_banded_impl(const LBuf &s, int n, const LBuf &t, int m, int w) {
+    constexpr int WC = BandC<WT>::WC;
     if (w < 0 || n <= w) {
-        // full DP; here n <= w <= MAX_BAND, but m can be anything: roll over i instead (rows of s)
-        // dp[i][j], keep row over j? m = n + w <= 2*MAX_BAND in every reachable call.
         int col[TINY];
         if (n >= TINY) n = TINY - 1;
-        tiny_full_dp(s, n, t, m, false, col);
+        tiny_full_dp(s, n, t, m, col);
         return col[n];
     }
-    int prev[MAX_BAND + 3], cur[MAX_BAND + 3];     // index c+1, c = j - i in [0,w]; pads at 0 and w+2
-    for (int c = 0; c <= w; ++c) prev[c + 1] = c;  // dp[0][j] = j
-    prev[0] = DPTINF;
-    prev[w + 2] = DPTINF;
+    int prev[WC + 3], cur[WC + 3];     // index c+1, c = j - i in [0,w]; everything outside is DPTINF
+#pragma unroll
+    for (int x = 0; x < WC + 3; ++x) prev[x] = (x >= 1 && x <= w + 1) ? x - 1 : DPTINF;   // dp[0][j] = j
     for (int i = 1; i <= n; ++i) {
-        cur[0] = DPTINF;                           // dp[i][i-1]
-        const uint8_t si = s.at(i - 1);
-        for (int c = 0; c <= w; ++c) {
-            const int j = i + c;
-            const int v = cmin(cmin(prev[c + 1] + diff_ch(si, t.at(j - 1)), prev[c + 2] + 1), cur[c] + 1);
+        cur[0] = DPTINF;                            // dp[i][i-1]
+        const uint8_t si = s.get(i - 1);
+#pragma unroll
+        for (int c = 0; c <= WC; ++c) {
+            int v = DPTINF;
+            if (c <= w) v = cmin(cmin(prev[c + 1] + ldiff(si, t.get(i + c - 1)), prev[c + 2] + 1), cur[c] + 1);
             cur[c + 1] = v;
         }
-        cur[w + 2] = DPTINF;
-        for (int c = 0; c <= w + 2; ++c) prev[c] = cur[c];
+        cur[WC + 2] = DPTINF;
+#pragma unroll
+        for (int x = 0; x < WC + 3; ++x) prev[x] = cur[x];
     }
-    return prev[(m - n) + 1];
+    int r = DPTINF;
+#pragma unroll
+    for (int x = 1; x <= WC + 1; ++x)
+        if (x == (m - n) + 1) r = prev[x];
+    return r;
 }
 
 // Alignment::global_banded_alignment[_reverse] + local_alignment_right/left, src/align.cpp:395-600.
-// Returns best.ed; indel / align_score as the reference.
-CM_HD inline int local_alignment_side(const Core &c, const SV &s, int n, const SV &t, int m, bool rev, int &indel, int &align_score) {
-    const int w = c.P.band;
+// Forward form only: the reverse variant is the same DP on reversed strings (the caller stages them so).
+template <int WT>
+CM_HD CM_NOINLINE int local_alignment_side_impl(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &indel, int &align_score) {
+    constexpr int WC = BandC<WT>::WC;
+    const int w = WT > 0 ? WT : c.P.band;
     const int max_edit = c.P.max_ed;
     Cand best{max_edit + 1, c.P.max_sc + 1, w + 1, -1 * (c.P.max_sc + 1) - 2 * (max_edit + 1)};
     if (w < 0 || n <= 2 * w || m <= w) {
         int col[TINY];
-        int nn = n < TINY ? n : TINY - 1;
-        tiny_full_dp(s, nn, t, m, rev, col);
+        const int nn = n < TINY ? n : TINY - 1;
+        tiny_full_dp(s, nn, t, m, col);
         for (int i = cmax(0, m - w); i <= cmin(m + w, nn); ++i)
             if (col[i] <= max_edit) {
                 Cand x{col[i], 0, m - i, -2 * col[i]};
@@ -540,27 +704,33 @@ CM_HD inline int local_alignment_side(const Core &c, const SV &s, int n, const S
             }
     } else {
         // column j holds rows i in [j-w, j+w]; slot k = i - j + w + 1 (pads at 0 and 2w+2)
-        int prev[2 * MAX_BAND + 3], cur[2 * MAX_BAND + 3];
-        for (int k = 0; k <= 2 * w + 2; ++k) prev[k] = DPTINF;
-        for (int i = 0; i <= w; ++i) prev[i + w + 1] = i;          // column 0: dp[i][0] = i
+        int prev[2 * WC + 3], cur[2 * WC + 3];
+#pragma unroll
+        for (int k = 0; k < 2 * WC + 3; ++k) prev[k] = (k >= w + 1 && k <= 2 * w + 1) ? k - w - 1 : DPTINF;   // column 0
+        CM_STAT(5, m * (2 * w + 1));
         for (int j = 1; j <= m; ++j) {
-            const uint8_t tj = rev ? t.at(m - j) : t.at(j - 1);
+            const uint8_t tj = t.get(j - 1);
             cur[0] = DPTINF;
-            for (int k = 1; k <= 2 * w + 1; ++k) {
+#pragma unroll
+            for (int k = 1; k <= 2 * WC + 1; ++k) {
                 const int i = j + k - w - 1;
                 int v = DPTINF;
-                if (i == 0) v = (j <= w) ? j : DPTINF;                  // dp[0][j]
-                else if (i > 0 && i <= n) {
-                    const uint8_t si = rev ? s.at(n - i) : s.at(i - 1);
-                    v = cmin(cmin(prev[k] + diff_ch(si, tj), cur[k - 1] + 1), prev[k + 1] + 1);
+                if (k <= 2 * w + 1) {
+                    if (i == 0) v = (j <= w) ? j : DPTINF;                  // dp[0][j]
+                    else if (i > 0 && i <= n) v = cmin(cmin(prev[k] + ldiff(s.get(i - 1), tj), cur[k - 1] + 1), prev[k + 1] + 1);
                 }
                 cur[k] = v;
             }
-            cur[2 * w + 2] = DPTINF;
-            for (int k = 0; k <= 2 * w + 2; ++k) prev[k] = cur[k];
+            cur[2 * WC + 2] = DPTINF;
+#pragma unroll
+            for (int k = 0; k < 2 * WC + 3; ++k) prev[k] = cur[k];
         }
         for (int i = cmax(0, m - w); i <= cmin(m + w, n); ++i) {
-            const int v = prev[i - m + w + 1];
+            const int slot = i - m + w + 1;
+            int v = DPTINF;
+#pragma unroll
+            for (int k = 1; k <= 2 * WC + 1; ++k)
+                if (k == slot) v = prev[k];
             if (v <= max_edit) {
                 Cand x{v, 0, m - i, -2 * v};
                 if (cand_less(x, best)) best = x;
@@ -573,42 +743,48 @@ CM_HD inline int local_alignment_side(const Core &c, const SV &s, int n, const S
 }
 
 // Alignment::global_banded_alignment_drop + DropAlignment::local_alignment_{right,left}_sc,
-// src/align.cpp:254-390, 669-723.  s = reference window (n), t = read residual (m); the caller passes
-// already-reversed views for the left variant.
-CM_HD inline int local_alignment_sc(const Core &c, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
-    const int w = c.P.band;
-    const int W2 = 2 * w + 3;                       // slot = (i - j) + w + 1, pads at 0 and 2w+2
-    int d0[2 * MAX_BAND + 3], d1[2 * MAX_BAND + 3], d2[2 * MAX_BAND + 3];   // anti-diagonals k, k-1, k-2
+// src/align.cpp:254-390, 669-723.  s = reference window (n), t = read residual (m); the left variant
+// is the same DP on reversed strings.  Anti-diagonal k is evaluated slot by slot (slot q <-> i - j =
+// q - w - 1) in ascending i, the reference's order, so the ">=" tie rule picks the same best cell.
+template <int WT>
+CM_HD CM_NOINLINE int local_alignment_sc_impl(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
+    constexpr int WC = BandC<WT>::WC;
+    constexpr int W2 = 2 * WC + 3;                  // slot = (i - j) + w + 1, pads at 0 and 2w+2
+    const int w = WT > 0 ? WT : c.P.band;
+    int d0[W2], d1[W2], d2[W2];                     // anti-diagonals k, k-1, k-2
     int on_s = 0, on_t = 0, best_score = 0;
     if (m > 0 && n > 0) {
-        for (int k = 0; k < W2; ++k) { d1[k] = -DPTINF; d2[k] = -DPTINF; }
-        d2[w + 1] = 0;                              // anti-diagonal 0: (0,0)
-        if (w >= 1) {                               // anti-diagonal 1: (1,0) and (0,1)
-            d1[w + 2] = SC_IND;
-            d1[w] = SC_IND;
+#pragma unroll
+        for (int q = 0; q < W2; ++q) {
+            d2[q] = (q == w + 1) ? 0 : -DPTINF;                                    // anti-diagonal 0: (0,0)
+            d1[q] = (w >= 1 && (q == w + 2 || q == w)) ? SC_IND : -DPTINF;         // anti-diagonal 1: (1,0), (0,1)
         }
         int pre_optimum = 0, cur_optimum = 0;
         int lb = 1, ub = 1, pre_ub = 0;
         for (int k = 2; k <= m + n; ++k) {
-            for (int q = 0; q < W2; ++q) d0[q] = -DPTINF;
-            if (k <= w) {                           // boundary cells (k,0) and (0,k)
-                d0[k + w + 1] = k * SC_IND;
-                d0[w + 1 - k] = k * SC_IND;
-            }
             int new_ub = -1;
-            for (int i = lb; i <= ub; ++i) {
-                const int j = k - i;
-                const int q = i - j + w + 1;
-                int v = cmax(cmax(d2[q] + score_ch(s.at(i - 1), t.at(j - 1)), d1[q - 1] + SC_IND), d1[q + 1] + SC_IND);
-                cur_optimum = cmax(cur_optimum, v);
-                if (v >= cur_optimum) {
-                    cur_optimum = v;
-                    on_s = i;
-                    on_t = j;
-                    best_score = v;
+            CM_STAT(4, ub - lb + 1);
+#pragma unroll
+            for (int q = 0; q < W2; ++q) {
+                int v = -DPTINF;
+                if (k <= w && (q == k + w + 1 || q == w + 1 - k)) v = k * SC_IND;   // boundary cells (k,0), (0,k)
+                const int twice_i = k + q - w - 1;
+                if (q >= 1 && q <= 2 * w + 1 && !(twice_i & 1)) {
+                    const int i = twice_i >> 1;
+                    if (i >= lb && i <= ub) {
+                        const int j = k - i;
+                        v = cmax(cmax(d2[q] + lscore(s.get(i - 1), t.get(j - 1)), d1[q - 1] + SC_IND), d1[q + 1] + SC_IND);
+                        cur_optimum = cmax(cur_optimum, v);
+                        if (v >= cur_optimum) {
+                            cur_optimum = v;
+                            on_s = i;
+                            on_t = j;
+                            best_score = v;
+                        }
+                        if (v + SC_XD < pre_optimum) v = -DPTINF;
+                        if (v > -DPTINF) new_ub = i;
+                    }
                 }
-                if (v + SC_XD < pre_optimum) v = -DPTINF;
-                if (v > -DPTINF) new_ub = i;
                 d0[q] = v;
             }
             const int lb_t = k - lb;
@@ -617,7 +793,11 @@ CM_HD inline int local_alignment_sc(const Core &c, const SV &s, int n, const SV 
             if ((pre_ub == -1 && new_ub == -1) || lb > ub) break;
             pre_ub = new_ub;
             pre_optimum = cmax(pre_optimum, cur_optimum);
-            for (int q = 0; q < W2; ++q) { d2[q] = d1[q]; d1[q] = d0[q]; }
+#pragma unroll
+            for (int q = 0; q < W2; ++q) {
+                d2[q] = d1[q];
+                d1[q] = d0[q];
+            }
         }
     }
     const int score = best_score;                   // dpx[on_s][on_t]; 0 when the best cell is (0,0)
@@ -634,6 +814,36 @@ CM_HD inline int local_alignment_sc(const Core &c, const SV &s, int n, const SV 
     indel = best.indel;
     return best.ed;
 }
+
+// Staging + dispatch on the (wave-uniform) band.  `sm` = the lane's two staging buffers.
+struct DpMem { LBuf a, b; g_err err; };
+CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
+    if (n <= sm.a.cap && m <= sm.b.cap && n >= 0 && m >= 0) return true;
+    flag_err(sm.err, ERR_BAND);
+    return false;
+}
+CM_HD inline int one_side_banded(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int w) {
+    if (!dp_fits(sm, n, m)) return c.P.max_ed + 1;
+    stage(s, n, sm.a, 4);
+    stage(t, m, sm.b, 5);
+    return c.P.band == 3 ? one_side_banded_impl<3>(sm.a, n, sm.b, m, w) : one_side_banded_impl<0>(sm.a, n, sm.b, m, w);
+}
+CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, bool rev, int &indel, int &align_score) {
+    if (!dp_fits(sm, n, m)) { indel = c.P.band + 1; align_score = -(c.P.max_ed + 1); return c.P.max_ed + 1; }
+    stage(rev ? s.rev(n) : s, n, sm.a, 4);
+    stage(rev ? t.rev(m) : t, m, sm.b, 5);
+    return c.P.band == 3 ? local_alignment_side_impl<3>(c, sm.a, n, sm.b, m, indel, align_score)
+                         : local_alignment_side_impl<0>(c, sm.a, n, sm.b, m, indel, align_score);
+}
+// the caller passes already-reversed views for the left variant
+CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
+    if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
+    stage(s, n, sm.a, 4);
+    stage(t, m, sm.b, 5);
+    return c.P.band == 3 ? local_alignment_sc_impl<3>(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
+                         : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+}
+
 
 // GenomeSeeder::pac2char, src/match_read.cpp:288-299
 CM_HD inline bool pac2char(const Core &c, uint32_t start, int len, SV &out) {
@@ -670,7 +880,7 @@ CM_HD inline MM mm_init(const Core &c) {
 CM_HD inline int mm_ed(const MM &m) { return m.left_ed + m.middle_ed + m.right_ed; }
 
 struct CH {            // read-only view of one stored chain
-    const cm_chain *p;
+    g_chain p;
     int kmer;
     CM_HD inline uint32_t len() const { return p->chain_len; }
     CM_HD inline uint32_t rpos(uint32_t i) const { return p->rpos[i]; }
@@ -789,7 +999,7 @@ CM_HD inline void overlap_to_spos(const Core &c, MM &m) {
     m.looked_up_spos = true;
 }
 CM_HD inline int calc_tlen(const Core &c, const MM &sm, const MM &lm, int &intron_num) {
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     int min_tlen = INF_I;
     const uint32_t ns = iv_nseg(A, sm.exons_epos);
     for (uint32_t i = 0; i < ns; ++i) {
@@ -800,7 +1010,7 @@ CM_HD inline int calc_tlen(const Core &c, const MM &sm, const MM &lm, int &intro
             const uint32_t sti = (uint32_t)(sm.exon_ind_epos - start_ind);
             const uint32_t eti = (uint32_t)(lm.exon_ind_spos - start_ind);
             const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-            const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+            const g_u8 t2s = A.t2s + A.t2s_off[tid];
             if (lm.exon_ind_spos < start_ind || eti >= tsz || t2s[eti] == 0) continue;
             int in = 0, tlen;
             if (sti == eti) {
@@ -830,7 +1040,7 @@ CM_HD inline int calc_tlen(const Core &c, const MM &sm, const MM &lm, int &intro
     return (min_tlen == INF_I) ? -1 : (int)(min_tlen + sm.matched_len - 1 + lm.matched_len - 1);
 }
 CM_HD inline bool same_gene_span(const Core &c, int iv, uint32_t s, uint32_t e) {      // utils.cpp:617-639
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     const uint32_t n = iv_nseg(A, iv);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t g = A.seg_gene_id[iv_segid(A, iv, i)];
@@ -839,7 +1049,7 @@ CM_HD inline bool same_gene_span(const Core &c, int iv, uint32_t s, uint32_t e) 
     return false;
 }
 CM_HD inline bool share_gene(const Core &c, int a, int b) {
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     const uint32_t na = iv_nseg(A, a), nb = iv_nseg(A, b);
     for (uint32_t i = 0; i < na; ++i)
         for (uint32_t j = 0; j < nb; ++j)
@@ -847,9 +1057,9 @@ CM_HD inline bool share_gene(const Core &c, int a, int b) {
     return false;
 }
 // same_transcript + intersect_trans, utils.cpp:322-354; returns count (order of the first list)
-CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, int *err) {
+CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, g_err err) {
     if (s < 0 || r < 0) return 0;
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     int n = 0;
     const uint32_t ns = iv_nseg(A, s), nr = iv_nseg(A, r);
     for (uint32_t i = 0; i < ns; ++i) {
@@ -873,7 +1083,7 @@ CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, int *er
 
 CM_HD inline bool concordant_explanation(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm, int pair_type) {
     if (sm.spos > lm.spos) return false;
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     int32_t tlen;
     const bool on_cdna = sm.exons_spos >= 0 && sm.exons_epos >= 0 && lm.exons_spos >= 0 && lm.exons_epos >= 0;
     const int good = (pair_type == 0) ? CM_CONCRD : CM_CONGEN;
@@ -916,7 +1126,7 @@ CM_HD inline void check_chimeric(const Core &c, const MM &sm, const MM &lm, cm_m
         mr_update(c, mr, sm, lm, row, (int32_t)(lm.epos - sm.spos + 1), 0, false, CM_CHIORF, r1_sm);
 }
 CM_HD inline void bsj_tail(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm, int type) {
-    const cm_annot_view &A = c.A;
+    const AnnotV &A = c.A;
     const int32_t tl = (int32_t)(lm.epos - sm.spos + 1);
     if (sm.exons_spos < 0 || lm.exons_spos < 0) {
         if ((sm.exons_spos >= 0 && same_gene_span(c, sm.exons_spos, lm.spos, lm.epos)) ||
@@ -1003,7 +1213,8 @@ CM_HD inline void memo_put(Memo &m, const MemoKey &k, const AlignRes &v) {
 
 struct Ext {
     const Core &c;
-    CM_HD explicit Ext(const Core &cc) : c(cc) {}
+    const DpMem &sm;
+    CM_HD Ext(const Core &cc, const DpMem &mem) : c(cc), sm(mem) {}
 
     CM_HD bool extend_middle(uint32_t pos, uint32_t exon_len, const SV &q, uint32_t qlen, int ed_th, AlignRes &best, AlignRes &curr,
                              AlignRes &exon_res, bool right) const {
@@ -1011,7 +1222,7 @@ struct Ext {
         if (!pac2char(c, right ? pos + 1 : pos - exon_len, (int)exon_len, ref)) return false;
         int indel, sc;
         const uint32_t seq_remain = cmin<uint32_t>(exon_len + (uint32_t)c.P.band, qlen);
-        const int ed = local_alignment_side(c, q, (int)seq_remain, ref, (int)exon_len, !right, indel, sc);
+        const int ed = local_alignment_side(c, sm, q, (int)seq_remain, ref, (int)exon_len, !right, indel, sc);
         const uint32_t np = right ? pos + exon_len : pos - exon_len;
         ar_set(exon_res, np, ed, 0, -indel, (int)exon_len - indel, sc);
         if (curr.ed + ed <= ed_th) {
@@ -1026,8 +1237,8 @@ struct Ext {
         SV ref;
         if (!pac2char(c, right ? pos + 1 : pos - ref_len, (int)ref_len, ref)) return;
         int sclen, indel, sc, ed;
-        if (right) ed = local_alignment_sc(c, ref, (int)ref_len, q, qlen, sclen, indel, sc);
-        else ed = local_alignment_sc(c, ref.rev((int)ref_len), (int)ref_len, q.rev(qlen), qlen, sclen, indel, sc);
+        if (right) ed = local_alignment_sc(c, sm, ref, (int)ref_len, q, qlen, sclen, indel, sc);
+        else ed = local_alignment_sc(c, sm, ref.rev((int)ref_len), (int)ref_len, q.rev(qlen), qlen, sclen, indel, sc);
         const uint32_t np = right ? pos + qlen - indel : pos - qlen + indel;
         ar_set(exon_res, np, ed, sclen, indel, qlen, sc);
         if ((curr.ed + ed <= ed_th) && (sclen <= c.P.max_sc) && (qlen - sclen >= sclen)) {
@@ -1068,8 +1279,9 @@ struct Ext {
 
     CM_HD void right_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t ub, AlignRes &best,
                            bool &consecutive, Memo &memo) const {
-        const cm_annot_view &A = c.A;
+        const AnnotV &A = c.A;
         consecutive = false;
+        CM_STAT(7, 1);
         AlignRes curr = ar_init(ub), exon_res = ar_init(ub);
         int it_ind;
         int it_seg = overlap_ind(c, pos, it_ind);
@@ -1078,7 +1290,7 @@ struct Ext {
         const int it_start = A.trans_start_ind[tid];
         const int rel_ind = it_ind - it_start;
         const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-        const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+        const g_u8 t2s = A.t2s + A.t2s_off[tid];
         uint32_t rspos = pos;
         int exon_len = (int)(A.iv_epos[it_seg] - pos);
         int remain_ref_len = ref_len;
@@ -1119,7 +1331,7 @@ struct Ext {
 
     CM_HD void left_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t lb, AlignRes &best,
                           bool &consecutive, Memo &memo) const {
-        const cm_annot_view &A = c.A;
+        const AnnotV &A = c.A;
         consecutive = false;
         AlignRes curr = ar_init(lb), exon_res = ar_init(lb);
         int it_ind;
@@ -1129,7 +1341,7 @@ struct Ext {
         const int it_start = A.trans_start_ind[tid];
         const int rel_ind = it_ind - it_start;
         const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-        const uint8_t *t2s = A.t2s + A.t2s_off[tid];
+        const g_u8 t2s = A.t2s + A.t2s_off[tid];
         uint32_t lepos = pos;
         int exon_len = 0;
         int remain_ref_len = ref_len;
@@ -1177,6 +1389,7 @@ struct Ext {
     // extend_right / extend_left, src/extend.cpp:285-432; q = the residual (len chars)
     CM_HD bool extend_side(const uint32_t *tids, int n_tid, const SV &q, uint32_t &pos, int len, int ed_th, uint32_t bound, AlignRes &best,
                            bool right) const {
+        CM_STAT(3, 1);
         const int seq_len = len, ref_len = len + c.P.band;
         const uint32_t orig_pos = pos;
         bool consecutive = false;
@@ -1195,8 +1408,8 @@ struct Ext {
         SV ref;
         if (!consecutive && pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) {
             int indel, sc;
-            if (right) min_ed = local_alignment_sc(c, ref, ref_len, q, seq_len, sclen_best, indel, sc);
-            else min_ed = local_alignment_sc(c, ref.rev(ref_len), ref_len, q.rev(seq_len), seq_len, sclen_best, indel, sc);
+            if (right) min_ed = local_alignment_sc(c, sm, ref, ref_len, q, seq_len, sclen_best, indel, sc);
+            else min_ed = local_alignment_sc(c, sm, ref.rev(ref_len), ref_len, q.rev(seq_len), seq_len, sclen_best, indel, sc);
             if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
                 const uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;
                 AlignRes curr = ar_init(bound);
@@ -1265,8 +1478,8 @@ struct Ext {
                 if (diff >= -c.P.band && diff <= c.P.band) {
                     SV ref;
                     if (!pac2char(c, rspos, rlen, ref)) ref = SV{c.X.genome, 0, 1, 2};    // defined as an all-NUL window
-                    if (diff >= 0) mid += one_side_banded(q.sub(qspos), qlen, ref, rlen, diff);
-                    else mid += one_side_banded(ref, rlen, q.sub(qspos), qlen, -diff);
+                    if (diff >= 0) mid += one_side_banded(c, sm, q.sub(qspos), qlen, ref, rlen, diff);
+                    else mid += one_side_banded(c, sm, ref, rlen, q.sub(qspos), qlen, -diff);
                 }
                 if (mid > edth) return edth + 1;
             }
@@ -1300,6 +1513,7 @@ struct Ext {
         return true;
     }
     CM_HD int chain_both_sides(const CH &ch, const Read &rd, MM &mr, int dir) const {
+        CM_STAT(2, 1);
         const int maxEd = c.P.max_ed;
         const SV seq = rd.view();
         const int seq_len = rd.len;
@@ -1346,16 +1560,16 @@ struct Ext {
 // K3 body: pair chains, extend, classify (A8-A10, A20)
 // ------------------------------------------------------------------------------------------
 struct ChainSet {          // chains of one (mate, orientation)
-    const cm_chain *ch;
+    g_chain ch;
     int n;
 };
 
 // FilterRead::process_mates (filter.cpp:244-395) with pair_chains (filter.cpp:484-551) fused in:
 // pass 1 evaluates the pairing predicate for every (i, j) (needed up-front for the *_paired
 // flags), pass 2 walks the accepted pairs in i-major order.
-CM_HD inline int process_mates(const Core &c, const ChainSet &fwd, const Read &frd, const ChainSet &bwd, const Read &brd, cm_mapped_read &mr,
-                               bool r1_forward, int *err) {
-    const Ext ext(c);
+CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &fwd, const Read &frd, const ChainSet &bwd, const Read &brd,
+                               cm_mapped_read &mr, bool r1_forward, g_err err) {
+    const Ext ext(c, sm);
     const int kmer = c.P.kmer;
     const int saved_type = mr.type;
     int fe[CM_BESTCHAINLIM], re[CM_BESTCHAINLIM];
@@ -1394,6 +1608,7 @@ CM_HD inline int process_mates(const Core &c, const ChainSet &fwd, const Read &f
             const int pair_type = (int)code - 1;
             const int n_tid = (code == 1) ? common_tids(c, fe[i], re[j], tids, err) : 0;
             // (when same_tr is false the reference's common_tid is empty: same_transcript clears it)
+            CM_STAT(0, 1);
             MM r1 = mm_init(c), r2 = mm_init(c);
             r1.dir = 1;
             r2.dir = -1;
@@ -1463,8 +1678,8 @@ CM_HD inline int process_mates(const Core &c, const ChainSet &fwd, const Read &f
 
 // FilterRead::process_read (PE), filter.cpp:124-241, after seeding + chaining.
 // sets[0..3] = chains of (R1 fwd, R1 rc, R2 fwd, R2 rc); high[] = high_hits of each.
-CM_HD inline int process_read(const Core &c, const uint8_t *s1, int len1, const uint8_t *s2, int len2, const ChainSet *sets, const int *high,
-                              cm_mapped_read &mr, int *err) {
+CM_HD inline int process_read(const Core &c, const DpMem &sm, g_u8 s1, int len1, g_u8 s2, int len2, const ChainSet *sets,
+                              const int *high, cm_mapped_read &mr, g_err err) {
     const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
     if (n1 + n2 <= 0) {
         if ((high[0] + high[1] > 0) && (high[2] + high[3] > 0)) {
@@ -1485,8 +1700,8 @@ CM_HD inline int process_read(const Core &c, const uint8_t *s1, int len1, const 
     const bool first = lhs >= rhs;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int a;
-        if ((attempt == 0) == first) a = process_mates(c, sets[0], r1f, sets[3], r2b, mr, true, err);    // forward R1 / backward R2
-        else a = process_mates(c, sets[2], r2f, sets[1], r1b, mr, false, err);                            // forward R2 / backward R1
+        if ((attempt == 0) == first) a = process_mates(c, sm, sets[0], r1f, sets[3], r2b, mr, true, err);    // forward R1 / backward R2
+        else a = process_mates(c, sm, sets[2], r2f, sets[1], r1b, mr, false, err);                            // forward R2 / backward R1
         if (c.P.scan_level == 0 && a == CM_CONCRD) return CM_CONCRD;
     }
     return mr.type;

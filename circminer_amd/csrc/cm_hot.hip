@@ -10,8 +10,10 @@
 // There is no CPU path in this file: without a HIP device cm_create fails with CM_ENODEV.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,11 +22,12 @@
 #include "cm_core.h"
 
 using cmc::Core;
+using cmc::KCore;
 
 namespace {
 
 constexpr int MAX_SLOTS = 16;
-constexpr uint32_t TILE_PAIRS = 131072;            // pairs per launch group (workspace sizing)
+constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (workspace sizing: ~30 KB of HBM per pair)
 constexpr int BLK = 256;
 constexpr int BLK_CHAIN = 64;
 constexpr int BLK_PAIR = 64;
@@ -35,8 +38,9 @@ struct ReadsDev {
 };
 
 // ------------------------------------------------------------------ kernels
-__global__ void __launch_bounds__(BLK) k_seed(Core c, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t n_tile, int S,
+__global__ void __launch_bounds__(BLK) k_seed(KCore kc, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t n_tile, int S,
                                               uint32_t *sstart, uint32_t *scnt, uint32_t *sraw, unsigned long long *counters) {
+    const Core c = cmc::to_core(kc);
     __shared__ unsigned int sh[3];
     if (threadIdx.x < 3) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(BLK) k_seed(Core c, ReadsDev rd, const uint8_t
             const int len = (int)(o1 - o0);
             const int k = c.P.kmer;
             if ((int)(s + 1) * k <= len) {
-                const cmc::Read R{(mate ? rd.seq2 : rd.seq1) + o0, len, orient};
+                const cmc::Read R{(cmc::g_u8)((mate ? rd.seq2 : rd.seq1) + o0), len, orient};
                 const cmc::Probe pr = cmc::seed_probe(c, R.view(), (int)s * k);
                 st = pr.start;
                 rw = pr.raw;
@@ -103,13 +107,14 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t *in, uint32_t n, u
     if (t == 1023) out[n] = part[1023];
 }
 
-__global__ void __launch_bounds__(BLK_CHAIN) k_chain(Core c, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
+__global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
                                                      const uint32_t *sstart, const uint32_t *scnt, const uint32_t *sraw,
                                                      const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
                                                      int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
                                                      unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err) {
     const uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
     if (r >= r1) return;
+    const Core c = cmc::to_core(kc);
     const uint64_t p = pair0 + (r >> 2);
     int n = 0, hh = 0;
     if (active[p]) {
@@ -123,23 +128,56 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(Core c, ReadsDev rd, const 
             if (sraw[(uint64_t)r * S + s] > 0 && cn[s] == 0) ++hh;       // get_best_chains high_hits
         }
         cmc::ChainWork w;
-        w.dp_score = dp_score + (celloff[r] - cellbase);
-        w.dp_prev = dp_prev + (celloff[r] - cellbase);
-        w.pool = pool;
+        w.dp_score = (CM_G double *)(dp_score + (celloff[r] - cellbase));
+        w.dp_prev = (CM_G int32_t *)(dp_prev + (celloff[r] - cellbase));
+        w.pool = (CM_G uint8_t *)pool;
         w.pool_bytes = pool_bytes;
-        w.pool_cursor = pool_cursor;
-        w.err = err;
-        n = cmc::chain_kbest(c, len, S, st, cn, w, chains + (uint64_t)r * CM_BESTCHAINLIM);
+        w.pool_cursor = (CM_G unsigned long long *)pool_cursor;
+        w.err = (cmc::g_err)err;
+        n = cmc::chain_kbest(c, len, S, st, cn, w, (CM_G cm_chain *)(chains + (uint64_t)r * CM_BESTCHAINLIM));
     }
     nchain[r] = n;
     high[r] = hh;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR) k_pair(Core c, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
-                                                   const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
-                                                   int *err, unsigned long long *counters) {
-    const uint32_t t = blockIdx.x * BLK_PAIR + threadIdx.x;
+// Heavy-first launch order for k_pair (longest-processing-time-first): a pair's work grows with
+// the number of chain pairs it has to extend, so pairs are binned by that estimate and the heavy
+// bins get the lowest block indices; their long lanes then overlap with the bulk instead of
+// forming the tail of the launch.  Results do not depend on the order.
+__device__ inline int pair_cost_class(const int32_t *nchain, const uint8_t *active, uint64_t p, uint32_t t) {
+    if (!active[p]) return 2;
+    const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
+    const int cost = a * d + c * b + a + b + c + d;
+    return cost > 64 ? 0 : (cost > 8 ? 1 : 2);
+}
+__global__ void __launch_bounds__(BLK) k_order_count(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, unsigned int *ctr) {
+    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
+    atomicAdd(&ctr[pair_cost_class(nchain, active, pair0 + t, t)], 1u);
+}
+__global__ void __launch_bounds__(BLK) k_order_place(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, unsigned int *ctr,
+                                                     uint32_t *perm, int identity) {
+    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= n_tile) return;
+    const int k = pair_cost_class(nchain, active, pair0 + t, t);
+    const unsigned int base = (k == 0) ? 0u : (k == 1 ? ctr[0] : ctr[0] + ctr[1]);
+    if (identity) perm[t] = t;      // tuning knob CM_NO_ORDER=1
+    else perm[base + atomicAdd(&ctr[3 + k], 1u)] = t;
+}
+
+__global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+                                                   const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
+                                                   int *err, unsigned long long *counters, int str_cap, const uint32_t *perm,
+                                                   unsigned long long *lane_clk) {
+    const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
+    // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
+    extern __shared__ uint32_t lds_words[];
+    CM_L uint8_t *lane_base = (CM_L uint8_t *)lds_words + 4 * threadIdx.x;
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
+    const Core c = cmc::to_core(kc);
+    const uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x;
+    if (slot >= n_tile) return;
+    const uint32_t t = perm[slot];
     const uint64_t p = pair0 + t;
     if (!active[p]) {
         cat[p] = -1;
@@ -150,23 +188,37 @@ __global__ void __launch_bounds__(BLK_PAIR) k_pair(Core c, ReadsDev rd, uint64_t
     int hh[4];
     for (int x = 0; x < 4; ++x) {
         const uint64_t r = (uint64_t)t * 4 + x;
-        sets[x].ch = chains + r * CM_BESTCHAINLIM;
+        sets[x].ch = (cmc::g_chain)(chains + r * CM_BESTCHAINLIM);
         sets[x].n = nchain[r];
         hh[x] = high[r];
     }
     cm_mapped_read mr = state[p];
-    const int st = cmc::process_read(c, rd.seq1 + a0, (int)(a1 - a0), rd.seq2 + b0, (int)(b1 - b0), sets, hh, mr, err);
+    const int st = cmc::process_read(c, sm, (cmc::g_u8)(rd.seq1 + a0), (int)(a1 - a0), (cmc::g_u8)(rd.seq2 + b0), (int)(b1 - b0), sets, hh, mr, (cmc::g_err)err);
     uint8_t act = 1;
     cmc::finish_round(c, st, is_last, (int)(a1 - a0), (int)(b1 - b0), mr, act);
     state[p] = mr;
     active[p] = act;
     cat[p] = st;
     atomicAdd(&counters[3], 1ull);
+    if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
 }
 
-__global__ void k_init_state(Core c, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
+__global__ void __launch_bounds__(BLK) k_collect(const uint8_t *active, const cm_mapped_read *state, uint64_t n, unsigned long long cap,
+                                                 unsigned long long *count, unsigned long long *out_idx, cm_mapped_read *out_state) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n || !active[i]) return;
+    const unsigned long long w = atomicAdd(count, 1ull);
+    if (w < cap) {
+        out_idx[w] = i;
+        out_state[w] = state[i];
+    }
+}
+
+__global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
+    Core c;
+    c.P = kc.P;
     cmc::default_mr(c, state[i]);
     active[i] = 1;
     cat[i] = -1;
@@ -191,12 +243,12 @@ struct cm_ctx {
     Slot slots[MAX_SLOTS];
     // reads
     uint64_t n_pairs = 0;
-    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
+    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr, *d_seq1_base = nullptr, *d_seq2_base = nullptr;
     uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
     cm_mapped_read *d_state = nullptr;
     uint8_t *d_active = nullptr;
     int32_t *d_cat = nullptr;
-    int n_seeds = 0;
+    int n_seeds = 0, max_len = 0;
     // workspace
     uint32_t tile = 0;
     uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
@@ -206,6 +258,9 @@ struct cm_ctx {
     unsigned long long cells_cap = 0;
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
+    uint32_t *d_perm = nullptr;
+    unsigned int *d_order_ctr = nullptr;
+    unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -257,11 +312,11 @@ void dfree(T *&p) {
 }
 
 void free_reads(cm_ctx *c) {
-    dfree(c->d_seq1); dfree(c->d_seq2); dfree(c->d_off1); dfree(c->d_off2);
+    dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool);
+    dfree(c->d_pool); dfree(c->d_perm); dfree(c->d_order_ctr); dfree(c->d_lane_clk);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -287,8 +342,8 @@ struct Timer {
     }
 };
 
-Core make_core(const cm_ctx *c, const Slot &s) {
-    Core k;
+KCore make_core(const cm_ctx *c, const Slot &s) {
+    KCore k;
     k.P = c->P;
     k.X = s.X;
     k.A = s.A;
@@ -303,7 +358,7 @@ int check_slot(cm_ctx *ctx, int slot, bool need_annot) {
 }
 
 // seeds (+ optionally chains) of one tile; leaves results in the workspace
-int run_seed_tile(cm_ctx *ctx, const Core &core, uint64_t pair0, uint32_t n_tile) {
+int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     const int S = ctx->n_seeds;
     const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
@@ -316,7 +371,7 @@ int run_seed_tile(cm_ctx *ctx, const Core &core, uint64_t pair0, uint32_t n_tile
     return CM_OK;
 }
 
-int run_chain_tile(cm_ctx *ctx, const Core &core, uint64_t pair0, uint32_t n_tile) {
+int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
@@ -370,7 +425,7 @@ int check_dev_err(cm_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (e) {
         return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
-                    (e & cmc::ERR_TID) ? " more than 64 common transcripts for one mate pair;" : "", (e & ~3) ? " other" : "");
+                    (e & cmc::ERR_TID) ? " more than 64 common transcripts for one mate pair;" : "", (e & ~3) ? " DP string longer than the staging buffer" : "");
     }
     return CM_OK;
 }
@@ -444,7 +499,15 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     const size_t nb = ((size_t)1 << (2 * CM_WINDOW_SIZE)) + 1;
     s.X = *iv;
     int rc;
-    if ((rc = up(ctx, s.idx_allocs, iv->genome, (size_t)iv->ref_len, &s.X.genome))) return rc;
+    {   // genome with CM_STAGE_PAD readable bytes on both sides (vector loads of the DP staging over-read)
+        uint8_t *g = nullptr;
+        const size_t pad = cmc::CM_STAGE_PAD;
+        HIPCHK(ctx, hipMalloc((void **)&g, (size_t)iv->ref_len + 2 * pad));
+        s.idx_allocs.push_back(g);
+        HIPCHK(ctx, hipMemsetAsync(g, 0, (size_t)iv->ref_len + 2 * pad, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(g + pad, iv->genome, (size_t)iv->ref_len, hipMemcpyHostToDevice, ctx->stream));
+        s.X.genome = g + pad;
+    }
     if ((rc = up(ctx, s.idx_allocs, iv->bucket_off, nb, &s.X.bucket_off))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->checksum, (size_t)iv->n_entries, &s.X.checksum))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->pos, (size_t)iv->n_entries, &s.X.pos))) return rc;
@@ -522,10 +585,16 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
         if ((int)l2 > max_len) max_len = (int)l2;
     }
     ctx->n_seeds = max_len / ctx->P.kmer;
+    ctx->max_len = max_len;
     if (ctx->n_seeds > cmc::MAX_SEEDS) return fail(ctx, CM_ELIMIT, "%d seeds per read > %d supported", ctx->n_seeds, cmc::MAX_SEEDS);
     const size_t b1 = (size_t)rd->off1[n], b2 = (size_t)rd->off2[n];
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq1, b1 ? b1 : 1));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq2, b2 ? b2 : 1));
+    const size_t pad = cmc::CM_STAGE_PAD;                  // readable slack around the reads (see cmc::stage)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq1_base, b1 + 2 * pad));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq2_base, b2 + 2 * pad));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_seq1_base, 0, b1 + 2 * pad, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_seq2_base, 0, b2 + 2 * pad, ctx->stream));
+    ctx->d_seq1 = ctx->d_seq1_base + pad;
+    ctx->d_seq2 = ctx->d_seq2_base + pad;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_off1, (n + 1) * sizeof(uint64_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_off2, (n + 1) * sizeof(uint64_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_state, n * sizeof(cm_mapped_read)));
@@ -536,7 +605,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_off1, rd->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_off2, rd->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->n_pairs = n;
-    Core k{};
+    KCore k{};
     k.P = ctx->P;
     hipLaunchKernelGGL(k_init_state, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active, ctx->d_cat, n);
     if (prior) {
@@ -545,7 +614,12 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, prior, n * sizeof(cm_mapped_read), hipMemcpyHostToDevice, ctx->stream));
     }
     // workspace for one tile
-    const uint32_t tile = (uint32_t)(n < TILE_PAIRS ? n : TILE_PAIRS);
+    uint32_t tile_cap = TILE_PAIRS;
+    if (const char *e = getenv("CM_TILE_PAIRS")) {       // tuning knob: pairs per launch group
+        const long v = atol(e);
+        if (v >= 64 && v <= (1l << 24)) tile_cap = (uint32_t)v;
+    }
+    const uint32_t tile = (uint32_t)(n < tile_cap ? n : tile_cap);
     ctx->tile = tile;
     const size_t nprob = (size_t)tile * 4, nprobe = nprob * (size_t)(ctx->n_seeds ? ctx->n_seeds : 1);
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_sstart, nprobe * 4));
@@ -565,6 +639,12 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_order_ctr, 6 * sizeof(unsigned int)));
+    if (getenv("CM_LANE_CLK")) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_lane_clk, n * 8));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_lane_clk, 0, n * 8, ctx->stream));
+    }
     unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
     if (pool < (256ull << 20)) pool = 256ull << 20;
     if (pool > (8ull << 30)) pool = 8ull << 30;
@@ -580,7 +660,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     if (ctx->n_pairs == 0) return CM_OK;
-    const Core core = make_core(ctx, ctx->slots[slot]);
+    const KCore core = make_core(ctx, ctx->slots[slot]);
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
@@ -588,8 +668,16 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
         if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
         {
             Timer t(ctx, 2);
-            hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), 0, ctx->stream, core, rd, p0, nt, ctx->d_chains,
-                               ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters);
+            // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
+            const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
+            const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_order_ctr, 0, 6 * sizeof(unsigned int), ctx->stream));
+            hipLaunchKernelGGL(k_order_count, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_order_ctr);
+            hipLaunchKernelGGL(k_order_place, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_order_ctr,
+                               ctx->d_perm, getenv("CM_NO_ORDER") ? 1 : 0);
+            hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
+                               ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
+                               str_cap, ctx->d_perm, ctx->d_lane_clk);
             ++ctx->launches[2];
             HIPCHK(ctx, hipGetLastError());
         }
@@ -602,6 +690,60 @@ int cm_sync(cm_ctx *ctx) {
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_dev_err(ctx);
+}
+
+int cm_reads_reset(cm_ctx *ctx) {
+    if (!ctx) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (ctx->n_pairs == 0) return CM_OK;
+    KCore k{};
+    k.P = ctx->P;
+    hipLaunchKernelGGL(k_init_state, dim3((unsigned)((ctx->n_pairs + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active,
+                       ctx->d_cat, ctx->n_pairs);
+    HIPCHK(ctx, hipGetLastError());
+    return CM_OK;
+}
+
+int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n) {
+    if (!ctx || !out_n || (cap && (!out_idx || !out_state))) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    *out_n = 0;
+    if (ctx->n_pairs == 0) return CM_OK;
+    unsigned long long *d_idx = nullptr;
+    cm_mapped_read *d_st = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_idx, (cap ? cap : 1) * sizeof(unsigned long long)));
+    if (hipMalloc((void **)&d_st, (cap ? cap : 1) * sizeof(cm_mapped_read)) != hipSuccess) {
+        (void)hipFree(d_idx);
+        return fail(ctx, CM_ENOMEM, "cm_collect_active: out of device memory");
+    }
+    // d_pool_cursor doubles as the append counter (no chain kernel is in flight at this point on the stream)
+    (void)hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream);
+    hipLaunchKernelGGL(k_collect, dim3((unsigned)((ctx->n_pairs + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, ctx->d_state, ctx->n_pairs,
+                       (unsigned long long)cap, ctx->d_pool_cursor, d_idx, d_st);
+    unsigned long long cnt = 0;
+    (void)hipMemcpyAsync(&cnt, ctx->d_pool_cursor, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    int rc = CM_OK;
+    if (e != hipSuccess) rc = fail(ctx, CM_EHIP, "cm_collect_active: %s", hipGetErrorString(e));
+    *out_n = cnt;
+    if (rc == CM_OK && cnt > cap) rc = fail(ctx, CM_ELIMIT, "cm_collect_active: %llu active pairs > cap %llu", cnt, (unsigned long long)cap);
+    if (rc == CM_OK && cnt) {
+        std::vector<unsigned long long> hi(cnt);
+        std::vector<cm_mapped_read> hs(cnt);
+        (void)hipMemcpy(hi.data(), d_idx, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs.data(), d_st, cnt * sizeof(cm_mapped_read), hipMemcpyDeviceToHost);
+        // the append order of the atomic is arbitrary: return ascending pair index
+        std::vector<uint32_t> ord(cnt);
+        for (uint32_t i = 0; i < cnt; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return hi[a] < hi[b]; });
+        for (uint32_t i = 0; i < cnt; ++i) {
+            out_idx[i] = hi[ord[i]];
+            out_state[i] = hs[ord[i]];
+        }
+    }
+    (void)hipFree(d_idx);
+    (void)hipFree(d_st);
+    return rc;
 }
 
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active) {
@@ -633,7 +775,7 @@ int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt,
     *out_n_slots = (uint32_t)ctx->n_seeds;
     const uint64_t need = ctx->n_pairs * 4ull * (uint64_t)ctx->n_seeds;
     if (need > cap_probes) return fail(ctx, CM_EINVAL, "cm_seed_batch: need room for %llu probes", (unsigned long long)need);
-    const Core core = make_core(ctx, ctx->slots[slot]);
+    const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
@@ -651,7 +793,7 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
     int rc = check_slot(ctx, slot, true);
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    const Core core = make_core(ctx, ctx->slots[slot]);
+    const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
@@ -665,6 +807,13 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return check_dev_err(ctx);
+}
+
+/* diagnostic: per-pair k_pair lane time in 100 MHz ticks (only when CM_LANE_CLK was set at upload) */
+int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) {
+    if (!ctx || !out || !ctx->d_lane_clk) return CM_EINVAL;
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8, hipMemcpyDeviceToHost));
+    return CM_OK;
 }
 
 int cm_prof_enable(cm_ctx *ctx, int on) {

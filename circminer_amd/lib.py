@@ -141,6 +141,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_reads_download": (C.c_int, [vp, vp, vp, vp]),
         "cm_map_batch": (C.c_int, [vp, C.c_int, C.c_int, pp(Reads), vp, vp, vp]),
         "cm_sync": (C.c_int, [vp]),
+        "cm_reads_reset": (C.c_int, [vp]),
+        "cm_collect_active": (C.c_int, [vp, C.c_uint64, vp, vp, pp(C.c_uint64)]),
         "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
         "cm_chain_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "cm_prof_enable": (C.c_int, [vp, C.c_int]),
@@ -163,7 +165,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation"]
 
@@ -239,6 +241,17 @@ class HotPath:
 
     def sync(self):
         self._chk(self.L.cm_sync(self.h), "cm_sync")
+
+    def reset(self):
+        self._chk(self.L.cm_reads_reset(self.h), "cm_reads_reset")
+
+    def collect_active(self, cap=None):
+        cap = int(cap if cap is not None else max(self.n, 1))
+        idx = np.zeros(cap, np.uint64)
+        st = np.zeros(cap, dtype=MAPPED_DTYPE)
+        n = C.c_uint64(0)
+        self._chk(self.L.cm_collect_active(self.h, cap, idx.ctypes.data, st.ctypes.data, C.byref(n)), "cm_collect_active")
+        return idx[:n.value], st[:n.value]
 
     def download(self):
         st = np.zeros(self.n, dtype=MAPPED_DTYPE)

@@ -291,18 +291,19 @@ def make_reads(rng, chr_seqs, genes, n_pairs, read_len=150, frag_lo=260, frag_hi
 
 
 PRESETS = {
-    # name: (chromosome lengths, genes/Mbp, contig size cap)
-    "tiny": ([120_000, 90_000], 60.0, 1_100_000_000),
-    "tiny2r": ([120_000, 90_000], 60.0, 150_000),        # two packed contigs -> two rounds
-    "small": ([2_000_000, 1_500_000, 1_000_000], 25.0, 1_100_000_000),
-    "chr21": ([46_700_000], 5.5, 1_100_000_000),         # BASELINE.json configs[1]
+    # name: (chromosome lengths, genes/Mbp, contig size cap, copies per repeat family)
+    "tiny": ([120_000, 90_000], 60.0, 1_100_000_000, 6),
+    "tiny2r": ([120_000, 90_000], 60.0, 150_000, 6),           # two packed contigs -> two rounds
+    "small": ([2_000_000, 1_500_000, 1_000_000], 25.0, 1_100_000_000, 120),
+    "chr21": ([46_700_000], 5.5, 1_100_000_000, 2000),         # BASELINE.json configs[1]
 }
 
 
 def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25, 0.05),
-             chr_lens=None, genes_per_mbp=None, contig_size=None, fam_copies=40) -> SynthData:
+             chr_lens=None, genes_per_mbp=None, contig_size=None, fam_copies=None, read_seed=None) -> SynthData:
     rng = np.random.default_rng(seed)
-    p_lens, p_gpm, p_cs = PRESETS[preset]
+    p_lens, p_gpm, p_cs, p_fc = PRESETS[preset]
+    fam_copies = fam_copies or p_fc
     chr_lens = list(chr_lens or p_lens)
     gpm = genes_per_mbp or p_gpm
     cs = contig_size or p_cs
@@ -311,5 +312,7 @@ def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25
     contigs, table = pack_genome(names, seqs, cs)
     genes = make_genes(rng, chr_lens, genes_per_mbp=gpm)
     gtf = gtf_text(genes, names)
+    if read_seed is not None:          # same genome / annotation, an independent shard of reads
+        rng = np.random.default_rng([seed, int(read_seed)])
     s1, s2, src, tc, lo, hi = make_reads(rng, seqs, genes, n_pairs, read_len=read_len, mix=mix)
     return SynthData(names, seqs, contigs, table, genes, gtf, s1, s2, src, tc, lo, hi)

@@ -186,6 +186,17 @@ int cm_map_batch(cm_ctx *ctx, int slot, int is_last_round, const cm_reads *reads
 
 int cm_sync(cm_ctx *ctx);
 
+/* Put the resident batch back into its first-round state (fill_map_info's "cnt != 23" state,
+ * every pair active) without touching the read bytes: lets a caller re-run all rounds on reads
+ * that are already in HBM. */
+int cm_reads_reset(cm_ctx *ctx);
+
+/* Compact the pairs that are still active into host buffers: after the last round these are the
+ * CHIBSJ / CHI2BSJ pairs that write_read_category hands to stage 2 (src/circminer.cpp:395-397);
+ * after an earlier round, the pairs re-queued for the next contig.  Ascending pair index.
+ * Returns CM_ELIMIT (and the needed count in *out_n) if cap is too small. */
+int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n);
+
 /* ---------------- finer-grained entry points used by the parity tests ---------------- */
 /* Seeds (GenomeSeeder::split_match_hash, src/match_read.cpp:270-286) of the resident batch:
  * for probe q = ((pair*2 + mate)*2 + orient)*n_slots + s (orient 0 = forward, 1 = reverse

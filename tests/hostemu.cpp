@@ -9,7 +9,9 @@
 #include <vector>
 
 #include "circminer_hot.h"
+#define CM_STATS 1
 #include "cm_core.h"
+extern "C" { unsigned long long cm_stats[16]; }
 
 using cmc::Core;
 
@@ -97,7 +99,7 @@ int emu_seed_batch(const cm_params *P, const cm_index_view *X, const cm_reads *R
                    uint32_t *out_raw) {
     Emu e;
     e.core.P = *P;
-    e.core.X = *X;
+    e.core.X = cmc::to_dev(*X);
     memset(&e.core.A, 0, sizeof e.core.A);
     e.R = R;
     e.S = n_seeds_of(P, R);
@@ -114,8 +116,8 @@ int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_v
                     int32_t *out_nchain, int32_t *out_high) {
     Emu e;
     e.core.P = *P;
-    e.core.X = *X;
-    e.core.A = *A;
+    e.core.X = cmc::to_dev(*X);
+    e.core.A = cmc::to_dev(*A);
     e.R = R;
     e.S = n_seeds_of(P, R);
     seed_all(e, nullptr);
@@ -131,8 +133,8 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
                   uint8_t *active, int32_t *category) {
     Emu e;
     e.core.P = *P;
-    e.core.X = *X;
-    e.core.A = *A;
+    e.core.X = cmc::to_dev(*X);
+    e.core.A = cmc::to_dev(*A);
     e.R = R;
     e.S = n_seeds_of(P, R);
     seed_all(e, active);
@@ -150,7 +152,9 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
             hh[x] = e.high[p * 4 + x];
         }
         const int l1 = (int)(R->off1[p + 1] - R->off1[p]), l2 = (int)(R->off2[p + 1] - R->off2[p]);
-        const int st = cmc::process_read(e.core, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);
+        uint8_t bufa[1024], bufb[1024];
+        const cmc::DpMem sm{cmc::LBuf{bufa, 1024}, cmc::LBuf{bufb, 1024}, &e.err};
+        const int st = cmc::process_read(e.core, sm, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);
         cmc::finish_round(e.core, st, is_last, l1, l2, state[p], active[p]);
         category[p] = st;
     }
@@ -161,16 +165,27 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
 int emu_edit_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *indel, int *score) {
     Core c{};
     c.P = *P;
-    return cmc::local_alignment_side(c, cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, left != 0, *indel, *score);
+    uint8_t bufa[2048], bufb[2048];
+    int err = 0;
+    const cmc::DpMem sm{cmc::LBuf{bufa, 2048}, cmc::LBuf{bufb, 2048}, &err};
+    return cmc::local_alignment_side(c, sm, cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, left != 0, *indel, *score);
 }
 int emu_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int left, int *sclen, int *indel, int *score) {
     Core c{};
     c.P = *P;
     cmc::SV a{s, 0, 1, 0}, b{t, 0, 1, 0};
-    if (left) return cmc::local_alignment_sc(c, a.rev(n), n, b.rev(m), m, *sclen, *indel, *score);
-    return cmc::local_alignment_sc(c, a, n, b, m, *sclen, *indel, *score);
+    uint8_t bufa[2048], bufb[2048];
+    int err = 0;
+    const cmc::DpMem sm{cmc::LBuf{bufa, 2048}, cmc::LBuf{bufb, 2048}, &err};
+    if (left) return cmc::local_alignment_sc(c, sm, a.rev(n), n, b.rev(m), m, *sclen, *indel, *score);
+    return cmc::local_alignment_sc(c, sm, a, n, b, m, *sclen, *indel, *score);
 }
-int emu_one_side(const uint8_t *s, int n, const uint8_t *t, int m, int w) {
-    return cmc::one_side_banded(cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, w);
+int emu_one_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int w) {
+    Core c{};
+    c.P = *P;
+    uint8_t bufa[2048], bufb[2048];
+    int err = 0;
+    const cmc::DpMem sm{cmc::LBuf{bufa, 2048}, cmc::LBuf{bufb, 2048}, &err};
+    return cmc::one_side_banded(c, sm, cmc::SV{s, 0, 1, 0}, n, cmc::SV{t, 0, 1, 0}, m, w);
 }
 }

@@ -34,6 +34,12 @@ extern "C" unsigned long long cm_stats[16];
 #else
 #define CM_STAT(i, n) ((void)0)
 #endif
+// diagnostic builds only (-DCM_DIAG): cut the pair routine short at phase n (cm_params.reserved)
+#if defined(CM_DIAG)
+#define CM_DBG_STOP(n, ret) do { if (c.P.reserved == (n)) return ret; } while (0)
+#else
+#define CM_DBG_STOP(n, ret) ((void)0)
+#endif
 
 // Explicit address spaces for the device build.  Pointers travel through structs and private
 // arrays here; without the qualifiers the compiler loses their provenance and emits flat_load /
@@ -581,6 +587,21 @@ struct LBuf {
     CM_L uint8_t *b;
     int cap;
     CM_HD inline uint8_t get(int i) const { return b[(i >> 2) * (4 * LSTRIDE) + (i & 3)]; }
+    CM_HD inline uint32_t word(int w) const {                 // staged bytes 4w .. 4w+3, little-endian
+#if defined(__HIP_DEVICE_COMPILE__)
+        return ((CM_L const uint32_t *)b)[w * LSTRIDE];
+#else
+        uint32_t x;
+        __builtin_memcpy(&x, b + 4 * w, 4);
+        return x;
+#endif
+    }
+    // 5 consecutive staged bytes starting at index `at` (0 <= at, at + 7 < capacity): byte r in bits 8r..8r+7
+    CM_HD inline uint64_t window(int at) const {
+        const int w = at >> 2;
+        const uint64_t lo = word(w), hi = word(w + 1);
+        return ((hi << 32) | lo) >> (8 * (at & 3));
+    }
     CM_HD inline void put(int i, uint8_t v) const { b[(i >> 2) * (4 * LSTRIDE) + (i & 3)] = v; }
 };
 // 4 ASCII bases -> 4 one-byte codes (SWAR).  A/a 0, C/c 1, T/t 2, G/g 3 (= (ch >> 1) & 3 of the
@@ -815,6 +836,79 @@ CM_HD CM_NOINLINE int local_alignment_sc_impl(const Core &c, const LBuf &s, int 
     return best.ed;
 }
 
+// Band-3 specialisation of the X-drop DP (the default bandWidth, >85 % of all DP cells).
+// Same recurrence, evaluation order and pruning as local_alignment_sc_impl, restructured for a GPU lane:
+//  * one register per slot, updated in place: anti-diagonal k only owns the slots q == k (mod 2), so
+//    d[q] still holds (k-2, q) when (k, q) is computed and d[q +- 1] hold anti-diagonal k-1;
+//  * branch-free cells (selects), at most 4 per anti-diagonal instead of a 9-slot loop;
+//  * the 4 reference and 4 read bases an anti-diagonal needs come from one 5-byte LDS window each.
+CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
+    constexpr int W = 3;
+    int d[2 * W + 3];
+    int on_s = 0, on_t = 0, best_score = 0;
+    if (m > 0 && n > 0) {
+#pragma unroll
+        for (int q = 0; q < 2 * W + 3; ++q) d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
+        int pre_optimum = 0, cur_optimum = 0;
+        int lb = 1, ub = 1, pre_ub = 0;
+        const int wcap = (s.cap < t.cap ? s.cap : t.cap) - 8;
+        for (int k = 2; k <= m + n; ++k) {
+            int new_ub = -1;
+            CM_STAT(4, ub - lb + 1);
+            const int par = k & 1;                       // slots q == k (mod 2) live on this anti-diagonal (W odd)
+            const int q0 = par ? 1 : 2;
+            const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot (exact: k + q0 - W - 1 is even)
+            // bases: s[i0-1+r], t[k-i0-1-r] for r = 0..3
+            int sb = i0 - 1;
+            sb = sb < 0 ? 0 : (sb > wcap ? wcap : sb);
+            const uint64_t sw = s.window(sb);
+            const int ttop = k - i0 - 1;
+            int tb = ttop - W;
+            tb = tb < 0 ? 0 : (tb > wcap ? wcap : tb);
+            const uint64_t tw = t.window(tb);
+#pragma unroll
+            for (int r = 0; r <= W; ++r) {
+                const int q = q0 + 2 * r;
+                if (q > 2 * W + 1) continue;             // static: the even class has only W slots
+                const int i = i0 + r, j = k - i;
+                const bool valid = (i >= lb) && (i <= ub);
+                const int so = (i - 1) - sb, to = (j - 1) - tb;      // 0..4 whenever the cell is valid
+                const uint32_t sc_ch = (uint32_t)(sw >> (8 * (so & 7))) & 0xFFu, tc_ch = (uint32_t)(tw >> (8 * (to & 7))) & 0xFFu;
+                const int sub = (sc_ch == tc_ch) ? SC_MAT : SC_MIS;
+                const int nb = d[q - 1] > d[q + 1] ? d[q - 1] : d[q + 1];
+                int v = d[q] + sub;
+                v = v > nb + SC_IND ? v : nb + SC_IND;
+                const bool take = valid && (v >= cur_optimum);
+                cur_optimum = take ? v : cur_optimum;
+                on_s = take ? i : on_s;
+                on_t = take ? j : on_t;
+                best_score = take ? v : best_score;
+                v = (v + SC_XD < pre_optimum) ? -DPTINF : v;
+                new_ub = (valid && v > -DPTINF) ? i : new_ub;
+                const bool bnd = (k <= W) && (q == k + W + 1 || q == W + 1 - k);     // boundary cells (k,0), (0,k)
+                d[q] = valid ? v : (bnd ? k * SC_IND : -DPTINF);
+            }
+            const int lb_t = k - lb;
+            if (lb_t == m || (k > W && ((k - W) % 2 == 0))) ++lb;
+            if (ub < n && (k <= W || (k > W && ((k - W) % 2 == 1)))) ++ub;
+            if ((pre_ub == -1 && new_ub == -1) || lb > ub) break;
+            pre_ub = new_ub;
+            pre_optimum = cmax(pre_optimum, cur_optimum);
+        }
+    }
+    const int score = best_score;
+    const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
+    Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, W + 1, 0};
+    if (ed <= (uint32_t)c.P.max_ed) {
+        Cand x{(int)ed, m - on_t, on_t - on_s, score};
+        best = x;
+    }
+    align_score = score;
+    sc_len = best.sclen;
+    indel = best.indel;
+    return best.ed;
+}
+
 // Staging + dispatch on the (wave-uniform) band.  `sm` = the lane's two staging buffers.
 struct DpMem { LBuf a, b; g_err err; };
 CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
@@ -840,7 +934,7 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
     stage(s, n, sm.a, 4);
     stage(t, m, sm.b, 5);
-    return c.P.band == 3 ? local_alignment_sc_impl<3>(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
+    return c.P.band == 3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
                          : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
 }
 
@@ -1494,6 +1588,7 @@ struct Ext {
         if (lmm.middle_ed <= maxEd) is_concord_impl(lch, (uint32_t)lr.len, lmm, true);
         if (rmm.middle_ed <= maxEd) is_concord_impl(rch, (uint32_t)rr.len, rmm, true);
         if (lmm.middle_ed > maxEd || rmm.middle_ed > maxEd) return false;
+        CM_DBG_STOP(2, false);
         lmm.is_concord = false;
         rmm.is_concord = false;
         int lerr = lmm.middle_ed, rerr = rmm.middle_ed;
@@ -1502,12 +1597,16 @@ struct Ext {
         lmm.qspos = 1;
         lmm.qepos = (uint32_t)lr.len;
         const bool llok = chain_left(tids, n_tid, lch, lseq, 0, MINLB, lmm, lerr);
+        CM_DBG_STOP(3, false);
         rmm.matched_len = (uint32_t)rr.len;
         rmm.qspos = 1;
         rmm.qepos = (uint32_t)rr.len;
         const bool rlok = chain_left(tids, n_tid, rch, rseq, 0, lmm.spos, rmm, rerr);
+        CM_DBG_STOP(4, false);
         const bool rrok = chain_right(tids, n_tid, rch, rseq, rr.len, MAXUB, rmm, rerr);
+        CM_DBG_STOP(5, false);
         const bool lrok = chain_right(tids, n_tid, lch, lseq, lr.len, rmm.epos, lmm, lerr);
+        CM_DBG_STOP(6, false);
         update_match_mate_info(c, llok, lrok, lerr, lmm);
         update_match_mate_info(c, rlok, rrok, rerr, rmm);
         return true;
@@ -1598,6 +1697,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
                 bpaired |= 1u << j;
             }
         }
+    CM_DBG_STOP(1, mr.type);
     int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN;
     bool r1_genic = false, r2_genic = false;
     for (int i = 0; i < fwd.n; ++i)

@@ -75,36 +75,67 @@ __global__ void __launch_bounds__(BLK) k_seed(KCore kc, ReadsDev rd, const uint8
     if (threadIdx.x < 3 && sh[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(BLK) k_cells(const uint32_t *scnt, int S, uint32_t n_prob, uint32_t *cells) {
-    const uint32_t r = blockIdx.x * BLK + threadIdx.x;
-    if (r >= n_prob) return;
-    uint32_t t = 0;
-    for (int s = 0; s < S; ++s) t += scnt[(uint64_t)r * S + s];
-    cells[r] = t;
+// cells per chaining problem + exclusive scan over the problems of a tile (3 phases):
+// k_scan_a: per block of SCAN_ELEMS problems, cells[r] = sum of its seed counts, block-local
+// exclusive offsets and the block total; k_scan_b: one workgroup scans the block totals;
+// k_scan_c: adds the block base.  out[n] = grand total.
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ELEMS = 1024;       // 4 per thread
+__global__ void __launch_bounds__(SCAN_T) k_scan_a(const uint32_t *scnt, int S, uint32_t n, unsigned long long *out, unsigned long long *bsum) {
+    __shared__ unsigned long long sh[SCAN_T];
+    const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    uint32_t v[4];
+    unsigned long long t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t c = 0;
+        if (base + k < n)
+            for (int s = 0; s < S; ++s) c += scnt[(uint64_t)(base + k) * S + s];
+        v[k] = c;
+        t += c;
+    }
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        const unsigned long long x = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    unsigned long long run = threadIdx.x ? sh[threadIdx.x - 1] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == SCAN_T - 1) bsum[blockIdx.x] = sh[SCAN_T - 1];
 }
-
-// single-workgroup exclusive scan (n <= a few million); out[n] = total
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t *in, uint32_t n, unsigned long long *out) {
+__global__ void __launch_bounds__(1024) k_scan_b(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
     __shared__ unsigned long long part[1024];
     const uint32_t t = threadIdx.x;
-    const uint32_t chunk = (n + 1023u) / 1024u;
-    const uint32_t a = t * chunk, b = (a + chunk < n) ? a + chunk : n;
+    const uint32_t chunk = (nb + 1023u) / 1024u;
+    const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
     unsigned long long s = 0;
-    for (uint32_t i = a; i < b; ++i) s += in[i];
+    for (uint32_t i = a; i < b; ++i) s += bsum[i];
     part[t] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        unsigned long long v = (t >= d) ? part[t - d] : 0ull;
+        const unsigned long long v = (t >= d) ? part[t - d] : 0ull;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    unsigned long long run = (t == 0) ? 0ull : part[t - 1];
+    unsigned long long run = t ? part[t - 1] : 0ull;
     for (uint32_t i = a; i < b; ++i) {
-        out[i] = run;
-        run += in[i];
+        const unsigned long long x = bsum[i];
+        bsum[i] = run;
+        run += x;
     }
-    if (t == 1023) out[n] = part[1023];
+    if (t == 1023) *total = part[1023];
+}
+__global__ void __launch_bounds__(SCAN_T) k_scan_c(unsigned long long *out, const unsigned long long *bsum, uint32_t n) {
+    const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
+    if (i < n) out[i] += bsum[i / SCAN_ELEMS];
 }
 
 __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
@@ -140,44 +171,17 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
     high[r] = hh;
 }
 
-// Heavy-first launch order for k_pair (longest-processing-time-first): a pair's work grows with
-// the number of chain pairs it has to extend, so pairs are binned by that estimate and the heavy
-// bins get the lowest block indices; their long lanes then overlap with the bulk instead of
-// forming the tail of the launch.  Results do not depend on the order.
-__device__ inline int pair_cost_class(const int32_t *nchain, const uint8_t *active, uint64_t p, uint32_t t) {
-    if (!active[p]) return 2;
-    const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
-    const int cost = a * d + c * b + a + b + c + d;
-    return cost > 64 ? 0 : (cost > 8 ? 1 : 2);
-}
-__global__ void __launch_bounds__(BLK) k_order_count(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, unsigned int *ctr) {
-    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
-    if (t >= n_tile) return;
-    atomicAdd(&ctr[pair_cost_class(nchain, active, pair0 + t, t)], 1u);
-}
-__global__ void __launch_bounds__(BLK) k_order_place(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, unsigned int *ctr,
-                                                     uint32_t *perm, int identity) {
-    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
-    if (t >= n_tile) return;
-    const int k = pair_cost_class(nchain, active, pair0 + t, t);
-    const unsigned int base = (k == 0) ? 0u : (k == 1 ? ctr[0] : ctr[0] + ctr[1]);
-    if (identity) perm[t] = t;      // tuning knob CM_NO_ORDER=1
-    else perm[base + atomicAdd(&ctr[3 + k], 1u)] = t;
-}
-
 __global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
-                                                   int *err, unsigned long long *counters, int str_cap, const uint32_t *perm,
-                                                   unsigned long long *lane_clk) {
+                                                   int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
     CM_L uint8_t *lane_base = (CM_L uint8_t *)lds_words + 4 * threadIdx.x;
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
     const Core c = cmc::to_core(kc);
-    const uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x;
-    if (slot >= n_tile) return;
-    const uint32_t t = perm[slot];
+    const uint32_t t = blockIdx.x * BLK_PAIR + threadIdx.x;
+    if (t >= n_tile) return;
     const uint64_t p = pair0 + t;
     if (!active[p]) {
         cat[p] = -1;
@@ -199,7 +203,10 @@ __global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64
     state[p] = mr;
     active[p] = act;
     cat[p] = st;
-    atomicAdd(&counters[3], 1ull);
+    {   // pair-rounds counter: one atomic per wave
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(&counters[3], (unsigned long long)__popcll(m));
+    }
     if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
 }
 
@@ -252,14 +259,12 @@ struct cm_ctx {
     // workspace
     uint32_t tile = 0;
     uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
-    unsigned long long *d_celloff = nullptr;
+    unsigned long long *d_celloff = nullptr, *d_bsum = nullptr;
     double *d_dpscore = nullptr;
     int32_t *d_dpprev = nullptr;
     unsigned long long cells_cap = 0;
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
-    uint32_t *d_perm = nullptr;
-    unsigned int *d_order_ctr = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
@@ -314,9 +319,9 @@ void dfree(T *&p) {
 void free_reads(cm_ctx *c) {
     dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
-    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff);
+    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_perm); dfree(c->d_order_ctr); dfree(c->d_lane_clk);
+    dfree(c->d_pool); dfree(c->d_lane_clk);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -378,9 +383,11 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
     if (n_prob == 0 || S == 0) return CM_OK;
     {
         Timer t(ctx, 3);
-        hipLaunchKernelGGL(k_cells, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_cells);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cells, n_prob, ctx->d_celloff);
-        ctx->launches[3] += 2;
+        const uint32_t nb = (n_prob + SCAN_ELEMS - 1) / SCAN_ELEMS;
+        hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(SCAN_T), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_celloff, ctx->d_bsum);
+        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_bsum, nb, ctx->d_celloff + n_prob);
+        hipLaunchKernelGGL(k_scan_c, dim3((n_prob + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, ctx->stream, ctx->d_celloff, ctx->d_bsum, n_prob);
+        ctx->launches[3] += 3;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
     }
     unsigned long long total = 0;
@@ -627,6 +634,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_sraw, nprobe * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cells, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_celloff, (nprob + 1) * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsum, (nprob / SCAN_ELEMS + 2) * 8));
     // DP cells: room for 64 cells per problem on average, at least 8M (one worst-case problem is
     // n_seeds * seed_lim cells); larger tiles are split into ranges by run_chain_tile.
     unsigned long long cap = (unsigned long long)nprob * 64ull;
@@ -639,8 +647,6 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_order_ctr, 6 * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_lane_clk, n * 8));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lane_clk, 0, n * 8, ctx->stream));
@@ -671,13 +677,9 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
             const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_order_ctr, 0, 6 * sizeof(unsigned int), ctx->stream));
-            hipLaunchKernelGGL(k_order_count, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_order_ctr);
-            hipLaunchKernelGGL(k_order_place, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_order_ctr,
-                               ctx->d_perm, getenv("CM_NO_ORDER") ? 1 : 0);
             hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
                                ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
-                               str_cap, ctx->d_perm, ctx->d_lane_clk);
+                               str_cap, ctx->d_lane_clk);
             ++ctx->launches[2];
             HIPCHK(ctx, hipGetLastError());
         }

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libcmhot.so")
+LIB_PATH = os.environ.get("CM_LIB") or os.path.join(HERE, "csrc", "libcmhot.so")
 
 CM_BESTCHAINLIM = 30
 CM_MAX_CHAIN_FRAGS = 16

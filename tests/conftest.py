@@ -46,7 +46,7 @@ def emu(built):
     E.emu_map_round.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.AnnotView), pp(cl.Reads), C.c_int, vp, vp, vp]
     E.emu_edit_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int)]
     E.emu_drop_sc.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int), pp(C.c_int)]
-    E.emu_one_side.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+    E.emu_one_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int]
     return E
 
 

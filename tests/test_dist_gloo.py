@@ -1,0 +1,67 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharding + BSJ gatherv used by bench.py.
+Each rank maps its contiguous shard (CPU oracle stands in for the per-rank mapper here: this test is
+about the sharding and the collective, the kernels are covered by the gpu tests)."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from circminer_amd import dist as cdist, lib as cl, synth
+    from oracle import oracle_py as op
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    d = synth.generate("tiny", n_pairs=n_total, seed=21)
+    gtf = os.path.join(outdir, f"r{rank}.gtf")
+    open(gtf, "w").write(d.gtf_text)
+    hi = cl.HostIndex(d.contigs, d.chr_table, gtf)
+    a, b = cdist.shard_bounds(n_total, rank, world)
+    batch = cl.ReadBatch(d.seq1[a:b], d.seq2[a:b])
+    P = cl.default_params()
+    st, act, _ = op.map_all_rounds(P, hi, batch)
+    idx = np.nonzero(act)[0].astype(np.uint64)
+    rec = cdist.gather_bsj(cdist.pack_records(idx + a, st[idx]))
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered.npy"), rec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover():
+    from circminer_amd import dist as cdist
+    for n, w in ((10, 3), (1000, 8), (7, 8), (0, 2)):
+        cuts = [cdist.shard_bounds(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+
+
+def test_two_rank_gather_equals_single_process(ds_tiny):
+    import torch.multiprocessing as mp
+    from circminer_amd import dist as cdist, lib as cl
+    from oracle import oracle_py as op
+    n_total = 600
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker, args=(2, _free_port(), n_total, td), nprocs=2, join=True)
+        got = np.load(os.path.join(td, "gathered.npy"))
+    # single-process answer on the same reads (generator is seed-deterministic)
+    from circminer_amd import synth
+    d = synth.generate("tiny", n_pairs=n_total, seed=21)
+    batch = cl.ReadBatch(d.seq1, d.seq2)
+    st, act, _ = op.map_all_rounds(cl.default_params(), ds_tiny.hi, batch)
+    idx = np.nonzero(act)[0].astype(np.uint64)
+    want = cdist.pack_records(idx, st[idx])
+    assert len(got) == len(want) and got.tobytes() == want.tobytes()

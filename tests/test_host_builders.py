@@ -1,0 +1,146 @@
+"""Host-side index / annotation builders against independent numpy / pure-Python restatements of the
+reference's build rules (mrsfast HashTable.c:769-839; gene_annotation.cpp:191-399;
+interval_tree_impl.h:40-127,186-242)."""
+import ctypes as C
+
+import numpy as np
+
+from circminer_amd import lib as cl
+
+
+def _np(ptr, n, dt):
+    return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt)
+
+
+def test_index_matches_numpy_restatement(ds_tiny):
+    iv = ds_tiny.hi.views[0]
+    g = ds_tiny.d.contigs[0]
+    k, W = 20, 14
+    code = np.full(256, 4, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    c = code[g]
+    n = len(g) - k + 1
+    bad = np.convolve((c == 4).astype(np.int64), np.ones(k, np.int64), "valid")
+    starts = np.nonzero(bad == 0)[0]
+    val = np.zeros(len(starts), np.uint64)
+    for j in range(k):
+        val = (val << np.uint64(2)) | c[starts + j].astype(np.uint64)
+    order = np.lexsort((starts, val))                    # (k-mer value, position) == (bucket, checksum, pos)
+    val, pos = val[order], starts[order] + 1
+    assert iv.n_entries == len(pos)
+    assert (_np(iv.pos, iv.n_entries, np.int64) == pos).all()
+    assert (_np(iv.checksum, iv.n_entries, np.uint64) == (val & np.uint64((1 << (2 * (k - W))) - 1))).all()
+    off = _np(iv.bucket_off, 4 ** W + 1, np.int64)
+    bucket = (val >> np.uint64(2 * (k - W))).astype(np.int64)
+    assert (off[1:] - off[:-1] == np.bincount(bucket, minlength=4 ** W)).all()
+    assert n > 0
+
+
+def _ref_intervals(segs):
+    """FlatIntervalTree::build restated literally in Python (insertion procedure)."""
+    iv = []          # [spos, epos, [seg idx...]]
+
+    def handle(cur, si):
+        s, e = segs[si][0], segs[si][1]
+        m = iv[cur]
+        if m[0] < s:
+            pre = m[1]
+            m[1] = s - 1
+            iv.insert(cur + 1, [s, min(pre, e), m[2] + [si]])
+            if pre < e:
+                return cur + 2, True
+            if pre == e:
+                return cur, False
+            iv.insert(cur + 2, [e + 1, pre, list(m[2])])
+            return cur, False
+        if m[1] < e:
+            m[2].append(si)
+            return cur + 1, True
+        if m[1] == e:
+            m[2].append(si)
+            return cur, False
+        iv.insert(cur, [m[0], e, m[2] + [si]])
+        iv[cur + 1][0] = e + 1
+        return cur, False
+
+    j = 0
+    for si, (s, e, *_r) in enumerate(segs):
+        while j < len(iv) and s > iv[j][1]:
+            j += 1
+        if j == len(iv):
+            iv.append([s, e, [si]])
+        else:
+            cur, rem = j, False
+            while cur < len(iv):
+                cur, rem = handle(cur, si)
+                if not rem:
+                    break
+            if cur == len(iv) and rem:
+                iv.append([iv[cur - 1][1] + 1, e, [si]])
+    return iv
+
+
+def test_annotation_matches_python_restatement(ds_tiny2r):
+    d = ds_tiny2r.d
+    for con in range(ds_tiny2r.hi.n_contigs):
+        av = ds_tiny2r.hi.annots[con]
+        shift = {name: (cid - 1, st) for name, cid, st, _ in d.chr_table}
+        # unique segments keyed like UniqSeg::operator< (start, end, gene, -next)
+        segmap, n_gene, n_trans = {}, 0, 0
+        genes = []
+        for g in d.genes:
+            c, sh = shift[d.chr_names[g.chrom]]
+            if c != con:
+                continue
+            gid = n_gene
+            n_gene += 1
+            genes.append((g.start + sh, g.end + sh))
+            for t in g.transcripts:
+                tid = n_trans
+                n_trans += 1
+                ex = t.exons
+                for k2, (a, b) in enumerate(ex):
+                    nxt = ex[k2 + 1][0] + sh if k2 + 1 < len(ex) else 0
+                    segmap.setdefault((a + sh, b + sh, gid, -nxt), []).append(tid)
+        keys = sorted(segmap)
+        segs = [(a, b, g_, -n_) for (a, b, g_, n_) in keys]
+        iv = _ref_intervals(segs)
+        assert av.n_iv == len(iv) and av.n_seg == len(segs) and av.n_gene == n_gene and av.n_trans == n_trans
+        assert (_np(av.iv_spos, av.n_iv, np.int64) == [x[0] for x in iv]).all()
+        assert (_np(av.iv_epos, av.n_iv, np.int64) == [x[1] for x in iv]).all()
+        off = _np(av.iv_seg_off, av.n_iv + 1, np.int64)
+        flat = _np(av.iv_seg, off[-1], np.int64)
+        assert list(flat) == [s for x in iv for s in x[2]]
+        assert (_np(av.seg_start, av.n_seg, np.int64) == [s[0] for s in segs]).all()
+        assert (_np(av.seg_next_exon_beg, av.n_seg, np.int64) == [s[3] for s in segs]).all()
+        assert (_np(av.seg_gene_id, av.n_seg, np.int64) == [s[2] for s in segs]).all()
+        toff = _np(av.seg_tid_off, av.n_seg + 1, np.int64)
+        tids = _np(av.seg_tid, toff[-1], np.int64)
+        assert list(tids) == [t for k2 in keys for t in segmap[k2]]
+        assert (_np(av.gene_start, av.n_gene, np.int64) == [x[0] for x in genes]).all()
+        # per-interval caches and the transcript -> segment table
+        mx = [max(segs[s][1] for s in x[2]) for x in iv]
+        assert (_np(av.iv_max_end, av.n_iv, np.int64) == mx).all()
+        starts = _np(av.trans_start_ind, av.n_trans, np.int64)
+        t2o = _np(av.t2s_off, av.n_trans + 1, np.int64)
+        t2s = _np(av.t2s, t2o[-1], np.int64)
+        for i, x in enumerate(iv):
+            for s in x[2]:
+                state = 1 if x[0] == segs[s][0] else (3 if x[1] == segs[s][1] else 2)
+                for t in segmap[keys[s]]:
+                    assert starts[t] <= i and t2s[t2o[t] + i - starts[t]] == state
+        # bitsets: near-border flanks and intronic positions
+        nb = np.unpackbits(_np(av.near_border_bits, av.n_bits // 64, np.uint64).view(np.uint8), bitorder="little")
+        it = np.unpackbits(_np(av.intronic_bits, av.n_bits // 64, np.uint64).view(np.uint8), bitorder="little")
+        exp_nb = np.zeros_like(nb)
+        exp_it = np.zeros_like(it)
+        for a, b in genes:
+            exp_it[a:b + 1] = 1
+        for (a, b, _g, _n) in segs:
+            exp_it[a:b + 1] = 0
+            if a >= 300:
+                exp_nb[a - 300:a] = 1
+            if b + 1 >= 300:
+                exp_nb[b - 299:b + 1] = 1
+        assert (nb == exp_nb).all() and (it == exp_it).all()

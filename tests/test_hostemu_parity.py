@@ -1,0 +1,118 @@
+"""The kernel bodies of circminer_amd/csrc/cm_core.h, run lane-by-lane on the CPU by
+tests/hostemu.cpp, against the oracle (bit-exact).  This is how the device code is debugged on the
+build box, which has no GPU; the same comparisons run on the real HIP path in test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from circminer_amd import lib as cl
+from oracle import oracle_py as op
+from conftest import first_diff
+
+
+def _emu_rounds(E, ds, P):
+    st0, act0 = op.default_state(P, ds.batch.n)
+    st1, act1 = st0.copy(), act0.copy()
+    for ci in range(ds.hi.n_contigs):
+        last = ci == ds.hi.n_contigs - 1
+        iv, av = ds.hi.views[ci], ds.hi.annots[ci]
+        cat0 = op.map_round(P, iv, av, ds.batch, last, st0, act0)
+        cat1 = np.full(ds.batch.n, -1, np.int32)
+        rc = E.emu_map_round(C.byref(P), C.byref(iv), C.byref(av), C.byref(ds.batch.c), int(last), st1.ctypes.data, act1.ctypes.data,
+                             cat1.ctypes.data)
+        assert rc == 0
+        assert (cat0 == cat1).all() and (act0 == act1).all()
+        assert st0.tobytes() == st1.tobytes(), first_diff(st0, st1)
+
+
+def test_seeds_and_chains(emu, ds_tiny):
+    P = cl.default_params()
+    iv, av, b = ds_tiny.hi.views[0], ds_tiny.hi.annots[0], ds_tiny.batch
+    S = b.max_len() // P.kmer
+    a0, b0, c0 = op.seeds(P, iv, b, S)
+    a1, b1, c1 = (np.zeros_like(a0) for _ in range(3))
+    assert emu.emu_seed_batch(C.byref(P), C.byref(iv), C.byref(b.c), S, a1.ctypes.data, b1.ctypes.data, c1.ctypes.data) == 0
+    assert (c0 == c1).all() and (b0 == b1).all() and (a0[c0 > 0] == a1[c0 > 0]).all()
+    ch0, n0, h0 = op.chains(P, iv, av, b)
+    ch1, n1, h1 = np.zeros_like(ch0), np.zeros_like(n0), np.zeros_like(h0)
+    assert emu.emu_chain_batch(C.byref(P), C.byref(iv), C.byref(av), C.byref(b.c), ch1.ctypes.data, n1.ctypes.data, h1.ctypes.data) == 0
+    assert (n0 == n1).all() and (h0 == h1).all()
+    x, y = ch0.reshape(-1, 30), ch1.reshape(-1, 30)
+    for r in np.nonzero(n0)[0]:
+        for k in range(n0[r]):
+            L = int(x[r, k]["chain_len"])
+            assert L == int(y[r, k]["chain_len"]) and x[r, k]["score"] == y[r, k]["score"]
+            assert (x[r, k]["rpos"][:L] == y[r, k]["rpos"][:L]).all() and (x[r, k]["qpos"][:L] == y[r, k]["qpos"][:L]).all()
+
+
+@pytest.mark.parametrize("name", ["ds_tiny", "ds_tiny2r"])
+def test_map_rounds(emu, name, request):
+    _emu_rounds(emu, request.getfixturevalue(name), cl.default_params())
+
+
+@pytest.mark.parametrize("kw", [dict(scan_level=1), dict(scan_level=2, max_ed=8, seed_lim=1000), dict(band=2), dict(band=5, max_ed=6),
+                                dict(max_chain_len=4, max_intron=5000), dict(max_sc=3, max_tlen=250)])
+def test_map_rounds_param_variants(emu, ds_tiny2r, kw):
+    _emu_rounds(emu, ds_tiny2r, cl.default_params(**kw))
+
+
+def test_k22_int16_checksum_quirk(emu, tmp_path_factory):
+    """k=22: the reference compares an int16 target with the uint16 checksum (match_read.cpp:77), so
+    k-mers whose checksum >= 0x8000 are never found.  Oracle and device code both reproduce it."""
+    from conftest import DataSet
+    ds = DataSet(tmp_path_factory.mktemp("k22"), "tiny", 600, 29, kmer=22)
+    P = cl.default_params(kmer=22)
+    iv, b = ds.hi.views[0], ds.batch
+    S = b.max_len() // 22
+    a0, b0, c0 = op.seeds(P, iv, b, S)
+    a1, b1, c1 = (np.zeros_like(a0) for _ in range(3))
+    assert emu.emu_seed_batch(C.byref(P), C.byref(iv), C.byref(b.c), S, a1.ctypes.data, b1.ctypes.data, c1.ctypes.data) == 0
+    assert (c0 == c1).all()
+    # forward-orientation probes of R1: found iff the 15th base of the seed is A or C
+    r1 = ds.d.seq1
+    probe = c0.reshape(b.n, 2, 2, S)[:, 0, 0, :]
+    base15 = r1[:, [s * 22 + 14 for s in range(S)]]
+    hi_half = np.isin(base15, [ord("G"), ord("T")])
+    assert (probe[hi_half] == 0).all() and (probe[~hi_half] > 0).mean() > 0.3   # ~half the R1s are reverse-strand
+    _emu_rounds(emu, ds, P)
+
+
+def test_dp_bodies_fuzz(emu):
+    O = op.load()
+    rng = np.random.default_rng(11)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for band, max_ed in ((3, 4), (2, 4), (5, 8)):
+        P = cl.default_params(band=band, max_ed=max_ed)
+        for _ in range(700):
+            m = int(rng.integers(1, 150))
+            t = A[rng.integers(0, 4, m)].copy()
+            s = t.copy()
+            for _k in range(int(rng.integers(0, 5))):
+                s[int(rng.integers(0, len(s)))] = A[rng.integers(0, 4)]
+            if rng.random() < 0.4 and len(s) > 3:
+                s = np.delete(s, int(rng.integers(0, len(s))))
+            if rng.random() < 0.4:
+                s = np.insert(s, int(rng.integers(0, len(s))), A[rng.integers(0, 4)])
+            s = np.concatenate([s, A[rng.integers(0, 4, band + 2)]])[:m + band]
+            if rng.random() < 0.15:
+                s[int(rng.integers(0, len(s)))] = ord("N")
+            if rng.random() < 0.15:
+                t[int(rng.integers(0, m))] = ord("n")
+            s, n = np.ascontiguousarray(s), len(s)
+            for left in (0, 1):
+                a = [C.c_int() for _ in range(3)]
+                b = [C.c_int() for _ in range(3)]
+                r0 = O.oracle_drop_sc(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, *[C.byref(x) for x in a])
+                r1 = emu.emu_drop_sc(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, *[C.byref(x) for x in b])
+                assert r0 == r1 and [x.value for x in a] == [x.value for x in b], (band, left, n, m)
+                if n > m:
+                    a, b = [C.c_int(), C.c_int()], [C.c_int(), C.c_int()]
+                    r0 = O.oracle_edit_side(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, C.byref(a[0]), C.byref(a[1]))
+                    r1 = emu.emu_edit_side(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, C.byref(b[0]), C.byref(b[1]))
+                    assert r0 == r1 and [x.value for x in a] == [x.value for x in b], (band, left, n, m)
+            w = int(rng.integers(0, band + 1))
+            n3 = int(rng.integers(0, 60))
+            s3 = A[rng.integers(0, 4, max(n3, 1))]
+            t3 = np.ascontiguousarray(np.concatenate([s3[:n3], A[rng.integers(0, 4, w + 1)]])[:n3 + w + 1])
+            assert O.oracle_one_side(s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w) == emu.emu_one_side(C.byref(P), s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w)

@@ -623,32 +623,67 @@ CM_HD inline uint8_t code1(uint8_t ch, bool comp, uint8_t other) { return (uint8
 // Device build: 16-byte global loads (the caller guarantees CM_STAGE_PAD readable bytes on both
 // sides of every global string, see cm_hot.hip) + whole-word LDS stores.
 constexpr int CM_STAGE_PAD = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+// codes of characters 4*w0 .. 4*w0+15 of view v, four per word
+CM_HD inline void load_codes16(const SV &v, int w0, uint8_t other, uint32_t q[4]) {
+    if (v.mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = 0x01010101u * other;
+        return;
+    }
+    uint32_t r[4];
+    if (v.step > 0) {
+        __builtin_memcpy(r, (const CM_G uint8_t *)(v.p + v.off + 4 * w0), 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = code4(r[k], v.mode == 1, other);
+    } else {                                                   // chars 4*w0 .. 4*w0+15 live at p[off - i]
+        __builtin_memcpy(r, (const CM_G uint8_t *)(v.p + v.off - 4 * w0 - 15), 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = code4(__builtin_bswap32(r[3 - k]), v.mode == 1, other);
+    }
+}
+#endif
 CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
 #if defined(__HIP_DEVICE_COMPILE__)
     CM_L uint32_t *dw = (CM_L uint32_t *)d.b;
     const int nw = (n + 3) >> 2;
-    if (v.mode == 2) {
-        for (int w = 0; w < nw; ++w) dw[w * LSTRIDE] = 0x01010101u * other;
-        return;
-    }
-    const bool comp = v.mode == 1;
     for (int w0 = 0; w0 < nw; w0 += 4) {
         uint32_t q[4];
-        if (v.step > 0) {
-            __builtin_memcpy(q, (const CM_G uint8_t *)(v.p + v.off + 4 * w0), 16);
-        } else {
-            uint32_t r[4];                                     // chars 4*w0 .. 4*w0+15 live at p[off - i]
-            __builtin_memcpy(r, (const CM_G uint8_t *)(v.p + v.off - 4 * w0 - 15), 16);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = __builtin_bswap32(r[3 - k]);
-        }
+        load_codes16(v, w0, other, q);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (w0 + k < nw) dw[(w0 + k) * LSTRIDE] = code4(q[k], comp, other);
+            if (w0 + k < nw) dw[(w0 + k) * LSTRIDE] = q[k];
     }
 #else
     for (int i = 0; i < n; ++i) d.put(i, v.mode == 2 ? other : code1(v.p[v.off + i * v.step], v.mode == 1, other));
 #endif
+}
+// number of positions i < len where a[i] and b[i] are not the same base (N never matches)
+CM_HD inline int prefix_mismatches(const SV &a, const SV &b, int len) {
+    int mm = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int w0 = 0; 4 * w0 < len; w0 += 4) {
+        uint32_t qa[4], qb[4];
+        load_codes16(a, w0, 4, qa);
+        load_codes16(b, w0, 5, qb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int base = 4 * (w0 + k);
+            if (base >= len) continue;
+            uint32_t x = qa[k] ^ qb[k];
+            x = (x | (x >> 1) | (x >> 2)) & 0x01010101u;                   // 1 per differing byte (codes < 8)
+            if (len - base < 4) x &= (1u << (8 * (len - base))) - 1u;
+            mm += __builtin_popcount(x);
+        }
+    }
+#else
+    for (int i = 0; i < len; ++i) {
+        const uint8_t x = a.mode == 2 ? 4 : code1(a.p[a.off + i * a.step], a.mode == 1, 4);
+        const uint8_t y = b.mode == 2 ? 5 : code1(b.p[b.off + i * b.step], b.mode == 1, 5);
+        mm += x != y;
+    }
+#endif
+    return mm;
 }
 CM_HD inline int ldiff(uint8_t a, uint8_t b) { return a == b ? 0 : 1; }
 CM_HD inline int lscore(uint8_t a, uint8_t b) { return a == b ? SC_MAT : SC_MIS; }
@@ -910,19 +945,42 @@ CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n,
 }
 
 // Staging + dispatch on the (wave-uniform) band.  `sm` = the lane's two staging buffers.
+#if defined(CM_DIAG) && defined(__HIPCC__)
+struct Tick { unsigned long long last; unsigned long long acc[16]; };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_TICK(sm_, id) do { const unsigned long long n_ = wall_clock64(); (sm_).tk->acc[id] += n_ - (sm_).tk->last; (sm_).tk->last = n_; } while (0)
+#else
+#define CM_TICK(sm_, id) ((void)0)
+#endif
+struct DpMem { LBuf a, b; g_err err; Tick *tk; };
+#else
+#define CM_TICK(sm_, id) ((void)0)
 struct DpMem { LBuf a, b; g_err err; };
+#endif
 CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
     if (n <= sm.a.cap && m <= sm.b.cap && n >= 0 && m >= 0) return true;
     flag_err(sm.err, ERR_BAND);
     return false;
 }
+// Closed forms used below (each provably equal to the DP it replaces):
+//  * one-sided DP with w == 0 is the Hamming distance; with w > 0 and s == t[0..n) it is w (= |m - n|);
+//  * banded edit DP with s[0..m) == t: dp[m][m] = 0 beats every other end row (score 0 vs <= -2);
+//  * X-drop DP with s[0..m) == t (all m bases valid): the diagonal is never pruned, cell (m, m) scores m
+//    and no other cell can (score <= matches - 3*gaps), so on_s = on_t = m, ed = 0, no clip, no indel.
 CM_HD inline int one_side_banded(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int w) {
+    if (w == 0 && m == n && n >= 0) return prefix_mismatches(s, t, n);
+    if (w > 0 && n > w && m == n + w && prefix_mismatches(s, t, n) == 0) return w;
     if (!dp_fits(sm, n, m)) return c.P.max_ed + 1;
     stage(s, n, sm.a, 4);
     stage(t, m, sm.b, 5);
     return c.P.band == 3 ? one_side_banded_impl<3>(sm.a, n, sm.b, m, w) : one_side_banded_impl<0>(sm.a, n, sm.b, m, w);
 }
 CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, bool rev, int &indel, int &align_score) {
+    if (m >= 1 && n >= m && prefix_mismatches(rev ? s.rev(n) : s, rev ? t.rev(m) : t, m) == 0) {
+        indel = 0;
+        align_score = 0;
+        return 0;
+    }
     if (!dp_fits(sm, n, m)) { indel = c.P.band + 1; align_score = -(c.P.max_ed + 1); return c.P.max_ed + 1; }
     stage(rev ? s.rev(n) : s, n, sm.a, 4);
     stage(rev ? t.rev(m) : t, m, sm.b, 5);
@@ -931,6 +989,12 @@ CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &
 }
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
+    if (m >= 1 && n >= m && prefix_mismatches(s, t, m) == 0) {
+        sc_len = 0;
+        indel = 0;
+        align_score = m * SC_MAT;
+        return 0;
+    }
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
     stage(s, n, sm.a, 4);
     stage(t, m, sm.b, 5);
@@ -1371,14 +1435,13 @@ struct Ext {
         }
     }
 
-    CM_HD void right_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t ub, AlignRes &best,
-                           bool &consecutive, Memo &memo) const {
+    // it_seg / it_ind: get_location_overlap_ind(pos), looked up once per extend call (same pos for every tid)
+    CM_HD void right_trans(uint32_t tid, uint32_t pos, int it_seg, int it_ind, int ref_len, const SV &q, int qlen, int ed_th, uint32_t ub,
+                           AlignRes &best, bool &consecutive, Memo &memo) const {
         const AnnotV &A = c.A;
         consecutive = false;
         CM_STAT(7, 1);
         AlignRes curr = ar_init(ub), exon_res = ar_init(ub);
-        int it_ind;
-        int it_seg = overlap_ind(c, pos, it_ind);
         if (it_seg < 0) return;
         int covered = 0;
         const int it_start = A.trans_start_ind[tid];
@@ -1423,13 +1486,11 @@ struct Ext {
         end_step(memo, key, rspos, (uint32_t)remain_ref_len, q.sub(covered), qlen - covered, ed_th, best, curr, exon_res, true);
     }
 
-    CM_HD void left_trans(uint32_t tid, uint32_t pos, int ref_len, const SV &q, int qlen, int ed_th, uint32_t lb, AlignRes &best,
-                          bool &consecutive, Memo &memo) const {
+    CM_HD void left_trans(uint32_t tid, uint32_t pos, int it_seg, int it_ind, int ref_len, const SV &q, int qlen, int ed_th, uint32_t lb,
+                          AlignRes &best, bool &consecutive, Memo &memo) const {
         const AnnotV &A = c.A;
         consecutive = false;
         AlignRes curr = ar_init(lb), exon_res = ar_init(lb);
-        int it_ind;
-        int it_seg = overlap_ind(c, pos, it_ind);
         if (it_seg < 0) return;
         int covered = 0;
         const int it_start = A.trans_start_ind[tid];
@@ -1490,11 +1551,14 @@ struct Ext {
         ar_set(best, pos, ed_th + 1, len + 1, c.P.band + 1, 0, 0);
         Memo memo;
         memo.n = 0;
+        int it_ind = -1, it_seg = -1;
+        if (n_tid > 0) it_seg = overlap_ind(c, pos, it_ind);
         for (int i = 0; i < n_tid; ++i) {
-            if (right) right_trans(tids[i], pos, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
-            else left_trans(tids[i], pos, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+            if (right) right_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+            else left_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
         }
         int min_ed = best.ed, sclen_best = best.sclen;
+        CM_TICK(sm, 11);
         if (min_ed <= ed_th) {
             pos = right ? best.pos - sclen_best : best.pos + sclen_best;
             if (best.qcovlen >= seq_len && sclen_best <= c.P.max_sc) return true;
@@ -1504,6 +1568,7 @@ struct Ext {
             int indel, sc;
             if (right) min_ed = local_alignment_sc(c, sm, ref, ref_len, q, seq_len, sclen_best, indel, sc);
             else min_ed = local_alignment_sc(c, sm, ref.rev(ref_len), ref_len, q.rev(seq_len), seq_len, sclen_best, indel, sc);
+            CM_TICK(sm, 12);
             if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
                 const uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;
                 AlignRes curr = ar_init(bound);
@@ -1583,12 +1648,14 @@ struct Ext {
     CM_HD bool both_mates(const CH &lch, const CH &rch, const uint32_t *tids, int n_tid, const Read &lr, const Read &rr, MM &lmm, MM &rmm) const {
         const int maxEd = c.P.max_ed;
         const SV lseq = lr.view(), rseq = rr.view();
+        CM_TICK(sm, 3);
         lmm.middle_ed = calc_middle_ed(lch, maxEd, lseq);
         rmm.middle_ed = calc_middle_ed(rch, maxEd, rseq);
         if (lmm.middle_ed <= maxEd) is_concord_impl(lch, (uint32_t)lr.len, lmm, true);
         if (rmm.middle_ed <= maxEd) is_concord_impl(rch, (uint32_t)rr.len, rmm, true);
         if (lmm.middle_ed > maxEd || rmm.middle_ed > maxEd) return false;
         CM_DBG_STOP(2, false);
+        CM_TICK(sm, 4);
         lmm.is_concord = false;
         rmm.is_concord = false;
         int lerr = lmm.middle_ed, rerr = rmm.middle_ed;
@@ -1598,15 +1665,19 @@ struct Ext {
         lmm.qepos = (uint32_t)lr.len;
         const bool llok = chain_left(tids, n_tid, lch, lseq, 0, MINLB, lmm, lerr);
         CM_DBG_STOP(3, false);
+        CM_TICK(sm, 5);
         rmm.matched_len = (uint32_t)rr.len;
         rmm.qspos = 1;
         rmm.qepos = (uint32_t)rr.len;
         const bool rlok = chain_left(tids, n_tid, rch, rseq, 0, lmm.spos, rmm, rerr);
         CM_DBG_STOP(4, false);
+        CM_TICK(sm, 6);
         const bool rrok = chain_right(tids, n_tid, rch, rseq, rr.len, MAXUB, rmm, rerr);
         CM_DBG_STOP(5, false);
+        CM_TICK(sm, 7);
         const bool lrok = chain_right(tids, n_tid, lch, lseq, lr.len, rmm.epos, lmm, lerr);
         CM_DBG_STOP(6, false);
+        CM_TICK(sm, 8);
         update_match_mate_info(c, llok, lrok, lerr, lmm);
         update_match_mate_info(c, rlok, rrok, rerr, rmm);
         return true;
@@ -1663,6 +1734,65 @@ struct ChainSet {          // chains of one (mate, orientation)
     int n;
 };
 
+// One mate pair of process_mates' loop (filter.cpp:261-342), split in two so that the expensive,
+// order-independent half can run as parallel tasks:
+//   extend_task : decide the left mate, extend both mates, look up the exon intervals of the ends;
+//   fold_task   : apply the outcome to the pair's MatchedRead — must be applied in (i, j) order;
+//                 returns true where the reference returns CONCRD from inside the loop.
+CM_HD inline void extend_task(const Core &c, const Ext &ext, const CH &F, const CH &R, const uint32_t *tids, int n_tid, const Read &frd,
+                              const Read &brd, MM &r1, MM &r2, bool &is_left, bool &ok, int &row) {
+    r1 = mm_init(c);
+    r2 = mm_init(c);
+    r1.dir = 1;
+    r2.dir = -1;
+    row = 0;
+    is_left = is_left_chain(F, R, frd.len);
+    if (is_left) ok = ext.both_mates(F, R, tids, n_tid, frd, brd, r1, r2);
+    else ok = ext.both_mates(R, F, tids, n_tid, brd, frd, r2, r1);
+    if (ok) {
+        row = chr_row(c, is_left ? r1.spos : r2.spos);
+        overlap_to_epos(c, r1); overlap_to_spos(c, r1);
+        overlap_to_epos(c, r2); overlap_to_spos(c, r2);
+    }
+}
+CM_HD inline bool fold_task(const Core &c, const MM &r1, const MM &r2, bool is_left, bool ok, int row, int pair_type, bool r1_forward,
+                            cm_mapped_read &mr) {
+    if (!ok) return false;
+    const bool both_c = r1.type == CM_CONCRD && r2.type == CM_CONCRD;
+    const bool one_c = (r1.type == CM_CANDID && r2.type == CM_CONCRD) || (r1.type == CM_CONCRD && r2.type == CM_CANDID);
+    const bool both_x = r1.type == CM_CANDID && r2.type == CM_CANDID;
+    if (is_left) {
+        if (both_c) {
+            if (concordant_explanation(c, r1, r2, mr, row, r1_forward, pair_type) && c.P.scan_level == 0) return true;
+        } else if (one_c) check_bsj(c, r1, r2, mr, row, r1_forward);
+        else if (both_x) check_2bsj(c, r1, r2, mr, row, r1_forward);
+    } else {
+        if (both_c) check_chimeric(c, r2, r1, mr, row, !r1_forward);
+        else if (one_c) check_bsj(c, r2, r1, mr, row, !r1_forward);
+        else if (both_x) check_2bsj(c, r2, r1, mr, row, !r1_forward);
+    }
+    return false;
+}
+// the pairing predicate of pair_chains for one (i, j): 0 = not paired, else pair type + 1
+CM_HD inline uint32_t pair_code(const Core &c, const CH &F, const CH &R, int fe_i, int re_j, int saved_type, uint32_t *tids, g_err err) {
+    const uint32_t fs = F.rpos(0), rs = R.rpos(0), fe_ = F.rend_excl(), re_ = R.rend_excl();
+    const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
+    bool same_tr = false, same_gen = false;
+    if (fe_i >= 0 && re_j >= 0) same_tr = common_tids(c, fe_i, re_j, tids, err) > 0;
+    if (!same_tr && fe_i >= 0 && ((c.P.scan_level == 0 && saved_type > CM_CONGEN) || (c.P.scan_level > 0 && saved_type >= CM_CONGEN)))
+        same_gen = same_gene_span(c, fe_i, rs, re_);
+    if (!same_gen && re_j >= 0 && saved_type >= CM_CONGEN) same_gen = same_gene_span(c, re_j, fs, fe_);
+    if (same_tr || same_gen || ((tlen <= MAXDISCRDTLEN) && (saved_type >= CM_CONGNM))) return same_tr ? 1u : (same_gen ? 2u : 3u);
+    return 0u;
+}
+// the category process_mates derives from the unpaired-chain extensions (filter.cpp:387-393)
+CM_HD inline int leftover_type(int min_ret1, int min_ret2, bool r1_genic, bool r2_genic) {
+    return (((min_ret1 == CM_ORPHAN) && (min_ret2 == CM_CONCRD)) || ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_ORPHAN))) ? CM_OEANCH
+         : ((min_ret1 == CM_ORPHAN) || (min_ret2 == CM_ORPHAN)) ? CM_ORPHAN
+         : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD) && (r1_genic && r2_genic)) ? CM_CHIFUS
+         : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD)) ? CM_OEA2 : CM_CANDID;
+}
+
 // FilterRead::process_mates (filter.cpp:244-395) with pair_chains (filter.cpp:484-551) fused in:
 // pass 1 evaluates the pairing predicate for every (i, j) (needed up-front for the *_paired
 // flags), pass 2 walks the accepted pairs in i-major order.
@@ -1681,16 +1811,8 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     for (int i = 0; i < fwd.n; ++i)
         for (int j = 0; j < bwd.n; ++j) {
             const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-            const uint32_t fs = F.rpos(0), rs = R.rpos(0), fe_ = F.rend_excl(), re_ = R.rend_excl();
-            const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
-            bool same_tr = false, same_gen = false;
-            if (fe[i] >= 0 && re[j] >= 0) same_tr = common_tids(c, fe[i], re[j], tids, err) > 0;
-            if (!same_tr && fe[i] >= 0 &&
-                ((c.P.scan_level == 0 && saved_type > CM_CONGEN) || (c.P.scan_level > 0 && saved_type >= CM_CONGEN)))
-                same_gen = same_gene_span(c, fe[i], rs, re_);
-            if (!same_gen && re[j] >= 0 && saved_type >= CM_CONGEN) same_gen = same_gene_span(c, re[j], fs, fe_);
-            if (same_tr || same_gen || ((tlen <= MAXDISCRDTLEN) && (saved_type >= CM_CONGNM))) {
-                const uint32_t code = same_tr ? 1u : (same_gen ? 2u : 3u);
+            const uint32_t code = pair_code(c, F, R, fe[i], re[j], saved_type, tids, err);
+            if (code) {
                 const int idx = i * CM_BESTCHAINLIM + j;
                 ptype[idx >> 4] |= code << ((idx & 15) * 2);
                 fpaired |= 1u << i;
@@ -1698,6 +1820,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             }
         }
     CM_DBG_STOP(1, mr.type);
+    CM_TICK(sm, 1);
     int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN;
     bool r1_genic = false, r2_genic = false;
     for (int i = 0; i < fwd.n; ++i)
@@ -1709,37 +1832,15 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             const int n_tid = (code == 1) ? common_tids(c, fe[i], re[j], tids, err) : 0;
             // (when same_tr is false the reference's common_tid is empty: same_transcript clears it)
             CM_STAT(0, 1);
-            MM r1 = mm_init(c), r2 = mm_init(c);
-            r1.dir = 1;
-            r2.dir = -1;
+            MM r1, r2;
+            bool is_left, ok;
+            int row;
             const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-            if (is_left_chain(F, R, frd.len)) {
-                if (ext.both_mates(F, R, tids, n_tid, frd, brd, r1, r2)) {
-                    const int row = chr_row(c, r1.spos);
-                    overlap_to_epos(c, r1); overlap_to_spos(c, r1);
-                    overlap_to_epos(c, r2); overlap_to_spos(c, r2);
-                    if (r1.type == CM_CONCRD && r2.type == CM_CONCRD) {
-                        if (concordant_explanation(c, r1, r2, mr, row, r1_forward, pair_type) && c.P.scan_level == 0) return CM_CONCRD;
-                    } else if ((r1.type == CM_CANDID && r2.type == CM_CONCRD) || (r1.type == CM_CONCRD && r2.type == CM_CANDID)) {
-                        check_bsj(c, r1, r2, mr, row, r1_forward);
-                    } else if (r1.type == CM_CANDID && r2.type == CM_CANDID) {
-                        check_2bsj(c, r1, r2, mr, row, r1_forward);
-                    }
-                }
-            } else {
-                if (ext.both_mates(R, F, tids, n_tid, brd, frd, r2, r1)) {
-                    const int row = chr_row(c, r2.spos);
-                    overlap_to_epos(c, r1); overlap_to_spos(c, r1);
-                    overlap_to_epos(c, r2); overlap_to_spos(c, r2);
-                    if (r1.type == CM_CONCRD && r2.type == CM_CONCRD) {
-                        check_chimeric(c, r2, r1, mr, row, !r1_forward);
-                    } else if ((r1.type == CM_CANDID && r2.type == CM_CONCRD) || (r1.type == CM_CONCRD && r2.type == CM_CANDID)) {
-                        check_bsj(c, r2, r1, mr, row, !r1_forward);
-                    } else if (r1.type == CM_CANDID && r2.type == CM_CANDID) {
-                        check_2bsj(c, r2, r1, mr, row, !r1_forward);
-                    }
-                }
-            }
+            CM_TICK(sm, 2);
+            extend_task(c, ext, F, R, tids, n_tid, frd, brd, r1, r2, is_left, ok, row);
+            CM_TICK(sm, 9);
+            if (fold_task(c, r1, r2, is_left, ok, row, pair_type, r1_forward, mr)) return CM_CONCRD;
+            CM_TICK(sm, 10);
             min_ret1 = cmin(r1.type, min_ret1);
             min_ret2 = cmin(r2.type, min_ret2);
             r1_genic = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
@@ -1768,10 +1869,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
                 overlap_to_epos(c, mm2);
                 r2_genic = (mm2.exons_spos >= 0) || (mm2.exons_epos >= 0);
             }
-    const int new_type = (((min_ret1 == CM_ORPHAN) && (min_ret2 == CM_CONCRD)) || ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_ORPHAN))) ? CM_OEANCH
-                       : ((min_ret1 == CM_ORPHAN) || (min_ret2 == CM_ORPHAN)) ? CM_ORPHAN
-                       : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD) && (r1_genic && r2_genic)) ? CM_CHIFUS
-                       : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD)) ? CM_OEA2 : CM_CANDID;
+    const int new_type = leftover_type(min_ret1, min_ret2, r1_genic, r2_genic);
     mr_update_type(mr, new_type);
     return mr.type;
 }

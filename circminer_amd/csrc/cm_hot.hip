@@ -173,12 +173,20 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
 
 __global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
-                                                   int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk) {
+                                                   int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
+                                                   const uint8_t *heavy_flag) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
     CM_L uint8_t *lane_base = (CM_L uint8_t *)lds_words + 4 * threadIdx.x;
+#if defined(CM_DIAG)
+    cmc::Tick tick;
+    for (int i = 0; i < 16; ++i) tick.acc[i] = 0;
+    tick.last = wall_clock64();
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err, &tick};
+#else
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
+#endif
     const Core c = cmc::to_core(kc);
     const uint32_t t = blockIdx.x * BLK_PAIR + threadIdx.x;
     if (t >= n_tile) return;
@@ -187,6 +195,7 @@ __global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64
         cat[p] = -1;
         return;
     }
+    if (heavy_flag[t]) return;          // mapped by k_pair_heavy, one pair per wave
     const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
     cmc::ChainSet sets[4];
     int hh[4];
@@ -207,7 +216,261 @@ __global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64
         const unsigned long long m = __ballot(1);
         if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(&counters[3], (unsigned long long)__popcll(m));
     }
+#if defined(CM_DIAG)
+    CM_TICK(sm, 13);
+    if (lane_clk) {                                           // section timing study: 16 words per pair
+        for (int i = 0; i < 15; ++i) lane_clk[p * 16 + i] = tick.acc[i];
+        lane_clk[p * 16 + 15] = wall_clock64() - clk0;
+    }
+#else
     if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
+#endif
+}
+
+// ---- light / heavy split of the pair stage -------------------------------------------------
+// A pair whose chain lists can produce many mate pairs and unpaired-chain extensions (reads from
+// repeats: up to 30 x 30 pairs plus 60 full-length extensions) costs 100x the median pair; as one lane
+// it would hold its whole wave for milliseconds.  Such pairs are listed by k_classify and mapped one
+// per *wave* by k_pair_heavy (64 lanes share the pairing predicate, the mate-pair extensions and the
+// unpaired-chain extensions; lane 0 folds the outcomes in the reference's order).  Everything else
+// stays one pair per lane in k_pair.
+constexpr int HEAVY_COST = 8;
+__global__ void __launch_bounds__(BLK) k_classify(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, uint8_t *heavy_flag,
+                                                  uint32_t *hlist, unsigned int *hcount) {
+    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+    bool heavy = false;
+    if (t < n_tile && active[pair0 + t]) {
+        const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
+        heavy = (a * d + c * b + a + b + c + d) > HEAVY_COST;
+    }
+    if (t < n_tile) heavy_flag[t] = heavy ? 1 : 0;
+    const unsigned long long m = __ballot(heavy);
+    if (heavy) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(hcount, (unsigned int)__popcll(m));
+        base = __shfl(base, leader);
+        hlist[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    }
+}
+
+struct HRes {            // outcome of one mate-pair task, handed from the computing lane to lane 0
+    cmc::MM r1, r2;
+    int32_t row;
+    int32_t pair_type;
+    uint8_t ok, is_left, pad[2];
+};
+struct HeavyLds {
+    CM_L uint8_t *codes;     // pairing predicate per (i, j), i-major          [900]
+    CM_L uint16_t *list;     // accepted (i, j) in order                        [900]
+    CM_L int *fe, *re;       // exon interval of each chain's first fragment    [32] + [32]
+    CM_L HRes *res;          // [64]
+};
+
+__device__ inline int nth_set_bit(uint32_t m, int k) {
+    for (int x = 0; x < k; ++x) m &= m - 1;
+    return __ffs((int)m) - 1;
+}
+template <class T> __device__ inline T wave_min(T v) {
+    for (int o = 32; o >= 1; o >>= 1) { const T u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+// process_mates (src/filter.cpp:244-395) for one pair, executed by one wave.  `mr` is authoritative on
+// lane 0; mr.type is kept in sync on every lane (it is the saved_type of the pairing predicate).
+__device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainSet &fwd, const cmc::Read &frd, const cmc::ChainSet &bwd,
+                          const cmc::Read &brd, cm_mapped_read &mr, bool r1_forward, cmc::g_err err, const HeavyLds &H, int lane) {
+    const int kmer = c.P.kmer;
+    const int saved_type = mr.type;
+    const cmc::Ext ext(c, sm);
+    uint32_t tids[cmc::MAX_TID];
+    if (lane < fwd.n) H.fe[lane] = cmc::overlap(c, fwd.ch[lane].rpos[0]);
+    if (lane >= 32 && lane - 32 < bwd.n) H.re[lane - 32] = cmc::overlap(c, bwd.ch[lane - 32].rpos[0]);
+    __syncthreads();
+    const int T = fwd.n * bwd.n;
+    uint32_t fp = 0, bp = 0;
+    for (int idx = lane; idx < T; idx += 64) {
+        const int i = idx / bwd.n, j = idx - i * bwd.n;
+        const cmc::CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+        const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type, tids, err);
+        H.codes[idx] = (uint8_t)code;
+        if (code) {
+            fp |= 1u << i;
+            bp |= 1u << j;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        fp |= __shfl_xor(fp, o);
+        bp |= __shfl_xor(bp, o);
+    }
+    __syncthreads();
+    int ntask = 0;
+    for (int base = 0; base < T; base += 64) {
+        const int idx = base + lane;
+        const uint32_t code = idx < T ? H.codes[idx] : 0u;
+        const unsigned long long m = __ballot(code != 0);
+        if (code) H.list[ntask + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+        ntask += __popcll(m);
+    }
+    __syncthreads();
+    int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN, g1 = 0, g2 = 0;          // meaningful on lane 0
+    for (int b0 = 0; b0 < ntask; b0 += 64) {
+        const int x = b0 + lane;
+        if (x < ntask) {
+            const int idx = H.list[x];
+            const int i = idx / bwd.n, j = idx - i * bwd.n;
+            const uint32_t code = H.codes[idx];
+            const int n_tid = (code == 1) ? cmc::common_tids(c, H.fe[i], H.re[j], tids, err) : 0;
+            const cmc::CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+            cmc::MM r1, r2;
+            bool il, ok;
+            int row;
+            cmc::extend_task(c, ext, F, R, tids, n_tid, frd, brd, r1, r2, il, ok, row);
+            H.res[lane].r1 = r1;
+            H.res[lane].r2 = r2;
+            H.res[lane].row = row;
+            H.res[lane].pair_type = (int)code - 1;
+            H.res[lane].ok = ok;
+            H.res[lane].is_left = il;
+        }
+        __syncthreads();
+        int early = 0;
+        if (lane == 0) {
+            const int cnt = (ntask - b0 < 64) ? ntask - b0 : 64;
+            for (int y = 0; y < cnt; ++y) {
+                const cmc::MM r1 = H.res[y].r1, r2 = H.res[y].r2;
+                if (cmc::fold_task(c, r1, r2, H.res[y].is_left != 0, H.res[y].ok != 0, H.res[y].row, H.res[y].pair_type, r1_forward, mr)) {
+                    early = 1;
+                    break;
+                }
+                min_ret1 = r1.type < min_ret1 ? r1.type : min_ret1;
+                min_ret2 = r2.type < min_ret2 ? r2.type : min_ret2;
+                g1 = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
+                g2 = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
+            }
+        }
+        early = __shfl(early, 0);
+        __syncthreads();
+        if (early) return CM_CONCRD;
+    }
+    mr.type = __shfl(mr.type, 0);
+    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return mr.type;
+    min_ret1 = __shfl(min_ret1, 0);
+    min_ret2 = __shfl(min_ret2, 0);
+    g1 = __shfl(g1, 0);
+    g2 = __shfl(g2, 0);
+    // unpaired-chain extensions: forward chains on lanes 0..31, backward chains on lanes 32..63.  The
+    // reference reuses one MatchedMate for all chains of a side, so only the first chain's exon lookups
+    // ever happen (stale looked_up_* flags, filter.cpp:356-385): lane 0 / lane 32 compute the genic flag.
+    const uint32_t fun = ~fp & (fwd.n >= 32 ? 0xffffffffu : ((1u << fwd.n) - 1u));
+    const uint32_t bun = ~bp & (bwd.n >= 32 ? 0xffffffffu : ((1u << bwd.n) - 1u));
+    const bool do_f = min_ret1 != CM_CONCRD && fun != 0, do_b = min_ret2 != CM_CONCRD && bun != 0;
+    int ex = 99, genic = 0;
+    {
+        const bool back = lane >= 32;
+        const int k = back ? lane - 32 : lane;
+        const uint32_t un = back ? bun : fun;
+        if ((back ? do_b : do_f) && k < __popc(un)) {
+            const int ci = nth_set_bit(un, k);
+            const cmc::CH ch{(back ? bwd.ch : fwd.ch) + ci, kmer};
+            cmc::MM m = cmc::mm_init(c);
+            ex = ext.chain_both_sides(ch, back ? brd : frd, m, back ? -1 : 1);
+            if (k == 0) {
+                cmc::overlap_to_spos(c, m);
+                cmc::overlap_to_epos(c, m);
+                genic = (m.exons_spos >= 0) || (m.exons_epos >= 0);
+            }
+        }
+    }
+    const int exf = wave_min(lane < 32 ? ex : 99), exb = wave_min(lane >= 32 ? ex : 99);
+    const int gf = __shfl(genic, 0), gb = __shfl(genic, 32);
+    if (do_f) {
+        min_ret1 = exf < min_ret1 ? exf : min_ret1;
+        g1 = gf;
+    }
+    if (do_b) {
+        min_ret2 = exb < min_ret2 ? exb : min_ret2;
+        g2 = gb;
+    }
+    cmc::mr_update_type(mr, cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0));
+    return mr.type;
+}
+
+__global__ void __launch_bounds__(BLK_PAIR) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
+                                                         const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
+                                                         uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
+                                                         int str_cap) {
+    extern __shared__ uint32_t lds_words[];
+    const int lane = threadIdx.x;
+    CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
+    CM_L uint8_t *lane_base = base + 4 * lane;
+#if defined(CM_DIAG)
+    cmc::Tick tick{};
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err, &tick};
+#else
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
+#endif
+    CM_L uint8_t *q = base + 2 * str_cap * BLK_PAIR;
+    HeavyLds H;
+    H.res = (CM_L HRes *)q;
+    q += ((sizeof(HRes) * 64 + 15) / 16) * 16;
+    H.fe = (CM_L int *)q;
+    H.re = H.fe + 32;
+    q += 64 * sizeof(int);
+    H.list = (CM_L uint16_t *)q;
+    q += 912 * sizeof(uint16_t);
+    H.codes = q;
+    const Core c = cmc::to_core(kc);
+    const unsigned int n_heavy = *hcount;
+    for (unsigned int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const uint32_t t = hlist[h];
+        const uint64_t p = pair0 + t;
+        const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
+        const int len1 = (int)(a1 - a0), len2 = (int)(b1 - b0);
+        cmc::ChainSet sets[4];
+        int hh[4];
+        for (int x = 0; x < 4; ++x) {
+            const uint64_t r = (uint64_t)t * 4 + x;
+            sets[x].ch = (cmc::g_chain)(chains + r * CM_BESTCHAINLIM);
+            sets[x].n = nchain[r];
+            hh[x] = high[r];
+        }
+        cm_mapped_read mr = state[p];
+        int st = -1;
+        const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
+        if (n1 + n2 <= 0) {             // unreachable for a pair classified heavy; kept for completeness
+            st = ((hh[0] + hh[1] > 0) && (hh[2] + hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
+            cmc::mr_update_type(mr, st);
+        } else if (n1 <= 0 || n2 <= 0) {
+            st = CM_OEANCH;
+            cmc::mr_update_type(mr, st);
+        } else {
+            const float fc1 = sets[0].n > 0 ? sets[0].ch[0].score : 0.f, bc1 = sets[1].n > 0 ? sets[1].ch[0].score : 0.f;
+            const float fc2 = sets[2].n > 0 ? sets[2].ch[0].score : 0.f, bc2 = sets[3].n > 0 ? sets[3].ch[0].score : 0.f;
+            const float lhs = fc1 + bc2, rhs = fc2 + bc1;
+            const cmc::g_u8 s1 = (cmc::g_u8)(rd.seq1 + a0), s2 = (cmc::g_u8)(rd.seq2 + b0);
+            const cmc::Read r1f{s1, len1, 0}, r1b{s1, len1, 1}, r2f{s2, len2, 0}, r2b{s2, len2, 1};
+            const bool first = lhs >= rhs;
+            for (int attempt = 0; attempt < 2 && st < 0; ++attempt) {
+                int a;
+                if ((attempt == 0) == first) a = mates_wave(c, sm, sets[0], r1f, sets[3], r2b, mr, true, (cmc::g_err)err, H, lane);
+                else a = mates_wave(c, sm, sets[2], r2f, sets[1], r1b, mr, false, (cmc::g_err)err, H, lane);
+                if (c.P.scan_level == 0 && a == CM_CONCRD) st = CM_CONCRD;
+                __syncthreads();
+            }
+            if (st < 0) st = __shfl(mr.type, 0);
+        }
+        if (lane == 0) {
+            uint8_t act = 1;
+            cmc::finish_round(c, st, is_last, len1, len2, mr, act);
+            state[p] = mr;
+            active[p] = act;
+            cat[p] = st;
+            atomicAdd(&counters[3], 1ull);
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(BLK) k_collect(const uint8_t *active, const cm_mapped_read *state, uint64_t n, unsigned long long cap,
@@ -266,6 +529,9 @@ struct cm_ctx {
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
+    uint8_t *d_heavy_flag = nullptr;
+    uint32_t *d_hlist = nullptr;
+    unsigned int *d_hcount = nullptr;
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -321,7 +587,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_heavy_flag); dfree(c->d_hlist); dfree(c->d_hcount);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -647,9 +913,17 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_heavy_flag, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hcount, sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_lane_clk, n * 8));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_lane_clk, 0, n * 8, ctx->stream));
+#if defined(CM_DIAG)
+        const size_t clk_words = 16;
+#else
+        const size_t clk_words = 1;
+#endif
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_lane_clk, n * 8 * clk_words));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_lane_clk, 0, n * 8 * clk_words, ctx->stream));
     }
     unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
     if (pool < (256ull << 20)) pool = 256ull << 20;
@@ -677,9 +951,17 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
             const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
+            const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_hcount, 0, sizeof(unsigned int), ctx->stream));
+            hipLaunchKernelGGL(k_classify, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_heavy_flag,
+                               ctx->d_hlist, ctx->d_hcount);
             hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
                                ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
-                               str_cap, ctx->d_lane_clk);
+                               str_cap, ctx->d_lane_clk, ctx->d_heavy_flag);
+            const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
+            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_hcount,
+                               ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
+                               ctx->d_counters, str_cap);
             ++ctx->launches[2];
             HIPCHK(ctx, hipGetLastError());
         }
@@ -814,7 +1096,11 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 /* diagnostic: per-pair k_pair lane time in 100 MHz ticks (only when CM_LANE_CLK was set at upload) */
 int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) {
     if (!ctx || !out || !ctx->d_lane_clk) return CM_EINVAL;
+#if defined(CM_DIAG)
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8 * 16, hipMemcpyDeviceToHost));
+#else
     HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8, hipMemcpyDeviceToHost));
+#endif
     return CM_OK;
 }
 

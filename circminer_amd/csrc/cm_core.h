@@ -871,72 +871,88 @@ CM_HD CM_NOINLINE int local_alignment_sc_impl(const Core &c, const LBuf &s, int 
     return best.ed;
 }
 
+struct XdropW3 {
+    int d[9];
+    int pre_optimum, cur_optimum, lb, ub, pre_ub, on_s, on_t, best_score;
+};
+// one anti-diagonal k with k & 1 == PAR (so every slot index below is a compile-time constant);
+// returns false when the reference's loop breaks
+template <int PAR>
+CM_HD inline bool xdrop_w3_step(XdropW3 &x, const LBuf &s, int n, const LBuf &t, int m, int k, int wcap) {
+    constexpr int W = 3;
+    constexpr int q0 = PAR ? 1 : 2;
+    int new_ub = -1;
+    CM_STAT(4, x.ub - x.lb + 1);
+    const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot (k + q0 - W - 1 is even)
+    int sb = i0 - 1;                             // bases: s[i0-1+r], t[k-i0-1-r] for r = 0..3
+    sb = sb < 0 ? 0 : (sb > wcap ? wcap : sb);
+    const uint64_t sw = s.window(sb);
+    int tb = k - i0 - 1 - W;
+    tb = tb < 0 ? 0 : (tb > wcap ? wcap : tb);
+    const uint64_t tw = t.window(tb);
+    const int lb = x.lb, ub = x.ub, pre = x.pre_optimum;
+#pragma unroll
+    for (int r = 0; r <= W; ++r) {
+        constexpr int QMAX = 2 * W + 1;
+        const int q = q0 + 2 * r;
+        if (q > QMAX) continue;                  // the even class has only W slots
+        const int i = i0 + r, j = k - i;
+        const bool valid = (i >= lb) && (i <= ub);
+        const int so = (i - 1) - sb, to = (j - 1) - tb;      // 0..4 whenever the cell is valid
+        const uint32_t sc_ch = (uint32_t)(sw >> (8 * (so & 7))) & 0xFFu, tc_ch = (uint32_t)(tw >> (8 * (to & 7))) & 0xFFu;
+        const int sub = (sc_ch == tc_ch) ? SC_MAT : SC_MIS;
+        const int nb = x.d[q - 1] > x.d[q + 1] ? x.d[q - 1] : x.d[q + 1];
+        int v = x.d[q] + sub;
+        v = v > nb + SC_IND ? v : nb + SC_IND;
+        const bool take = valid && (v >= x.cur_optimum);
+        x.cur_optimum = take ? v : x.cur_optimum;
+        x.on_s = take ? i : x.on_s;
+        x.on_t = take ? j : x.on_t;
+        x.best_score = take ? v : x.best_score;
+        v = (v + SC_XD < pre) ? -DPTINF : v;
+        new_ub = (valid && v > -DPTINF) ? i : new_ub;
+        const bool bnd = (k <= W) && (q == k + W + 1 || q == W + 1 - k);     // boundary cells (k,0), (0,k)
+        x.d[q] = valid ? v : (bnd ? k * SC_IND : -DPTINF);
+    }
+    const int lb_t = k - x.lb;
+    if (lb_t == m || (k > W && ((k - W) % 2 == 0))) ++x.lb;
+    if (x.ub < n && (k <= W || (k > W && ((k - W) % 2 == 1)))) ++x.ub;
+    if ((x.pre_ub == -1 && new_ub == -1) || x.lb > x.ub) return false;
+    x.pre_ub = new_ub;
+    x.pre_optimum = cmax(x.pre_optimum, x.cur_optimum);
+    return true;
+}
 // Band-3 specialisation of the X-drop DP (the default bandWidth, >85 % of all DP cells).
 // Same recurrence, evaluation order and pruning as local_alignment_sc_impl, restructured for a GPU lane:
 //  * one register per slot, updated in place: anti-diagonal k only owns the slots q == k (mod 2), so
 //    d[q] still holds (k-2, q) when (k, q) is computed and d[q +- 1] hold anti-diagonal k-1;
+//  * the loop is unrolled by two anti-diagonals so the slot class of each half is static;
 //  * branch-free cells (selects), at most 4 per anti-diagonal instead of a 9-slot loop;
 //  * the 4 reference and 4 read bases an anti-diagonal needs come from one 5-byte LDS window each.
 CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
     constexpr int W = 3;
-    int d[2 * W + 3];
-    int on_s = 0, on_t = 0, best_score = 0;
+    XdropW3 x;
+    x.on_s = x.on_t = x.best_score = 0;
     if (m > 0 && n > 0) {
 #pragma unroll
-        for (int q = 0; q < 2 * W + 3; ++q) d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
-        int pre_optimum = 0, cur_optimum = 0;
-        int lb = 1, ub = 1, pre_ub = 0;
+        for (int q = 0; q < 2 * W + 3; ++q) x.d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
+        x.pre_optimum = x.cur_optimum = 0;
+        x.lb = x.ub = 1;
+        x.pre_ub = 0;
         const int wcap = (s.cap < t.cap ? s.cap : t.cap) - 8;
-        for (int k = 2; k <= m + n; ++k) {
-            int new_ub = -1;
-            CM_STAT(4, ub - lb + 1);
-            const int par = k & 1;                       // slots q == k (mod 2) live on this anti-diagonal (W odd)
-            const int q0 = par ? 1 : 2;
-            const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot (exact: k + q0 - W - 1 is even)
-            // bases: s[i0-1+r], t[k-i0-1-r] for r = 0..3
-            int sb = i0 - 1;
-            sb = sb < 0 ? 0 : (sb > wcap ? wcap : sb);
-            const uint64_t sw = s.window(sb);
-            const int ttop = k - i0 - 1;
-            int tb = ttop - W;
-            tb = tb < 0 ? 0 : (tb > wcap ? wcap : tb);
-            const uint64_t tw = t.window(tb);
-#pragma unroll
-            for (int r = 0; r <= W; ++r) {
-                const int q = q0 + 2 * r;
-                if (q > 2 * W + 1) continue;             // static: the even class has only W slots
-                const int i = i0 + r, j = k - i;
-                const bool valid = (i >= lb) && (i <= ub);
-                const int so = (i - 1) - sb, to = (j - 1) - tb;      // 0..4 whenever the cell is valid
-                const uint32_t sc_ch = (uint32_t)(sw >> (8 * (so & 7))) & 0xFFu, tc_ch = (uint32_t)(tw >> (8 * (to & 7))) & 0xFFu;
-                const int sub = (sc_ch == tc_ch) ? SC_MAT : SC_MIS;
-                const int nb = d[q - 1] > d[q + 1] ? d[q - 1] : d[q + 1];
-                int v = d[q] + sub;
-                v = v > nb + SC_IND ? v : nb + SC_IND;
-                const bool take = valid && (v >= cur_optimum);
-                cur_optimum = take ? v : cur_optimum;
-                on_s = take ? i : on_s;
-                on_t = take ? j : on_t;
-                best_score = take ? v : best_score;
-                v = (v + SC_XD < pre_optimum) ? -DPTINF : v;
-                new_ub = (valid && v > -DPTINF) ? i : new_ub;
-                const bool bnd = (k <= W) && (q == k + W + 1 || q == W + 1 - k);     // boundary cells (k,0), (0,k)
-                d[q] = valid ? v : (bnd ? k * SC_IND : -DPTINF);
-            }
-            const int lb_t = k - lb;
-            if (lb_t == m || (k > W && ((k - W) % 2 == 0))) ++lb;
-            if (ub < n && (k <= W || (k > W && ((k - W) % 2 == 1)))) ++ub;
-            if ((pre_ub == -1 && new_ub == -1) || lb > ub) break;
-            pre_ub = new_ub;
-            pre_optimum = cmax(pre_optimum, cur_optimum);
+        const int kmax = m + n;
+        for (int k = 2; k <= kmax; k += 2) {
+            if (!xdrop_w3_step<0>(x, s, n, t, m, k, wcap)) break;
+            if (k + 1 > kmax) break;
+            if (!xdrop_w3_step<1>(x, s, n, t, m, k + 1, wcap)) break;
         }
     }
-    const int score = best_score;
+    const int score = x.best_score, on_s = x.on_s, on_t = x.on_t;
     const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
     Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, W + 1, 0};
     if (ed <= (uint32_t)c.P.max_ed) {
-        Cand x{(int)ed, m - on_t, on_t - on_s, score};
-        best = x;
+        Cand y{(int)ed, m - on_t, on_t - on_s, score};
+        best = y;
     }
     align_score = score;
     sc_len = best.sclen;

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
     high[r] = hh;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+__global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
                                                    int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
                                                    const uint8_t *heavy_flag) {
@@ -397,7 +397,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     return mr.type;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
+__global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
                                                          int str_cap) {
@@ -530,6 +530,9 @@ struct cm_ctx {
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
     uint8_t *d_heavy_flag = nullptr;
+    unsigned long long *d_collect_idx = nullptr;
+    cm_mapped_read *d_collect_st = nullptr;
+    uint64_t collect_cap = 0;
     uint32_t *d_hlist = nullptr;
     unsigned int *d_hcount = nullptr;
     uint8_t *d_pool = nullptr;
@@ -752,6 +755,8 @@ void cm_destroy(cm_ctx *ctx) {
         free_all(s.idx_allocs);
         free_all(s.ann_allocs);
     }
+    dfree(ctx->d_collect_idx);
+    dfree(ctx->d_collect_st);
     dfree(ctx->d_pool_cursor);
     dfree(ctx->d_err);
     dfree(ctx->d_counters);
@@ -993,13 +998,16 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     *out_n = 0;
     if (ctx->n_pairs == 0) return CM_OK;
-    unsigned long long *d_idx = nullptr;
-    cm_mapped_read *d_st = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_idx, (cap ? cap : 1) * sizeof(unsigned long long)));
-    if (hipMalloc((void **)&d_st, (cap ? cap : 1) * sizeof(cm_mapped_read)) != hipSuccess) {
-        (void)hipFree(d_idx);
-        return fail(ctx, CM_ENOMEM, "cm_collect_active: out of device memory");
+    if (cap > ctx->collect_cap) {                 // grow-only scratch, reused across calls
+        dfree(ctx->d_collect_idx);
+        dfree(ctx->d_collect_st);
+        ctx->collect_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_idx, cap * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_st, cap * sizeof(cm_mapped_read)));
+        ctx->collect_cap = cap;
     }
+    unsigned long long *d_idx = ctx->d_collect_idx;
+    cm_mapped_read *d_st = ctx->d_collect_st;
     // d_pool_cursor doubles as the append counter (no chain kernel is in flight at this point on the stream)
     (void)hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream);
     hipLaunchKernelGGL(k_collect, dim3((unsigned)((ctx->n_pairs + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, ctx->d_state, ctx->n_pairs,
@@ -1025,8 +1033,6 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
             out_state[i] = hs[ord[i]];
         }
     }
-    (void)hipFree(d_idx);
-    (void)hipFree(d_st);
     return rc;
 }
 

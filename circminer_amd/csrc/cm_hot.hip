@@ -544,8 +544,8 @@ struct cm_ctx {
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
-    double ms[4] = {0, 0, 0, 0};
-    uint64_t launches[4] = {0, 0, 0, 0};
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -952,22 +952,32 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
         if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
         {
-            Timer t(ctx, 2);
             // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
             const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
             const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
             HIPCHK(ctx, hipMemsetAsync(ctx->d_hcount, 0, sizeof(unsigned int), ctx->stream));
+            {
+            Timer t(ctx, 5);
             hipLaunchKernelGGL(k_classify, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_heavy_flag,
                                ctx->d_hlist, ctx->d_hcount);
+            ++ctx->launches[5];
+            }
+            {
+            Timer t(ctx, 2);
             hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
                                ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
                                str_cap, ctx->d_lane_clk, ctx->d_heavy_flag);
+            ++ctx->launches[2];
+            }
+            {
+            Timer t(ctx, 4);
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
             hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_hcount,
                                ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
                                ctx->d_counters, str_cap);
-            ++ctx->launches[2];
+            ++ctx->launches[4];
+            }
             HIPCHK(ctx, hipGetLastError());
         }
     }
@@ -1125,7 +1135,7 @@ int cm_prof_reset(cm_ctx *ctx) {
         (void)hipEventDestroy(r.b);
     }
     ctx->recs.clear();
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         ctx->ms[i] = 0;
         ctx->launches[i] = 0;
     }
@@ -1134,7 +1144,7 @@ int cm_prof_reset(cm_ctx *ctx) {
     return CM_OK;
 }
 
-int cm_prof_get(cm_ctx *ctx, double ms[4], uint64_t launches[4]) {
+int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) {
     if (!ctx || !ms || !launches) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1145,7 +1155,7 @@ int cm_prof_get(cm_ctx *ctx, double ms[4], uint64_t launches[4]) {
         (void)hipEventDestroy(r.b);
     }
     ctx->recs.clear();
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         ms[i] = ctx->ms[i];
         launches[i] = ctx->launches[i];
     }

@@ -285,8 +285,8 @@ class HotPath:
         self._chk(self.L.cm_prof_reset(self.h), "cm_prof_reset")
 
     def prof_get(self):
-        ms = (C.c_double * 4)()
-        n = (C.c_uint64 * 4)()
+        ms = (C.c_double * 8)()
+        n = (C.c_uint64 * 8)()
         self._chk(self.L.cm_prof_get(self.h, ms, n), "cm_prof_get")
         cnt = (C.c_uint64 * 4)()
         self._chk(self.L.cm_prof_counters(self.h, cnt), "cm_prof_counters")

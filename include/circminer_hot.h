@@ -213,11 +213,11 @@ int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt,
 int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nchain, int32_t *out_high);
 
 /* ---------------- timing hooks for bench.py (HIP events on the ctx stream) ---------------- */
-/* Milliseconds spent in each kernel class since the last cm_prof_reset():
- * [0]=seed_probe [1]=chain [2]=pair_extend_classify [3]=scan/other; and launch counts. */
+/* Milliseconds spent in each kernel class since the last cm_prof_reset(), and launch counts:
+ * [0]=k_seed [1]=k_chain [2]=k_pair (light pairs) [3]=k_scan_* [4]=k_pair_heavy [5]=k_classify [6..7]=0. */
 int cm_prof_enable(cm_ctx *ctx, int on);
 int cm_prof_reset(cm_ctx *ctx);
-int cm_prof_get(cm_ctx *ctx, double ms[4], uint64_t launches[4]);
+int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]);
 /* Algorithmic byte counters of SURVEY §8(d) accumulated by the kernels since cm_prof_reset():
  * [0]=probes [1]=binary-search touches [2]=hits consumed (cnt<=seedLim) [3]=pair-rounds. */
 int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]);

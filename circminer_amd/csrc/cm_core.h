@@ -263,6 +263,7 @@ CM_HD inline uint32_t iv_nseg(const AnnotV &A, int iv) { return A.iv_seg_off[iv 
 CM_HD inline uint32_t iv_segid(const AnnotV &A, int iv, uint32_t i) { return A.iv_seg[A.iv_seg_off[iv] + i]; }
 
 CM_HD inline int iv_find_ind(const AnnotV &A, uint32_t pos, int &ind) {   // interval_tree_impl.h:136-175
+    CM_STAT(10, 1);
     ind = -1;
     if (pos < A.iv_spos[0]) return -1;
     int beg = 0, end = (int)A.n_iv;
@@ -644,6 +645,7 @@ CM_HD inline void load_codes16(const SV &v, int w0, uint8_t other, uint32_t q[4]
 }
 #endif
 CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
+    CM_STAT(8, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
     CM_L uint32_t *dw = (CM_L uint32_t *)d.b;
     const int nw = (n + 3) >> 2;
@@ -1006,6 +1008,7 @@ CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
     if (m >= 1 && n >= m && prefix_mismatches(s, t, m) == 0) {
+        CM_STAT(9, 1);
         sc_len = 0;
         indel = 0;
         align_score = m * SC_MAT;

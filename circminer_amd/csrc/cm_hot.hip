@@ -142,12 +142,13 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
                                                      const uint32_t *sstart, const uint32_t *scnt, const uint32_t *sraw,
                                                      const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
                                                      int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
-                                                     unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err) {
+                                                     unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err,
+                                                     uint16_t *resid) {
     const uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
     if (r >= r1) return;
     const Core c = cmc::to_core(kc);
     const uint64_t p = pair0 + (r >> 2);
-    int n = 0, hh = 0;
+    int n = 0, hh = 0, rs = 0;
     if (active[p]) {
         const int mate = (int)((r >> 1) & 1u);
         const uint64_t o0 = mate ? rd.off2[p] : rd.off1[p], o1 = mate ? rd.off2[p + 1] : rd.off1[p + 1];
@@ -166,15 +167,20 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
         w.pool_cursor = (CM_G unsigned long long *)pool_cursor;
         w.err = (cmc::g_err)err;
         n = cmc::chain_kbest(c, len, S, st, cn, w, (CM_G cm_chain *)(chains + (uint64_t)r * CM_BESTCHAINLIM));
+        if (n > 0) {          // bases of the best chain left to extend (work proxy used by the pair-stage ordering)
+            const cm_chain &b = chains[(uint64_t)r * CM_BESTCHAINLIM];
+            rs = b.qpos[0] + (len - (b.qpos[b.chain_len - 1] + c.P.kmer));
+        }
     }
     nchain[r] = n;
     high[r] = hh;
+    resid[r] = (uint16_t)(rs < 0 ? 0 : rs);
 }
 
 __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
                                                    int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
-                                                   const uint8_t *heavy_flag) {
+                                                   const uint32_t *perm, const unsigned int *n_light) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
@@ -188,14 +194,10 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
 #endif
     const Core c = cmc::to_core(kc);
-    const uint32_t t = blockIdx.x * BLK_PAIR + threadIdx.x;
-    if (t >= n_tile) return;
+    const uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x;
+    if (slot >= *n_light) return;       // light pairs only, in bucket order (heavy pairs: k_pair_heavy)
+    const uint32_t t = perm[slot];
     const uint64_t p = pair0 + t;
-    if (!active[p]) {
-        cat[p] = -1;
-        return;
-    }
-    if (heavy_flag[t]) return;          // mapped by k_pair_heavy, one pair per wave
     const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
     cmc::ChainSet sets[4];
     int hh[4];
@@ -235,23 +237,109 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
 // unpaired-chain extensions; lane 0 folds the outcomes in the reference's order).  Everything else
 // stays one pair per lane in k_pair.
 constexpr int HEAVY_COST = 8;
-__global__ void __launch_bounds__(BLK) k_classify(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, uint8_t *heavy_flag,
-                                                  uint32_t *hlist, unsigned int *hcount) {
-    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
-    bool heavy = false;
-    if (t < n_tile && active[pair0 + t]) {
-        const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
-        heavy = (a * d + c * b + a + b + c + d) > HEAVY_COST;
+constexpr int N_BUCKETS = 8;
+// class of a pair for the pair stage: -2 inactive, -1 heavy (k_pair_heavy), else a bucket of the total
+// residual length of its best chains (bases left to extend = a proxy of its DP work).  k_pair walks the
+// light pairs bucket by bucket so the lanes of a wave carry similar work; results do not depend on order.
+__device__ inline int pair_class(const uint16_t *resid4, const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t t) {
+    if (!active[pair0 + t]) return -2;
+    const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
+    if ((a * d + c * b + a + b + c + d) > HEAVY_COST) return -1;
+    const uint16_t *q = resid4 + 4 * (uint64_t)t;
+    const int resid = (int)q[0] + q[1] + q[2] + q[3];
+    return resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : resid < 400 ? 6 : 7;
+}
+// Atomic-free counting sort of the tile's pairs by class (bucket 0..7, heavy = class 8):
+// k_cls_count: class per pair + per-block class histogram;  k_cls_scan: one workgroup turns the
+// [class][block] histogram into exclusive bases (heaviest light bucket first) and totals;
+// k_cls_place: writes perm[] (light pairs) / hlist[] (heavy pairs) at base + rank inside the block.
+constexpr int CLS_T = 1024;            // threads per block = 16 waves
+constexpr int N_CLS = N_BUCKETS + 1;
+__device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], unsigned int &rank_in_wave, int lane, int wave) {
+    // wcnt[w][c] = number of lanes of wave w with class c; rank_in_wave = rank of this lane among its class in its wave
+    rank_in_wave = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLS; ++c) {
+        const unsigned long long m = __ballot(k == c);
+        if (lane == 0) wcnt[wave][c] = (unsigned int)__popcll(m);
+        if (k == c) rank_in_wave = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
     }
-    if (t < n_tile) heavy_flag[t] = heavy ? 1 : 0;
-    const unsigned long long m = __ballot(heavy);
-    if (heavy) {
-        const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(hcount, (unsigned int)__popcll(m));
-        base = __shfl(base, leader);
-        hlist[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+}
+__global__ void __launch_bounds__(CLS_T) k_cls_count(const uint16_t *resid, const int32_t *nchain, const uint8_t *active, uint64_t pair0,
+                                                     uint32_t n_tile, int8_t *cls, unsigned int *blk_cnt, uint32_t nb, int32_t *cat) {
+    __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
+    const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
+    int k = -2;
+    if (t < n_tile) {
+        k = pair_class(resid, nchain, active, pair0, t);
+        cls[t] = (int8_t)k;
+        if (k == -2) cat[pair0 + t] = -1;      // retired in an earlier round: not mapped
+    }
+    const int kk = k == -1 ? N_BUCKETS : k;     // heavy -> class 8, inactive stays -2
+    unsigned int r;
+    block_class_ranks(kk, wcnt, r, threadIdx.x & 63, threadIdx.x >> 6);
+    __syncthreads();
+    if (threadIdx.x < N_CLS) {
+        unsigned int tot = 0;
+        for (int w = 0; w < CLS_T / 64; ++w) tot += wcnt[w][threadIdx.x];
+        blk_cnt[(size_t)threadIdx.x * nb + blockIdx.x] = tot;
+    }
+}
+// ctr[c] = total of class c, ctr[9] = number of light pairs, ctr[10 + c] = base offset of class c in perm[]
+__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr) {
+    __shared__ unsigned int part[1024];
+    __shared__ unsigned int tot[N_CLS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (nb + 1023u) / 1024u;
+    for (int c = 0; c < N_CLS; ++c) {
+        unsigned int *row = blk_cnt + (size_t)c * nb;
+        const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
+        unsigned int s = 0;
+        for (uint32_t i = a; i < b; ++i) s += row[i];
+        part[t] = s;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const unsigned int v = (t >= d) ? part[t - d] : 0u;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        unsigned int run = t ? part[t - 1] : 0u;
+        for (uint32_t i = a; i < b; ++i) {
+            const unsigned int x = row[i];
+            row[i] = run;
+            run += x;
+        }
+        if (t == 1023) tot[c] = part[1023];
+        __syncthreads();
+    }
+    if (t == 0) {
+        unsigned int off = 0;
+        for (int c = N_BUCKETS - 1; c >= 0; --c) {      // heaviest light bucket first
+            ctr[10 + c] = off;
+            off += tot[c];
+        }
+        ctr[9] = off;
+        ctr[10 + N_BUCKETS] = 0;
+        for (int c = 0; c < N_CLS; ++c) ctr[c] = tot[c];
+    }
+}
+__global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t n_tile, const unsigned int *blk_base, uint32_t nb,
+                                                     const unsigned int *ctr, uint32_t *perm, uint32_t *hlist) {
+    __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
+    const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
+    const int k0 = t < n_tile ? (int)cls[t] : -2;
+    const int k = k0 == -1 ? N_BUCKETS : k0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int r;
+    block_class_ranks(k, wcnt, r, lane, wave);
+    __syncthreads();
+    if (k >= 0) {
+        unsigned int before = 0;
+        for (int w = 0; w < wave; ++w) before += wcnt[w][k];
+        const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
+        if (k == N_BUCKETS) hlist[pos] = t;
+        else perm[ctr[10 + k] + pos] = t;
     }
 }
 
@@ -529,12 +617,14 @@ struct cm_ctx {
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
-    uint8_t *d_heavy_flag = nullptr;
+    int8_t *d_cls = nullptr;
+    uint16_t *d_resid = nullptr;
+    uint32_t *d_perm = nullptr;
+    unsigned int *d_cls_ctr = nullptr, *d_blk_cnt = nullptr;
     unsigned long long *d_collect_idx = nullptr;
     cm_mapped_read *d_collect_st = nullptr;
     uint64_t collect_cap = 0;
     uint32_t *d_hlist = nullptr;
-    unsigned int *d_hcount = nullptr;
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -590,7 +680,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_heavy_flag); dfree(c->d_hlist); dfree(c->d_hcount);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -688,7 +778,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         const uint32_t n = rg.second - rg.first;
         hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
                            rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
-                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err);
+                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid);
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
     }
@@ -918,9 +1008,12 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_heavy_flag, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hcount, sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, 32 * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
         const size_t clk_words = 16;
@@ -956,24 +1049,27 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
             const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
             const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_hcount, 0, sizeof(unsigned int), ctx->stream));
             {
             Timer t(ctx, 5);
-            hipLaunchKernelGGL(k_classify, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_heavy_flag,
-                               ctx->d_hlist, ctx->d_hcount);
-            ++ctx->launches[5];
+            const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
+            hipLaunchKernelGGL(k_cls_count, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_cls,
+                               ctx->d_blk_cnt, nbk, ctx->d_cat);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr);
+            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
+                               ctx->d_hlist);
+            ctx->launches[5] += 3;
             }
             {
             Timer t(ctx, 2);
             hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
                                ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
-                               str_cap, ctx->d_lane_clk, ctx->d_heavy_flag);
+                               str_cap, ctx->d_lane_clk, ctx->d_perm, ctx->d_cls_ctr + 9);
             ++ctx->launches[2];
             }
             {
             Timer t(ctx, 4);
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
-            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_hcount,
+            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + 8,
                                ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
                                ctx->d_counters, str_cap);
             ++ctx->launches[4];

@@ -143,9 +143,17 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
                                                      const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
                                                      int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
                                                      unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err,
-                                                     uint16_t *resid) {
-    const uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
-    if (r >= r1) return;
+                                                     uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm, const int8_t *cls) {
+    // perm == null: index order, skipping problems of a heavy work class when cls != null;
+    // perm != null: the heavy problems, heaviest class first (perm[0 .. *n_perm))
+    uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
+    if (perm) {
+        if (r >= *n_perm) return;
+        r = perm[r];
+    } else {
+        if (r >= r1) return;
+        if (cls && cls[r] > 0) return;
+    }
     const Core c = cmc::to_core(kc);
     const uint64_t p = pair0 + (r >> 2);
     int n = 0, hh = 0, rs = 0;
@@ -265,19 +273,38 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
         if (k == c) rank_in_wave = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
     }
 }
-__global__ void __launch_bounds__(CLS_T) k_cls_count(const uint16_t *resid, const int32_t *nchain, const uint8_t *active, uint64_t pair0,
-                                                     uint32_t n_tile, int8_t *cls, unsigned int *blk_cnt, uint32_t nb, int32_t *cat) {
+__global__ void __launch_bounds__(BLK) k_pair_cls(const uint16_t *resid, const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile,
+                                                 int8_t *cls, int32_t *cat) {
+    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= n_tile) return;
+    const int k = pair_class(resid, nchain, active, pair0, t);
+    cls[t] = (int8_t)(k == -1 ? N_BUCKETS : k);       // heavy -> class 8, inactive stays -2
+    if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
+}
+// work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
+__global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high) {
+    const uint32_t r = blockIdx.x * BLK + threadIdx.x;
+    if (r >= n_prob) return;
+    unsigned long long w = 0, suffix = 0;
+    int hh = 0;
+    for (int s = S - 1; s >= 0; --s) {
+        const unsigned long long c = scnt[(uint64_t)r * S + s];
+        w += c * suffix;
+        suffix += c;
+        if (sraw[(uint64_t)r * S + s] > 0 && c == 0) ++hh;       // get_best_chains high_hits (also for problems k_chain skips)
+    }
+    high[r] = hh;
+    // class 0 = light (mapped in index order: coalesced seed/cell accesses matter more than balance there),
+    // 1..8 = heavy, mapped by a second launch in work order so that long DPs share waves
+    cls[r] = (int8_t)(suffix == 0 ? -2 : w <= 64 ? 0 : w <= 256 ? 1 : w <= 1024 ? 2 : w <= 4096 ? 3 : w <= 16384 ? 4 : w <= 65536 ? 5 : w <= 262144 ? 6
+                                       : w <= 1048576 ? 7 : 8);
+}
+__global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
-    int k = -2;
-    if (t < n_tile) {
-        k = pair_class(resid, nchain, active, pair0, t);
-        cls[t] = (int8_t)k;
-        if (k == -2) cat[pair0 + t] = -1;      // retired in an earlier round: not mapped
-    }
-    const int kk = k == -1 ? N_BUCKETS : k;     // heavy -> class 8, inactive stays -2
+    const int k = t < n ? (int)cls[t] : -2;
     unsigned int r;
-    block_class_ranks(kk, wcnt, r, threadIdx.x & 63, threadIdx.x >> 6);
+    block_class_ranks(k, wcnt, r, threadIdx.x & 63, threadIdx.x >> 6);
     __syncthreads();
     if (threadIdx.x < N_CLS) {
         unsigned int tot = 0;
@@ -286,7 +313,7 @@ __global__ void __launch_bounds__(CLS_T) k_cls_count(const uint16_t *resid, cons
     }
 }
 // ctr[c] = total of class c, ctr[9] = number of light pairs, ctr[10 + c] = base offset of class c in perm[]
-__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr) {
+__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int heavy_separate) {
     __shared__ unsigned int part[1024];
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
@@ -315,12 +342,15 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
     }
     if (t == 0) {
         unsigned int off = 0;
-        for (int c = N_BUCKETS - 1; c >= 0; --c) {      // heaviest light bucket first
+        if (!heavy_separate) {                          // class 8 leads the single permutation
+            ctr[10 + N_BUCKETS] = 0;
+            off = tot[N_BUCKETS];
+        } else ctr[10 + N_BUCKETS] = 0;                  // class 8 goes to its own list
+        for (int c = N_BUCKETS - 1; c >= 0; --c) {      // heaviest bucket first
             ctr[10 + c] = off;
             off += tot[c];
         }
         ctr[9] = off;
-        ctr[10 + N_BUCKETS] = 0;
         for (int c = 0; c < N_CLS; ++c) ctr[c] = tot[c];
     }
 }
@@ -328,8 +358,7 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
                                                      const unsigned int *ctr, uint32_t *perm, uint32_t *hlist) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
-    const int k0 = t < n_tile ? (int)cls[t] : -2;
-    const int k = k0 == -1 ? N_BUCKETS : k0;
+    const int k = t < n_tile ? (int)cls[t] : -2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int r;
     block_class_ranks(k, wcnt, r, lane, wave);
@@ -338,7 +367,7 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
         unsigned int before = 0;
         for (int w = 0; w < wave; ++w) before += wcnt[w][k];
         const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
-        if (k == N_BUCKETS) hlist[pos] = t;
+        if (k == N_BUCKETS && hlist) hlist[pos] = t;
         else perm[ctr[10 + k] + pos] = t;
     }
 }
@@ -561,15 +590,17 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
     }
 }
 
-__global__ void __launch_bounds__(BLK) k_collect(const uint8_t *active, const cm_mapped_read *state, uint64_t n, unsigned long long cap,
-                                                 unsigned long long *count, unsigned long long *out_idx, cm_mapped_read *out_state) {
+__global__ void __launch_bounds__(BLK) k_active_cls(const uint8_t *active, uint64_t n, int8_t *cls) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
-    if (i >= n || !active[i]) return;
-    const unsigned long long w = atomicAdd(count, 1ull);
-    if (w < cap) {
-        out_idx[w] = i;
-        out_state[w] = state[i];
-    }
+    if (i < n) cls[i] = active[i] ? 0 : -2;
+}
+__global__ void __launch_bounds__(BLK) k_gather_active(const uint32_t *perm, const unsigned int *count, unsigned long long cap, const cm_mapped_read *state,
+                                                       unsigned long long *out_idx, cm_mapped_read *out_state) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= *count || i >= cap) return;
+    const uint32_t p = perm[i];
+    out_idx[i] = p;
+    out_state[i] = state[p];
 }
 
 __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
@@ -617,13 +648,17 @@ struct cm_ctx {
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
-    int8_t *d_cls = nullptr;
+    int8_t *d_cls = nullptr, *d_cls4 = nullptr;
+    uint32_t *d_perm4 = nullptr;
     uint16_t *d_resid = nullptr;
     uint32_t *d_perm = nullptr;
     unsigned int *d_cls_ctr = nullptr, *d_blk_cnt = nullptr;
     unsigned long long *d_collect_idx = nullptr;
     cm_mapped_read *d_collect_st = nullptr;
     uint64_t collect_cap = 0;
+    int8_t *d_col_cls = nullptr;
+    uint32_t *d_col_perm = nullptr;
+    unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
     uint32_t *d_hlist = nullptr;
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
@@ -680,7 +715,8 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist);
+    dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -771,6 +807,20 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             a = b;
         }
     }
+    // Measured on MI355X (1 M pairs): splitting the heavy problems into their own work-ordered launch is slower
+    // (4.6 ms light + 12.3 ms heavy vs 8.2 ms together): the few very long DPs no longer overlap with the bulk.
+    // Kept behind this switch until the heavy problems get a wave-cooperative kernel.
+    const bool ordered = false && ranges.size() == 1;
+    if (ordered) {
+        Timer t(ctx, 5);
+        const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
+        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 0);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
+                           (uint32_t *)nullptr);
+        ctx->launches[5] += 4;
+    }
     for (auto &rg : ranges) {
         unsigned long long base = 0;
         if (rg.first != 0) base = ctx->h_celloff[rg.first];
@@ -778,7 +828,16 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         const uint32_t n = rg.second - rg.first;
         hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
                            rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
-                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid);
+                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid,
+                           (const uint32_t *)nullptr, (const unsigned int *)nullptr, ordered ? ctx->d_cls4 : (const int8_t *)nullptr);
+        if (ordered) {          // heavy problems: at most a few % of the tile; grid sized for the worst case, surplus blocks exit at once
+            const uint32_t hb = (n + BLK_CHAIN - 1) / BLK_CHAIN;
+            hipLaunchKernelGGL(k_chain, dim3(hb), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, 0u, n, S,
+                               ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes,
+                               ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + 10,
+                               (const int8_t *)nullptr);
+            ++ctx->launches[1];
+        }
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
     }
@@ -1009,11 +1068,13 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls4, (size_t)tile * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm4, (size_t)tile * 4 * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, 32 * sizeof(unsigned int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (tile / CLS_T + 2) * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
         const size_t clk_words = 16;
@@ -1052,12 +1113,13 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
-            hipLaunchKernelGGL(k_cls_count, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt, ctx->d_cls,
-                               ctx->d_blk_cnt, nbk, ctx->d_cat);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr);
+            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt,
+                               ctx->d_cls, ctx->d_cat);
+            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
                                ctx->d_hlist);
-            ctx->launches[5] += 3;
+            ctx->launches[5] += 4;
             }
             {
             Timer t(ctx, 2);
@@ -1103,8 +1165,17 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     if (!ctx || !out_n || (cap && (!out_idx || !out_state))) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     *out_n = 0;
-    if (ctx->n_pairs == 0) return CM_OK;
-    if (cap > ctx->collect_cap) {                 // grow-only scratch, reused across calls
+    const uint64_t n = ctx->n_pairs;
+    if (n == 0) return CM_OK;
+    if (n > 0xfffffff0ull) return fail(ctx, CM_ELIMIT, "cm_collect_active: too many pairs");
+    const uint32_t nbk = (uint32_t)((n + CLS_T - 1) / CLS_T);
+    if (!ctx->d_col_cls) {                        // scratch sized for the whole batch, allocated on first use
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_cls, n));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_perm, n * 4));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, 32 * sizeof(unsigned int)));
+    }
+    if (cap > ctx->collect_cap) {                 // grow-only output staging
         dfree(ctx->d_collect_idx);
         dfree(ctx->d_collect_st);
         ctx->collect_cap = 0;
@@ -1112,34 +1183,26 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_st, cap * sizeof(cm_mapped_read)));
         ctx->collect_cap = cap;
     }
-    unsigned long long *d_idx = ctx->d_collect_idx;
-    cm_mapped_read *d_st = ctx->d_collect_st;
-    // d_pool_cursor doubles as the append counter (no chain kernel is in flight at this point on the stream)
-    (void)hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream);
-    hipLaunchKernelGGL(k_collect, dim3((unsigned)((ctx->n_pairs + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, ctx->d_state, ctx->n_pairs,
-                       (unsigned long long)cap, ctx->d_pool_cursor, d_idx, d_st);
-    unsigned long long cnt = 0;
-    (void)hipMemcpyAsync(&cnt, ctx->d_pool_cursor, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    int rc = CM_OK;
-    if (e != hipSuccess) rc = fail(ctx, CM_EHIP, "cm_collect_active: %s", hipGetErrorString(e));
+    // stable compaction (block histogram -> scan -> place): ascending pair index, no atomics, no host sort
+    hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
+    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, 0);
+    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
+                       ctx->d_col_perm, (uint32_t *)nullptr);
+    if (cap)
+        hipLaunchKernelGGL(k_gather_active, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
+                           (unsigned long long)cap, ctx->d_state, ctx->d_collect_idx, ctx->d_collect_st);
+    unsigned int cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&cnt, ctx->d_col_ctr, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out_n = cnt;
-    if (rc == CM_OK && cnt > cap) rc = fail(ctx, CM_ELIMIT, "cm_collect_active: %llu active pairs > cap %llu", cnt, (unsigned long long)cap);
-    if (rc == CM_OK && cnt) {
-        std::vector<unsigned long long> hi(cnt);
-        std::vector<cm_mapped_read> hs(cnt);
-        (void)hipMemcpy(hi.data(), d_idx, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(hs.data(), d_st, cnt * sizeof(cm_mapped_read), hipMemcpyDeviceToHost);
-        // the append order of the atomic is arbitrary: return ascending pair index
-        std::vector<uint32_t> ord(cnt);
-        for (uint32_t i = 0; i < cnt; ++i) ord[i] = i;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return hi[a] < hi[b]; });
-        for (uint32_t i = 0; i < cnt; ++i) {
-            out_idx[i] = hi[ord[i]];
-            out_state[i] = hs[ord[i]];
-        }
+    if (cnt > cap) return fail(ctx, CM_ELIMIT, "cm_collect_active: %u active pairs > cap %llu", cnt, (unsigned long long)cap);
+    if (cnt) {
+        HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->d_collect_idx, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_state, ctx->d_collect_st, (size_t)cnt * sizeof(cm_mapped_read), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return rc;
+    return check_dev_err(ctx);
 }
 
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active) {

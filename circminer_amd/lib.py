@@ -246,12 +246,15 @@ class HotPath:
         self._chk(self.L.cm_reads_reset(self.h), "cm_reads_reset")
 
     def collect_active(self, cap=None):
+        """Active pairs (ascending index) and their carried state; host buffers are reused across calls."""
         cap = int(cap if cap is not None else max(self.n, 1))
-        idx = np.zeros(cap, np.uint64)
-        st = np.zeros(cap, dtype=MAPPED_DTYPE)
+        if getattr(self, "_col_cap", 0) < cap:
+            self._col_idx = np.empty(cap, np.uint64)
+            self._col_st = np.empty(cap, dtype=MAPPED_DTYPE)
+            self._col_cap = cap
         n = C.c_uint64(0)
-        self._chk(self.L.cm_collect_active(self.h, cap, idx.ctypes.data, st.ctypes.data, C.byref(n)), "cm_collect_active")
-        return idx[:n.value], st[:n.value]
+        self._chk(self.L.cm_collect_active(self.h, cap, self._col_idx.ctypes.data, self._col_st.ctypes.data, C.byref(n)), "cm_collect_active")
+        return self._col_idx[:n.value].copy(), self._col_st[:n.value].copy()
 
     def download(self):
         st = np.zeros(self.n, dtype=MAPPED_DTYPE)

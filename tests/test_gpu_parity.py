@@ -34,6 +34,9 @@ def _run_all_rounds(ds, P):
         assert (cat0 == cat1).all(), np.nonzero(cat0 != cat1)[0][:10]
         assert (act0 == act1).all()
         assert st0.tobytes() == st1.tobytes(), first_diff(st0, st1)
+        idx, stc = hp.collect_active()                 # stable device-side compaction of the re-queued pairs
+        want = np.nonzero(act1)[0]
+        assert (idx == want).all() and stc.tobytes() == st1[want].tobytes()
     hp.close()
     return st0
 

@@ -88,6 +88,8 @@ struct AnnotV {
     uint32_t n_chr;
     g_u32 chr_shift;
     g_i32 chr_id;
+    g_u32 iv_bucket;
+    uint32_t iv_bucket_shift, n_iv_bucket;
 };
 CM_HD inline IndexV to_dev(const cm_index_view &v) {
     IndexV d;
@@ -106,6 +108,7 @@ CM_HD inline AnnotV to_dev(const cm_annot_view &v) {
     d.gene_start = (g_u32)v.gene_start; d.gene_end = (g_u32)v.gene_end;
     d.near_border_bits = (g_u64)v.near_border_bits; d.intronic_bits = (g_u64)v.intronic_bits;
     d.chr_shift = (g_u32)v.chr_shift; d.chr_id = (g_i32)v.chr_id;
+    d.iv_bucket = (g_u32)v.iv_bucket; d.iv_bucket_shift = v.iv_bucket_shift; d.n_iv_bucket = v.n_iv_bucket;
     return d;
 }
 
@@ -266,9 +269,19 @@ CM_HD inline int iv_find_ind(const AnnotV &A, uint32_t pos, int &ind) {   // int
     CM_STAT(10, 1);
     ind = -1;
     if (pos < A.iv_spos[0]) return -1;
+    // FlatIntervalTree::search returns the number of intervals whose spos <= pos; narrow the range
+    // with the bucket table when the caller supplied one (same result, ~2 probes instead of log2 n)
     int beg = 0, end = (int)A.n_iv;
+    const uint32_t b = pos >> A.iv_bucket_shift;
+    if (A.iv_bucket && b + 1 < A.n_iv_bucket) {
+        beg = (int)A.iv_bucket[b];
+        end = (int)A.iv_bucket[b + 1];
+        if (beg > 0) --beg;                     // keep the invariant spos[beg] <= pos (spos[0] <= pos was checked)
+        if (end < (int)A.n_iv) ++end;
+        if (end <= beg) end = beg + 1;
+    }
     while (end - beg > 1) {
-        int mid = (beg + end) / 2;
+        const int mid = (beg + end) / 2;
         if (pos < A.iv_spos[mid]) end = mid;
         else beg = mid;
     }
@@ -1056,14 +1069,29 @@ CM_HD inline MM mm_init(const Core &c) {
 }
 CM_HD inline int mm_ed(const MM &m) { return m.left_ed + m.middle_ed + m.right_ed; }
 
-struct CH {            // read-only view of one stored chain
-    g_chain p;
+// One stored chain copied into private memory when a task starts: the pair logic reads fragment
+// fields dozens of times, and per-lane private arrays cost one coalesced access per wave where a
+// global field read costs 64 separate cache lines.
+struct CH {
+    uint32_t r[MAX_SEEDS];
+    int32_t q[MAX_SEEDS];
+    uint32_t n;
     int kmer;
-    CM_HD inline uint32_t len() const { return p->chain_len; }
-    CM_HD inline uint32_t rpos(uint32_t i) const { return p->rpos[i]; }
-    CM_HD inline int32_t qpos(uint32_t i) const { return p->qpos[i]; }
-    CM_HD inline uint32_t rend_excl() const { return p->rpos[p->chain_len - 1] + (uint32_t)kmer; }
-    CM_HD inline int32_t qend_excl() const { return p->qpos[p->chain_len - 1] + kmer; }
+    CM_HD CH(g_chain p, int k) : n(p->chain_len), kmer(k) {
+        for (uint32_t i = 0; i < (uint32_t)MAX_SEEDS; ++i) {
+            r[i] = i < n ? p->rpos[i] : 0u;
+            q[i] = i < n ? p->qpos[i] : 0;
+        }
+    }
+    CM_HD inline uint32_t len() const { return n; }
+    CM_HD inline uint32_t rpos(uint32_t i) const { return r[i]; }
+    CM_HD inline int32_t qpos(uint32_t i) const { return q[i]; }
+    CM_HD inline uint32_t rend_excl() const { return r[n - 1] + (uint32_t)kmer; }
+    CM_HD inline int32_t qend_excl() const { return q[n - 1] + kmer; }
+};
+struct CHEnds {         // just the reference span of a chain (pairing predicate)
+    uint32_t r0, rend;
+    CM_HD CHEnds(g_chain p, int k) : r0(p->rpos[0]), rend(p->rpos[p->chain_len - 1] + (uint32_t)k) {}
 };
 
 CM_HD inline void default_mr(const Core &c, cm_mapped_read &m) {
@@ -1793,8 +1821,8 @@ CM_HD inline bool fold_task(const Core &c, const MM &r1, const MM &r2, bool is_l
     return false;
 }
 // the pairing predicate of pair_chains for one (i, j): 0 = not paired, else pair type + 1
-CM_HD inline uint32_t pair_code(const Core &c, const CH &F, const CH &R, int fe_i, int re_j, int saved_type, uint32_t *tids, g_err err) {
-    const uint32_t fs = F.rpos(0), rs = R.rpos(0), fe_ = F.rend_excl(), re_ = R.rend_excl();
+CM_HD inline uint32_t pair_code(const Core &c, const CHEnds &F, const CHEnds &R, int fe_i, int re_j, int saved_type, uint32_t *tids, g_err err) {
+    const uint32_t fs = F.r0, rs = R.r0, fe_ = F.rend, re_ = R.rend;
     const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
     bool same_tr = false, same_gen = false;
     if (fe_i >= 0 && re_j >= 0) same_tr = common_tids(c, fe_i, re_j, tids, err) > 0;
@@ -1829,7 +1857,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     uint32_t tids[MAX_TID];
     for (int i = 0; i < fwd.n; ++i)
         for (int j = 0; j < bwd.n; ++j) {
-            const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+            const CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
             const uint32_t code = pair_code(c, F, R, fe[i], re[j], saved_type, tids, err);
             if (code) {
                 const int idx = i * CM_BESTCHAINLIM + j;

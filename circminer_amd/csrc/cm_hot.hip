@@ -409,7 +409,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     uint32_t fp = 0, bp = 0;
     for (int idx = lane; idx < T; idx += 64) {
         const int i = idx / bwd.n, j = idx - i * bwd.n;
-        const cmc::CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+        const cmc::CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
         const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type, tids, err);
         H.codes[idx] = (uint8_t)code;
         if (code) {
@@ -978,6 +978,13 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     if ((rc = up(ctx, al, av->intronic_bits, (size_t)(av->n_bits / 64), &A.intronic_bits))) return rc;
     if ((rc = up(ctx, al, av->chr_shift, (size_t)av->n_chr, &A.chr_shift))) return rc;
     if ((rc = up(ctx, al, av->chr_id, (size_t)av->n_chr, &A.chr_id))) return rc;
+    if (av->iv_bucket && av->n_iv_bucket >= 2) {
+        if ((rc = up(ctx, al, av->iv_bucket, (size_t)av->n_iv_bucket, &A.iv_bucket))) return rc;
+    } else {
+        A.iv_bucket = nullptr;
+        A.n_iv_bucket = 0;
+        A.iv_bucket_shift = 0;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     s.has_annot = true;
     return CM_OK;

@@ -347,6 +347,20 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
         A.n_chr = (uint32_t)cshift.size();
         A.chr_shift = dup(cshift);
         A.chr_id = dup(cid);
+        {   // bucketed index over the interval starts (query accelerator, see circminer_hot.h)
+            const uint32_t shift = 10;
+            const uint64_t nbk = (A.n_bits >> shift) + 2;
+            std::vector<uint32_t> bk(nbk);
+            size_t k = 0;
+            for (uint64_t b = 0; b < nbk; ++b) {
+                const uint64_t lim = b << shift;
+                while (k < iv.size() && (uint64_t)iv[k].spos < lim) ++k;
+                bk[b] = (uint32_t)k;
+            }
+            A.iv_bucket = dup(bk);
+            A.iv_bucket_shift = shift;
+            A.n_iv_bucket = (uint32_t)nbk;
+        }
     }
     return CM_OK;
 }
@@ -358,7 +372,7 @@ extern "C" void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs) {
         const void *ptrs[] = {A.iv_spos, A.iv_epos, A.iv_max_end, A.iv_min_end, A.iv_max_next_exon, A.iv_seg_off,
                               A.iv_seg, A.seg_start, A.seg_end, A.seg_next_exon_beg, A.seg_gene_id, A.seg_tid_off,
                               A.seg_tid, A.trans_start_ind, A.t2s_off, A.t2s, A.gene_start, A.gene_end,
-                              A.near_border_bits, A.intronic_bits, A.chr_shift, A.chr_id};
+                              A.near_border_bits, A.intronic_bits, A.chr_shift, A.chr_id, A.iv_bucket};
         for (const void *p : ptrs) free((void *)p);
         memset(&A, 0, sizeof(A));
     }

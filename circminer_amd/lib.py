@@ -50,7 +50,8 @@ class AnnotView(C.Structure):
                 ("n_trans", C.c_uint32), ("trans_start_ind", i32p), ("t2s_off", u32p), ("t2s", u8p),
                 ("n_gene", C.c_uint32), ("gene_start", u32p), ("gene_end", u32p),
                 ("n_bits", C.c_uint64), ("near_border_bits", u64p), ("intronic_bits", u64p),
-                ("n_chr", C.c_uint32), ("chr_shift", u32p), ("chr_id", i32p)]
+                ("n_chr", C.c_uint32), ("chr_shift", u32p), ("chr_id", i32p),
+                ("iv_bucket", u32p), ("iv_bucket_shift", C.c_uint32), ("n_iv_bucket", C.c_uint32)]
 
 
 class MappedRead(C.Structure):

@@ -114,6 +114,11 @@ typedef struct cm_annot_view {
     uint32_t n_chr;
     const uint32_t *chr_shift;   /* ContigLen.start_pos                                        */
     const int32_t *chr_id;       /* global chromosome ordinal (row of .index.info)             */
+    /* optional accelerator for FlatIntervalTree::search (interval_tree_impl.h:136-150): iv_bucket[b] =
+     * number of intervals with spos < (b << iv_bucket_shift), b = 0 .. n_iv_bucket-1 (covers n_bits + one
+     * extra bucket).  NULL = plain binary search.  Results are identical either way. */
+    const uint32_t *iv_bucket;
+    uint32_t iv_bucket_shift, n_iv_bucket;
 } cm_annot_view;
 
 /* ---- POD mirror of MatchedRead (src/common.h:311-352); carried between rounds through the

@@ -72,24 +72,42 @@ struct IndexV {
     g_u32 pos;
     uint64_t n_entries;
 };
-struct AnnotV {
-    uint32_t n_iv;
-    g_u32 iv_spos, iv_epos, iv_max_end, iv_min_end, iv_max_next_exon, iv_seg_off, iv_seg;
-    uint32_t n_seg;
-    g_u32 seg_start, seg_end, seg_next_exon_beg, seg_gene_id, seg_tid_off, seg_tid;
-    uint32_t n_trans;
-    g_i32 trans_start_ind;
-    g_u32 t2s_off;
-    g_u8 t2s;
-    uint32_t n_gene;
-    g_u32 gene_start, gene_end;
+// Device layout of the annotation: array-of-structs records (one 32-byte load serves the five to
+// seven parallel arrays of cm_annot_view that a query touches together; 12 pointers instead of 23).
+// cm_load_annotation (and the host emulation) repack the caller's SoA view with build_annot_aos().
+struct IvRec { uint32_t spos, epos, max_end, min_end, max_next_exon, seg_off, nseg, pad; };
+struct SegRec { uint32_t start, end, next_exon_beg, gene_id, tid_off, ntid, pad0, pad1; };
+struct TrRec { int32_t start_ind; uint32_t t2s_off, t2s_len, pad; };
+struct GeneRec { uint32_t start, end; };
+struct AnnotDev {            // plain-pointer form (kernel argument / host side)
+    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket, pad;
     uint64_t n_bits;
+    const IvRec *iv;
+    const uint32_t *iv_seg;
+    const SegRec *seg;
+    const uint32_t *seg_tid;
+    const TrRec *tr;
+    const uint8_t *t2s;
+    const GeneRec *gene;
+    const uint64_t *near_border_bits, *intronic_bits;
+    const uint32_t *chr_shift;
+    const int32_t *chr_id;
+    const uint32_t *iv_bucket;
+};
+struct AnnotV {              // the same with global-qualified pointers (device code)
+    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket;
+    uint64_t n_bits;
+    const CM_G IvRec *iv;
+    g_u32 iv_seg;
+    const CM_G SegRec *seg;
+    g_u32 seg_tid;
+    const CM_G TrRec *tr;
+    g_u8 t2s;
+    const CM_G GeneRec *gene;
     g_u64 near_border_bits, intronic_bits;
-    uint32_t n_chr;
     g_u32 chr_shift;
     g_i32 chr_id;
     g_u32 iv_bucket;
-    uint32_t iv_bucket_shift, n_iv_bucket;
 };
 CM_HD inline IndexV to_dev(const cm_index_view &v) {
     IndexV d;
@@ -97,18 +115,14 @@ CM_HD inline IndexV to_dev(const cm_index_view &v) {
     d.genome = (g_u8)v.genome; d.bucket_off = (g_u32)v.bucket_off; d.checksum = (g_u16)v.checksum; d.pos = (g_u32)v.pos;
     return d;
 }
-CM_HD inline AnnotV to_dev(const cm_annot_view &v) {
+CM_HD inline AnnotV to_dev(const AnnotDev &v) {
     AnnotV d;
-    d.n_iv = v.n_iv; d.n_seg = v.n_seg; d.n_trans = v.n_trans; d.n_gene = v.n_gene; d.n_bits = v.n_bits; d.n_chr = v.n_chr;
-    d.iv_spos = (g_u32)v.iv_spos; d.iv_epos = (g_u32)v.iv_epos; d.iv_max_end = (g_u32)v.iv_max_end; d.iv_min_end = (g_u32)v.iv_min_end;
-    d.iv_max_next_exon = (g_u32)v.iv_max_next_exon; d.iv_seg_off = (g_u32)v.iv_seg_off; d.iv_seg = (g_u32)v.iv_seg;
-    d.seg_start = (g_u32)v.seg_start; d.seg_end = (g_u32)v.seg_end; d.seg_next_exon_beg = (g_u32)v.seg_next_exon_beg;
-    d.seg_gene_id = (g_u32)v.seg_gene_id; d.seg_tid_off = (g_u32)v.seg_tid_off; d.seg_tid = (g_u32)v.seg_tid;
-    d.trans_start_ind = (g_i32)v.trans_start_ind; d.t2s_off = (g_u32)v.t2s_off; d.t2s = (g_u8)v.t2s;
-    d.gene_start = (g_u32)v.gene_start; d.gene_end = (g_u32)v.gene_end;
+    d.n_iv = v.n_iv; d.n_seg = v.n_seg; d.n_trans = v.n_trans; d.n_gene = v.n_gene; d.n_chr = v.n_chr;
+    d.iv_bucket_shift = v.iv_bucket_shift; d.n_iv_bucket = v.n_iv_bucket; d.n_bits = v.n_bits;
+    d.iv = (const CM_G IvRec *)v.iv; d.iv_seg = (g_u32)v.iv_seg; d.seg = (const CM_G SegRec *)v.seg; d.seg_tid = (g_u32)v.seg_tid;
+    d.tr = (const CM_G TrRec *)v.tr; d.t2s = (g_u8)v.t2s; d.gene = (const CM_G GeneRec *)v.gene;
     d.near_border_bits = (g_u64)v.near_border_bits; d.intronic_bits = (g_u64)v.intronic_bits;
-    d.chr_shift = (g_u32)v.chr_shift; d.chr_id = (g_i32)v.chr_id;
-    d.iv_bucket = (g_u32)v.iv_bucket; d.iv_bucket_shift = v.iv_bucket_shift; d.n_iv_bucket = v.n_iv_bucket;
+    d.chr_shift = (g_u32)v.chr_shift; d.chr_id = (g_i32)v.chr_id; d.iv_bucket = (g_u32)v.iv_bucket;
     return d;
 }
 
@@ -126,10 +140,10 @@ constexpr int MEMO_N = 8;                   // memoised exon alignments per exte
 
 enum { ERR_POOL = 1, ERR_TID = 2, ERR_SEEDS = 4, ERR_BAND = 8 };
 
-struct KCore {          // what the host passes as a kernel argument (plain C views, device pointers)
+struct KCore {          // what the host passes as a kernel argument (plain pointers to device memory)
     cm_params P;
     cm_index_view X;
-    cm_annot_view A;
+    AnnotDev A;
 };
 struct Core {
     cm_params P;
@@ -262,13 +276,13 @@ CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
 // annotation queries (A7)
 // ------------------------------------------------------------------------------------------
 CM_HD inline bool bit_at(g_u64 b, uint64_t n, uint64_t p) { return p < n && ((b[p >> 6] >> (p & 63)) & 1ull); }
-CM_HD inline uint32_t iv_nseg(const AnnotV &A, int iv) { return A.iv_seg_off[iv + 1] - A.iv_seg_off[iv]; }
-CM_HD inline uint32_t iv_segid(const AnnotV &A, int iv, uint32_t i) { return A.iv_seg[A.iv_seg_off[iv] + i]; }
+CM_HD inline uint32_t iv_nseg(const AnnotV &A, int iv) { return A.iv[iv].nseg; }
+CM_HD inline uint32_t iv_segid(const AnnotV &A, int iv, uint32_t i) { return A.iv_seg[A.iv[iv].seg_off + i]; }
 
 CM_HD inline int iv_find_ind(const AnnotV &A, uint32_t pos, int &ind) {   // interval_tree_impl.h:136-175
     CM_STAT(10, 1);
     ind = -1;
-    if (pos < A.iv_spos[0]) return -1;
+    if (pos < A.iv[0].spos) return -1;
     // FlatIntervalTree::search returns the number of intervals whose spos <= pos; narrow the range
     // with the bucket table when the caller supplied one (same result, ~2 probes instead of log2 n)
     int beg = 0, end = (int)A.n_iv;
@@ -282,11 +296,11 @@ CM_HD inline int iv_find_ind(const AnnotV &A, uint32_t pos, int &ind) {   // int
     }
     while (end - beg > 1) {
         const int mid = (beg + end) / 2;
-        if (pos < A.iv_spos[mid]) end = mid;
+        if (pos < A.iv[mid].spos) end = mid;
         else beg = mid;
     }
     ind = end - 1;
-    if (ind < 0 || A.iv_epos[ind] < pos) return -1;
+    if (ind < 0 || A.iv[ind].epos < pos) return -1;
     return ind;
 }
 CM_HD inline int overlap_ind(const Core &c, uint32_t loc, int &ind) {            // gene_annotation.cpp:555-568
@@ -305,27 +319,27 @@ CM_HD inline uint32_t upper_bound_lookup(const Core &c, uint32_t spos, uint32_t 
     if (ov < 0 || iv_nseg(A, ov) == 0) {
         ol = -1;
         int nx = it_ind + 1;
-        max_end = ((nx < 0 || nx >= (int)A.n_iv) ? 0u : A.iv_spos[nx]) - 1u;
+        max_end = ((nx < 0 || nx >= (int)A.n_iv) ? 0u : A.iv[nx].spos) - 1u;
         if (max_end < epos) return 0;
         return cmin(spos + rlen + (uint32_t)c.P.max_ed, max_end - mlen + 1);
     }
     ol = -1;
     uint32_t min_end = 1000000000u, max_next = 0;
-    if (epos > A.iv_epos[ov]) {
+    if (epos > A.iv[ov].epos) {
         const uint32_t n = iv_nseg(A, ov);
         for (uint32_t i = 0; i < n; ++i) {
             uint32_t s = iv_segid(A, ov, i);
-            uint32_t e = A.seg_end[s];
+            uint32_t e = A.seg[s].end;
             if (e >= epos) {
                 max_end = cmax(max_end, e);
                 min_end = cmin(min_end, e);
-                max_next = cmax(max_next, A.seg_next_exon_beg[s]);
+                max_next = cmax(max_next, A.seg[s].next_exon_beg);
             }
         }
     } else {
-        max_end = A.iv_max_end[ov];
-        min_end = A.iv_min_end[ov];
-        max_next = A.iv_max_next_exon[ov];
+        max_end = A.iv[ov].max_end;
+        min_end = A.iv[ov].min_end;
+        max_next = A.iv[ov].max_next_exon;
     }
     if (max_end > 0 && max_end >= epos) {
         ol = ov;
@@ -380,8 +394,8 @@ CM_HD inline bool check_junction(const Core &c, uint32_t s1, uint32_t s2, int ol
     const uint32_t n = iv_nseg(A, ol);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t s = iv_segid(A, ol, i);
-        const int e12end = (int)(A.seg_end[s] - e1);
-        const int beg2s2 = (int)(s2 - A.seg_next_exon_beg[s]);
+        const int e12end = (int)(A.seg[s].end - e1);
+        const int beg2s2 = (int)(s2 - A.seg[s].next_exon_beg);
         if (e12end >= 0 && e12end < read_dist && beg2s2 + kmer < 0) td2intron = (int)(s2 - e1 - 1);
         if (e12end < 0 || beg2s2 < 0) continue;
         trans_dist = e12end + beg2s2;
@@ -1209,32 +1223,32 @@ CM_HD inline int calc_tlen(const Core &c, const MM &sm, const MM &lm, int &intro
     const uint32_t ns = iv_nseg(A, sm.exons_epos);
     for (uint32_t i = 0; i < ns; ++i) {
         const uint32_t sg = iv_segid(A, sm.exons_epos, i);
-        for (uint32_t j = A.seg_tid_off[sg]; j < A.seg_tid_off[sg + 1]; ++j) {
+        for (uint32_t j = A.seg[sg].tid_off; j < A.seg[sg].tid_off + A.seg[sg].ntid; ++j) {
             const uint32_t tid = A.seg_tid[j];
-            const int start_ind = A.trans_start_ind[tid];
+            const int start_ind = A.tr[tid].start_ind;
             const uint32_t sti = (uint32_t)(sm.exon_ind_epos - start_ind);
             const uint32_t eti = (uint32_t)(lm.exon_ind_spos - start_ind);
-            const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-            const g_u8 t2s = A.t2s + A.t2s_off[tid];
+            const uint32_t tsz = A.tr[tid].t2s_len;
+            const g_u8 t2s = A.t2s + A.tr[tid].t2s_off;
             if (lm.exon_ind_spos < start_ind || eti >= tsz || t2s[eti] == 0) continue;
             int in = 0, tlen;
             if (sti == eti) {
                 tlen = (int)(lm.spos - sm.epos + 1);
             } else {
                 bool pre_zero = false;
-                tlen = (int)(A.iv_epos[sm.exons_epos] - sm.epos + 1);
+                tlen = (int)(A.iv[sm.exons_epos].epos - sm.epos + 1);
                 int it = sm.exon_ind_epos;
                 for (uint32_t k = sti + 1; k < eti; ++k) {
                     ++it;
                     if (t2s[k] != 0) {
-                        tlen += (int)(A.iv_epos[it] - A.iv_spos[it] + 1);
+                        tlen += (int)(A.iv[it].epos - A.iv[it].spos + 1);
                         pre_zero = false;
                     } else {
                         if (!pre_zero) ++in;
                         pre_zero = true;
                     }
                 }
-                tlen += (int)(lm.spos - A.iv_spos[lm.exons_spos] + 1);
+                tlen += (int)(lm.spos - A.iv[lm.exons_spos].spos + 1);
             }
             if (tlen < min_tlen) {
                 intron_num = in;
@@ -1248,8 +1262,8 @@ CM_HD inline bool same_gene_span(const Core &c, int iv, uint32_t s, uint32_t e) 
     const AnnotV &A = c.A;
     const uint32_t n = iv_nseg(A, iv);
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t g = A.seg_gene_id[iv_segid(A, iv, i)];
-        if (A.gene_start[g] <= s && e <= A.gene_end[g]) return true;
+        const uint32_t g = A.seg[iv_segid(A, iv, i)].gene_id;
+        if (A.gene[g].start <= s && e <= A.gene[g].end) return true;
     }
     return false;
 }
@@ -1258,7 +1272,7 @@ CM_HD inline bool share_gene(const Core &c, int a, int b) {
     const uint32_t na = iv_nseg(A, a), nb = iv_nseg(A, b);
     for (uint32_t i = 0; i < na; ++i)
         for (uint32_t j = 0; j < nb; ++j)
-            if (A.seg_gene_id[iv_segid(A, a, i)] == A.seg_gene_id[iv_segid(A, b, j)]) return true;
+            if (A.seg[iv_segid(A, a, i)].gene_id == A.seg[iv_segid(A, b, j)].gene_id) return true;
     return false;
 }
 // same_transcript + intersect_trans, utils.cpp:322-354; returns count (order of the first list)
@@ -1269,12 +1283,12 @@ CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, g_err e
     const uint32_t ns = iv_nseg(A, s), nr = iv_nseg(A, r);
     for (uint32_t i = 0; i < ns; ++i) {
         const uint32_t g = iv_segid(A, s, i);
-        for (uint32_t k = A.seg_tid_off[g]; k < A.seg_tid_off[g + 1]; ++k) {
+        for (uint32_t k = A.seg[g].tid_off; k < A.seg[g].tid_off + A.seg[g].ntid; ++k) {
             const uint32_t t1 = A.seg_tid[k];
             bool found = false;
             for (uint32_t j = 0; j < nr && !found; ++j) {
                 const uint32_t h = iv_segid(A, r, j);
-                for (uint32_t l = A.seg_tid_off[h]; l < A.seg_tid_off[h + 1]; ++l)
+                for (uint32_t l = A.seg[h].tid_off; l < A.seg[h].tid_off + A.seg[h].ntid; ++l)
                     if (A.seg_tid[l] == t1) { found = true; break; }
             }
             if (found) {
@@ -1300,7 +1314,7 @@ CM_HD inline bool concordant_explanation(const Core &c, const MM &sm, const MM &
         for (uint32_t i = 0; i < na; ++i)
             for (uint32_t j = 0; j < nb; ++j) {
                 const uint32_t x = iv_segid(A, sm.exons_spos, i), y = iv_segid(A, lm.exons_spos, j);
-                if (A.seg_start[x] == A.seg_start[y] && A.seg_end[x] == A.seg_end[y]) {
+                if (A.seg[x].start == A.seg[y].start && A.seg[x].end == A.seg[y].end) {
                     tlen = (int32_t)(lm.spos + lm.matched_len - sm.spos);
                     mr_update(c, mr, sm, lm, row, tlen, 0, on_cdna, tlen <= c.P.max_tlen ? good : CM_DISCRD, r1_sm);
                 }
@@ -1341,7 +1355,7 @@ CM_HD inline void bsj_tail(const Core &c, const MM &sm, const MM &lm, cm_mapped_
         }
         if (bit_at(A.intronic_bits, A.n_bits, sm.spos) && bit_at(A.intronic_bits, A.n_bits, lm.spos) && sm.exon_ind_spos >= 0 &&
             lm.exon_ind_epos >= 0 && sm.exon_ind_spos == lm.exon_ind_epos &&
-            (uint32_t)(sm.spos - A.iv_epos[sm.exon_ind_spos]) <= LARIAT2BEGTH)
+            (uint32_t)(sm.spos - A.iv[sm.exon_ind_spos].epos) <= LARIAT2BEGTH)
             mr_update(c, mr, sm, lm, row, tl, 0, false, type, r1_sm);
         return;
     }
@@ -1491,12 +1505,12 @@ struct Ext {
         AlignRes curr = ar_init(ub), exon_res = ar_init(ub);
         if (it_seg < 0) return;
         int covered = 0;
-        const int it_start = A.trans_start_ind[tid];
+        const int it_start = A.tr[tid].start_ind;
         const int rel_ind = it_ind - it_start;
-        const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-        const g_u8 t2s = A.t2s + A.t2s_off[tid];
+        const uint32_t tsz = A.tr[tid].t2s_len;
+        const g_u8 t2s = A.t2s + A.tr[tid].t2s_off;
         uint32_t rspos = pos;
-        int exon_len = (int)(A.iv_epos[it_seg] - pos);
+        int exon_len = (int)(A.iv[it_seg].epos - pos);
         int remain_ref_len = ref_len;
         int indel = 0;
         for (unsigned int i = (unsigned int)(rel_ind + 1); i < tsz; ++i) {
@@ -1513,11 +1527,11 @@ struct Ext {
                 remain_ref_len -= exon_len;
                 covered += exon_len + indel;
                 exon_len = 0;
-                rspos = A.iv_spos[(int)i + it_start] - 1;
+                rspos = A.iv[(int)i + it_start].spos - 1;
             }
             if (st != 0) {
                 const int iv = (int)i + it_start;
-                exon_len += (int)(A.iv_epos[iv] - A.iv_spos[iv] + 1);
+                exon_len += (int)(A.iv[iv].epos - A.iv[iv].spos + 1);
             }
         }
         if ((exon_len > 0) && (exon_len < qlen - covered) && (rspos + exon_len <= ub)) {
@@ -1540,10 +1554,10 @@ struct Ext {
         AlignRes curr = ar_init(lb), exon_res = ar_init(lb);
         if (it_seg < 0) return;
         int covered = 0;
-        const int it_start = A.trans_start_ind[tid];
+        const int it_start = A.tr[tid].start_ind;
         const int rel_ind = it_ind - it_start;
-        const uint32_t tsz = A.t2s_off[tid + 1] - A.t2s_off[tid];
-        const g_u8 t2s = A.t2s + A.t2s_off[tid];
+        const uint32_t tsz = A.tr[tid].t2s_len;
+        const g_u8 t2s = A.t2s + A.tr[tid].t2s_off;
         uint32_t lepos = pos;
         int exon_len = 0;
         int remain_ref_len = ref_len;
@@ -1554,11 +1568,11 @@ struct Ext {
             if (st != 0) {
                 const int iv = i + it_start;
                 if (first_seg) {
-                    exon_len = (int)(pos - A.iv_spos[iv]);
+                    exon_len = (int)(pos - A.iv[iv].spos);
                     first_seg = false;
                 } else {
-                    if (exon_len == 0) lepos = A.iv_epos[iv] + 1;
-                    exon_len += (int)(A.iv_epos[iv] - A.iv_spos[iv] + 1);
+                    if (exon_len == 0) lepos = A.iv[iv].epos + 1;
+                    exon_len += (int)(A.iv[iv].epos - A.iv[iv].spos + 1);
                 }
             }
             if (exon_len >= qlen - covered) break;

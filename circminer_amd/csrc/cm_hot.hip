@@ -20,6 +20,7 @@
 
 #include "circminer_hot.h"
 #include "cm_core.h"
+#include "cm_aos.h"
 
 using cmc::Core;
 using cmc::KCore;
@@ -617,7 +618,7 @@ __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, i
 struct Slot {
     bool loaded = false, has_annot = false;
     cm_index_view X{};
-    cm_annot_view A{};
+    cmc::AnnotDev A{};
     std::vector<void *> idx_allocs, ann_allocs;
 };
 
@@ -951,40 +952,30 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     Slot &s = ctx->slots[slot];
     free_all(s.ann_allocs);
     s.has_annot = false;
-    s.A = *av;
-    cm_annot_view &A = s.A;
+    cmc::AnnotAosHost aos;
+    cmc::build_annot_aos(*av, aos);
+    cmc::AnnotDev &A = s.A;
+    A = cmc::AnnotDev{};
+    A.n_iv = av->n_iv; A.n_seg = av->n_seg; A.n_trans = av->n_trans; A.n_gene = av->n_gene; A.n_chr = av->n_chr; A.n_bits = av->n_bits;
     int rc;
     auto &al = s.ann_allocs;
-    const size_t niv = av->n_iv, nseg = av->n_seg, nt = av->n_trans;
-    if ((rc = up(ctx, al, av->iv_spos, niv, &A.iv_spos))) return rc;
-    if ((rc = up(ctx, al, av->iv_epos, niv, &A.iv_epos))) return rc;
-    if ((rc = up(ctx, al, av->iv_max_end, niv, &A.iv_max_end))) return rc;
-    if ((rc = up(ctx, al, av->iv_min_end, niv, &A.iv_min_end))) return rc;
-    if ((rc = up(ctx, al, av->iv_max_next_exon, niv, &A.iv_max_next_exon))) return rc;
-    if ((rc = up(ctx, al, av->iv_seg_off, niv + 1, &A.iv_seg_off))) return rc;
-    if ((rc = up(ctx, al, av->iv_seg, (size_t)av->iv_seg_off[niv], &A.iv_seg))) return rc;
-    if ((rc = up(ctx, al, av->seg_start, nseg, &A.seg_start))) return rc;
-    if ((rc = up(ctx, al, av->seg_end, nseg, &A.seg_end))) return rc;
-    if ((rc = up(ctx, al, av->seg_next_exon_beg, nseg, &A.seg_next_exon_beg))) return rc;
-    if ((rc = up(ctx, al, av->seg_gene_id, nseg, &A.seg_gene_id))) return rc;
-    if ((rc = up(ctx, al, av->seg_tid_off, nseg + 1, &A.seg_tid_off))) return rc;
-    if ((rc = up(ctx, al, av->seg_tid, (size_t)av->seg_tid_off[nseg], &A.seg_tid))) return rc;
-    if ((rc = up(ctx, al, av->trans_start_ind, nt, &A.trans_start_ind))) return rc;
-    if ((rc = up(ctx, al, av->t2s_off, nt + 1, &A.t2s_off))) return rc;
-    if ((rc = up(ctx, al, av->t2s, (size_t)av->t2s_off[nt], &A.t2s))) return rc;
-    if ((rc = up(ctx, al, av->gene_start, (size_t)av->n_gene, &A.gene_start))) return rc;
-    if ((rc = up(ctx, al, av->gene_end, (size_t)av->n_gene, &A.gene_end))) return rc;
+    if ((rc = up(ctx, al, aos.iv.data(), aos.iv.size(), &A.iv))) return rc;
+    if ((rc = up(ctx, al, av->iv_seg, (size_t)av->iv_seg_off[av->n_iv], &A.iv_seg))) return rc;
+    if ((rc = up(ctx, al, aos.seg.data(), aos.seg.size(), &A.seg))) return rc;
+    if ((rc = up(ctx, al, av->seg_tid, (size_t)av->seg_tid_off[av->n_seg], &A.seg_tid))) return rc;
+    if ((rc = up(ctx, al, aos.tr.data(), aos.tr.size(), &A.tr))) return rc;
+    if ((rc = up(ctx, al, av->t2s, (size_t)av->t2s_off[av->n_trans], &A.t2s))) return rc;
+    if ((rc = up(ctx, al, aos.gene.data(), aos.gene.size(), &A.gene))) return rc;
     if ((rc = up(ctx, al, av->near_border_bits, (size_t)(av->n_bits / 64), &A.near_border_bits))) return rc;
     if ((rc = up(ctx, al, av->intronic_bits, (size_t)(av->n_bits / 64), &A.intronic_bits))) return rc;
     if ((rc = up(ctx, al, av->chr_shift, (size_t)av->n_chr, &A.chr_shift))) return rc;
     if ((rc = up(ctx, al, av->chr_id, (size_t)av->n_chr, &A.chr_id))) return rc;
     if (av->iv_bucket && av->n_iv_bucket >= 2) {
         if ((rc = up(ctx, al, av->iv_bucket, (size_t)av->n_iv_bucket, &A.iv_bucket))) return rc;
-    } else {
-        A.iv_bucket = nullptr;
-        A.n_iv_bucket = 0;
-        A.iv_bucket_shift = 0;
+        A.iv_bucket_shift = av->iv_bucket_shift;
+        A.n_iv_bucket = av->n_iv_bucket;
     }
+    // the staging copies are asynchronous: the host vectors must outlive them
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     s.has_annot = true;
     return CM_OK;

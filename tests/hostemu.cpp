@@ -11,6 +11,7 @@
 #include "circminer_hot.h"
 #define CM_STATS 1
 #include "cm_core.h"
+#include "cm_aos.h"
 extern "C" { unsigned long long cm_stats[16]; }
 
 using cmc::Core;
@@ -24,6 +25,7 @@ struct Emu {
     std::vector<cm_chain> chains;
     std::vector<int32_t> nchain, high;
     std::vector<uint8_t> pool;
+    cmc::AnnotAosHost aos;
     unsigned long long cursor = 0;
     int err = 0;
 };
@@ -117,7 +119,8 @@ int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_v
     Emu e;
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
-    e.core.A = cmc::to_dev(*A);
+    cmc::build_annot_aos(*A, e.aos);
+    e.core.A = cmc::to_dev(cmc::annot_dev_host(*A, e.aos));
     e.R = R;
     e.S = n_seeds_of(P, R);
     seed_all(e, nullptr);
@@ -134,7 +137,8 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
     Emu e;
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
-    e.core.A = cmc::to_dev(*A);
+    cmc::build_annot_aos(*A, e.aos);
+    e.core.A = cmc::to_dev(cmc::annot_dev_host(*A, e.aos));
     e.R = R;
     e.S = n_seeds_of(P, R);
     seed_all(e, active);

@@ -29,10 +29,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("CM_EXTRA_FLAGS", "").split()
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc, "-c", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", INC, "-I", CSRC,
+        cmd = [hipcc, "-c", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *extra, "-I", INC, "-I", CSRC,
                os.path.join(CSRC, s), "-o", o]
         if s.endswith(".hip"):
             cmd[1:1] = ["--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] if verbose else ["--offload-arch=gfx950"]

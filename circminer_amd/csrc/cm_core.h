@@ -47,9 +47,15 @@ extern "C" unsigned long long cm_stats[16];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CM_G __attribute__((address_space(1)))
 #define CM_L __attribute__((address_space(3)))
+#if defined(CM_STAGE_PRIVATE)
+#define CM_S __attribute__((address_space(5)))      // DP staging buffers in private (scratch) memory
+#else
+#define CM_S CM_L                                   // DP staging buffers in LDS, word-interleaved per lane
+#endif
 #else
 #define CM_G
 #define CM_L
+#define CM_S
 #endif
 
 namespace cmc {
@@ -606,18 +612,18 @@ CM_HD inline bool cand_less(const Cand &a, const Cand &b) {     // AlignCandid::
 // (the left-hand variants stage reversed views).  On the GPU the buffer is LDS, word-interleaved
 // across the 64 lanes of the wave (byte i of lane l lives in word (i/4)*64 + l), so concurrent
 // per-lane accesses fall in distinct banks; on the host build it is a plain array.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_STAGE_PRIVATE)
 constexpr int LSTRIDE = 64;
 #else
 constexpr int LSTRIDE = 1;
 #endif
 struct LBuf {
-    CM_L uint8_t *b;
+    CM_S uint8_t *b;
     int cap;
     CM_HD inline uint8_t get(int i) const { return b[(i >> 2) * (4 * LSTRIDE) + (i & 3)]; }
     CM_HD inline uint32_t word(int w) const {                 // staged bytes 4w .. 4w+3, little-endian
 #if defined(__HIP_DEVICE_COMPILE__)
-        return ((CM_L const uint32_t *)b)[w * LSTRIDE];
+        return ((CM_S const uint32_t *)b)[w * LSTRIDE];
 #else
         uint32_t x;
         __builtin_memcpy(&x, b + 4 * w, 4);
@@ -674,7 +680,7 @@ CM_HD inline void load_codes16(const SV &v, int w0, uint8_t other, uint32_t q[4]
 CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
     CM_STAT(8, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
-    CM_L uint32_t *dw = (CM_L uint32_t *)d.b;
+    CM_S uint32_t *dw = (CM_S uint32_t *)d.b;
     const int nw = (n + 3) >> 2;
     for (int w0 = 0; w0 < nw; w0 += 4) {
         uint32_t q[4];

@@ -32,6 +32,7 @@ constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (wo
 constexpr int BLK = 256;
 constexpr int BLK_CHAIN = 64;
 constexpr int BLK_PAIR = 64;
+constexpr int STAGE_WORDS = 80;                  // private staging: 320 chars per string (max_read_len 300 + band + slack)
 
 struct ReadsDev {
     const uint8_t *seq1, *seq2;
@@ -192,15 +193,23 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
                                                    const uint32_t *perm, const unsigned int *n_light) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
+#if defined(CM_STAGE_PRIVATE)
+    uint32_t stage_words[2 * STAGE_WORDS];
+    CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
+    str_cap = 4 * STAGE_WORDS;
+    const int str_stride = str_cap;
+#else
     extern __shared__ uint32_t lds_words[];
-    CM_L uint8_t *lane_base = (CM_L uint8_t *)lds_words + 4 * threadIdx.x;
+    CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
+    const int str_stride = str_cap * BLK_PAIR;
+#endif
 #if defined(CM_DIAG)
     cmc::Tick tick;
     for (int i = 0; i < 16; ++i) tick.acc[i] = 0;
     tick.last = wall_clock64();
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err, &tick};
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
     const Core c = cmc::to_core(kc);
     const uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x;
@@ -522,14 +531,24 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
-    CM_L uint8_t *lane_base = base + 4 * lane;
+#if defined(CM_STAGE_PRIVATE)
+    uint32_t stage_words[2 * STAGE_WORDS];
+    CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
+    const int lds_stage_bytes = 0;
+    str_cap = 4 * STAGE_WORDS;
+    const int str_stride = str_cap;
+#else
+    CM_S uint8_t *lane_base = base + 4 * lane;
+    const int lds_stage_bytes = 2 * str_cap * BLK_PAIR;
+    const int str_stride = str_cap * BLK_PAIR;
+#endif
 #if defined(CM_DIAG)
     cmc::Tick tick{};
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err, &tick};
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_cap * BLK_PAIR, str_cap}, (cmc::g_err)err};
+    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
-    CM_L uint8_t *q = base + 2 * str_cap * BLK_PAIR;
+    CM_L uint8_t *q = base + lds_stage_bytes;
     HeavyLds H;
     H.res = (CM_L HRes *)q;
     q += ((sizeof(HRes) * 64 + 15) / 16) * 16;
@@ -1106,7 +1125,11 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
         {
             // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
+#if defined(CM_STAGE_PRIVATE)
+            const size_t lds_bytes = 0;
+#else
             const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
+#endif
             const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
             {
             Timer t(ctx, 5);

@@ -100,3 +100,46 @@ def test_map_batch_wrapper_and_errors(ds_tiny):
     cat0 = op.map_round(P, ds_tiny.hi.views[0], ds_tiny.hi.annots[0], ds_tiny.batch, True, st0, act0)
     assert (cat0 == cat).all() and st0.tobytes() == st.tobytes()
     hp.close()
+
+
+def test_full_size_parity_chr21_1M(tmp_path_factory):
+    """BASELINE.json configs[1] at full size: chr21-like contig, 1 M pairs — every pair's state, category and
+    active flag bit-exact against the oracle (run on all host cores of the GPU box)."""
+    import os
+    import threading
+    from conftest import DataSet
+    ds = DataSet(tmp_path_factory.mktemp("chr21"), "chr21", 1_000_000, 21)
+    P = cl.default_params()
+    hp = cl.HotPath(P)
+    hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
+    hp.upload(ds.batch)
+    hp.map_round(0, True)
+    st1, cat1, act1 = hp.download()
+    n = ds.batch.n
+    st0, act0 = op.default_state(P, n)
+    cat0 = np.full(n, -1, np.int32)
+    T = max(1, min(os.cpu_count() or 1, 64))
+    L = op.load()
+    import ctypes as C
+
+    def work(a, b):
+        L.oracle_map_round(C.byref(P), C.byref(ds.hi.views[0]), C.byref(ds.hi.annots[0]), C.byref(ds.batch.c), 1, st0.ctypes.data,
+                           act0.ctypes.data, cat0.ctypes.data, a, b)
+
+    th = [threading.Thread(target=work, args=((n * i) // T, (n * (i + 1)) // T)) for i in range(T)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert (cat0 == cat1).all() and (act0 == act1).all()
+    assert st0.tobytes() == st1.tobytes(), first_diff(st0, st1)
+    # size-independent properties at full size
+    assert (act1 == np.isin(st1["type"], [3, 4])).all()
+    idx, stc = hp.collect_active()
+    assert (idx == np.nonzero(act1)[0]).all()
+    hp.close()
+
+
+def test_config5_stress_params(tmp_path_factory):
+    """BASELINE.json configs[4] flags on a small genome: k=22 --seed-lim 1000 --max-ed 8 --scan-lev 2."""
+    from conftest import DataSet
+    ds = DataSet(tmp_path_factory.mktemp("k22s"), "small", 8000, 37, kmer=22)
+    _run_all_rounds(ds, cl.default_params(kmer=22, seed_lim=1000, max_ed=8, scan_level=2))

@@ -415,25 +415,103 @@ CM_HD inline bool check_junction(const Core &c, uint32_t s1, uint32_t s2, int ol
     return false;
 }
 
-// seeds: ordinal s has qpos s*kmer, hits pos[start[s] .. start[s]+cnt[s]).  Returns #chains.
-CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint32_t *start, const uint32_t *cnt,
-                             ChainWork &w, CM_G cm_chain *out) {
+// Storage policies of the chaining DP.
+//  * ChainStoreGlobal: cells (score, back pointer) in the launch's HBM workspace, hit positions read from
+//    the index, improvement log in the shared pool (grows by x4, flags ERR_POOL when the pool is exhausted);
+//  * ChainStoreSmall: everything in lane-private arrays — for problems with at most SMALL_W (hit, later
+//    hit) pairs, i.e. at most SMALL_W improvements and SMALL_W + 1 cells: >95 % of all problems, and no
+//    global atomics, no scattered HBM cells for them.
+constexpr int SMALL_W = 32;
+struct ChainStoreGlobal {
+    ChainWork &w;
+    g_u32 POS;
+    const uint32_t *start;
+    const uint32_t *base;
+    CM_G Event *ev;
+    uint32_t n_ev, cap_ev;
+    bool lost;
+    CM_HD ChainStoreGlobal(ChainWork &ww, g_u32 pos, const uint32_t *st, const uint32_t *bs) : w(ww), POS(pos), start(st), base(bs), ev(nullptr), n_ev(0), cap_ev(0), lost(false) {}
+    CM_HD inline void init(uint32_t n_cells, double v) {
+        for (uint32_t x = 0; x < n_cells; ++x) {
+            w.dp_score[x] = v;
+            w.dp_prev[x] = -1;
+        }
+    }
+    CM_HD inline uint32_t pos(int s, uint32_t i) const { return POS[start[s] + i]; }
+    CM_HD inline double score(uint32_t x) const { return w.dp_score[x]; }
+    CM_HD inline int32_t prev(uint32_t x) const { return w.dp_prev[x]; }
+    CM_HD inline void set(uint32_t x, double sc, int32_t pv) {
+        w.dp_score[x] = sc;
+        w.dp_prev[x] = pv;
+    }
+    CM_HD inline void push(double sc, uint32_t cell) {
+        if (n_ev == cap_ev && !lost) {
+            const uint32_t ncap = cap_ev ? cap_ev * 4u : 32u;
+            const unsigned long long bytes = (unsigned long long)ncap * sizeof(Event);
+            const unsigned long long off = pool_take(w.pool_cursor, bytes);
+            if (off + bytes > w.pool_bytes) {
+                lost = true;
+                flag_err(w.err, ERR_POOL);
+            } else {
+                CM_G Event *ne = (CM_G Event *)(w.pool + off);
+                for (uint32_t q = 0; q < n_ev; ++q) ne[q] = ev[q];
+                ev = ne;
+                cap_ev = ncap;
+            }
+        }
+        if (n_ev < cap_ev) {
+            ev[n_ev].score = sc;
+            ev[n_ev].cell = cell;
+            ++n_ev;
+        }
+    }
+    CM_HD inline uint32_t n_events() const { return n_ev; }
+    CM_HD inline double ev_score(uint32_t q) const { return ev[q].score; }
+    CM_HD inline uint32_t ev_cell(uint32_t q) const { return ev[q].cell; }
+};
+struct ChainStoreSmall {
+    double sc[SMALL_W + 2];
+    int32_t pv[SMALL_W + 2];
+    uint32_t hp[SMALL_W + 2];
+    double es[SMALL_W];
+    uint32_t ec[SMALL_W];
+    const uint32_t *base;
+    uint32_t n_ev;
+    CM_HD ChainStoreSmall(g_u32 POS, const uint32_t *start, const uint32_t *cnt, const uint32_t *bs, int kc) : base(bs), n_ev(0) {
+        for (int s = 0; s < kc; ++s)
+            for (uint32_t i = 0; i < cnt[s]; ++i) hp[bs[s] + i] = POS[start[s] + i];
+    }
+    CM_HD inline void init(uint32_t n_cells, double v) {
+        for (uint32_t x = 0; x < n_cells; ++x) {
+            sc[x] = v;
+            pv[x] = -1;
+        }
+    }
+    CM_HD inline uint32_t pos(int s, uint32_t i) const { return hp[base[s] + i]; }
+    CM_HD inline double score(uint32_t x) const { return sc[x]; }
+    CM_HD inline int32_t prev(uint32_t x) const { return pv[x]; }
+    CM_HD inline void set(uint32_t x, double v, int32_t p) {
+        sc[x] = v;
+        pv[x] = p;
+    }
+    CM_HD inline void push(double v, uint32_t cell) {
+        if (n_ev < (uint32_t)SMALL_W) {       // cannot overflow: improvements <= (hit, later hit) pairs <= SMALL_W
+            es[n_ev] = v;
+            ec[n_ev] = cell;
+            ++n_ev;
+        }
+    }
+    CM_HD inline uint32_t n_events() const { return n_ev; }
+    CM_HD inline double ev_score(uint32_t q) const { return es[q]; }
+    CM_HD inline uint32_t ev_cell(uint32_t q) const { return ec[q]; }
+};
+
+// seeds: ordinal s has qpos s*kmer, cnt[s] hits (positions through the store).  Returns #chains.
+template <class ST>
+CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, const uint32_t *cnt, const uint32_t *base, ST &S, CM_G cm_chain *out) {
     const int kmer = c.P.kmer;
     const uint32_t max_best = (uint32_t)c.P.max_chain_len;
-    const g_u32 POS = c.X.pos;
-    int kc = n_seeds;
-    while (kc >= 1 && cnt[kc - 1] == 0) --kc;
-    if (kc <= 0) return 0;
-    uint32_t base[MAX_SEEDS + 1];
-    base[0] = 0;
-    for (int s = 0; s < kc; ++s) base[s + 1] = base[s] + cnt[s];
-    for (uint32_t x = 0; x < base[kc]; ++x) {
-        w.dp_score[x] = (double)kmer;
-        w.dp_prev[x] = -1;
-    }
-    CM_G Event *ev = nullptr;
-    uint32_t n_ev = 0, cap_ev = 0;
-    bool lost = false;
+    S.init(base[kc], (double)kmer);
     uint32_t lb_ind[MAX_SEEDS];
     uint32_t max_exon_end = 0;
     int ol = -1;
@@ -442,22 +520,21 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
         const uint32_t read_remain = (uint32_t)(seq_len - ii * kmer - kmer);
         for (int k = 0; k < kc; ++k) lb_ind[k] = 0;
         for (uint32_t i = 0; i < cnt[ii]; ++i) {
-            const int32_t cur_info = (int32_t)POS[start[ii] + i];
+            const int32_t cur_info = (int32_t)S.pos(ii, i);
             const uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
             uint32_t max_lpos_lim = MAXUB;
-            double my_score = w.dp_score[base[ii] + i];
+            double my_score = S.score(base[ii] + i);
             for (int jj = ii + 1; jj < kc; ++jj) {
                 const uint32_t pcn = cnt[jj];
                 if (pcn == 0 || lb_ind[jj] >= pcn) continue;
-                const g_u32 pp = POS + start[jj];
-                if (cur_info + c.P.max_intron < (int32_t)pp[lb_ind[jj]]) continue;
-                while (lb_ind[jj] < pcn && (int32_t)pp[lb_ind[jj]] <= cur_info) ++lb_ind[jj];
+                if (cur_info + c.P.max_intron < (int32_t)S.pos(jj, lb_ind[jj])) continue;
+                while (lb_ind[jj] < pcn && (int32_t)S.pos(jj, lb_ind[jj]) <= cur_info) ++lb_ind[jj];
                 if (lb_ind[jj] >= pcn) continue;
                 if (max_lpos_lim == MAXUB) max_lpos_lim = upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
                 const int distr = (jj - ii) * kmer - kmer;
                 uint32_t j = lb_ind[jj];
-                while (j < pcn && pp[j] <= max_lpos_lim) {
-                    const uint32_t pinfo = pp[j];
+                while (j < pcn && S.pos(jj, j) <= max_lpos_lim) {
+                    const uint32_t pinfo = S.pos(jj, j);
                     int genome_dist, distt, trans_dist;
                     if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
                     else genome_dist = INF_I;
@@ -472,31 +549,12 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
                     const int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
                     const double beta = 0.1 * (double)(maxd - mind);
                     const double alpha = 2e4 * (double)kmer;
-                    const double t1 = w.dp_score[base[jj] + j] + alpha;     // (prev + alpha) - beta, no contraction
+                    const double t1 = S.score(base[jj] + j) + alpha;     // (prev + alpha) - beta, no contraction
                     const double temp_score = t1 - beta;
                     if (temp_score > my_score) {
                         my_score = temp_score;
-                        w.dp_score[base[ii] + i] = temp_score;
-                        w.dp_prev[base[ii] + i] = (int32_t)(((uint32_t)jj << 16) | j);
-                        if (n_ev == cap_ev && !lost) {
-                            const uint32_t ncap = cap_ev ? cap_ev * 4u : 32u;
-                            const unsigned long long bytes = (unsigned long long)ncap * sizeof(Event);
-                            const unsigned long long off = pool_take(w.pool_cursor, bytes);
-                            if (off + bytes > w.pool_bytes) {
-                                lost = true;
-                                flag_err(w.err, ERR_POOL);
-                            } else {
-                                CM_G Event *ne = (CM_G Event *)(w.pool + off);
-                                for (uint32_t q = 0; q < n_ev; ++q) ne[q] = ev[q];
-                                ev = ne;
-                                cap_ev = ncap;
-                            }
-                        }
-                        if (n_ev < cap_ev) {
-                            ev[n_ev].score = temp_score;
-                            ev[n_ev].cell = ((uint32_t)ii << 16) | i;
-                            ++n_ev;
-                        }
+                        S.set(base[ii] + i, temp_score, (int32_t)(((uint32_t)jj << 16) | j));
+                        S.push(temp_score, ((uint32_t)ii << 16) | i);
                     }
                     ++j;
                 }
@@ -507,20 +565,22 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
     // back-tracking, src/chain.cpp:242-281: score groups descending, insertion order inside a group,
     // at most max_best cells per group (the cap applied at insertion time in the reference).
     uint32_t best_count = 0;
+    const uint32_t n_ev = S.n_events();
     if (n_ev > 0) {
-        double best_score = ev[0].score;
-        for (uint32_t q = 1; q < n_ev; ++q) best_score = ev[q].score > best_score ? ev[q].score : best_score;
+        double best_score = S.ev_score(0);
+        for (uint32_t q = 1; q < n_ev; ++q) best_score = S.ev_score(q) > best_score ? S.ev_score(q) : best_score;
         double cur = best_score;
         bool have = true;
         while (have && best_count < max_best) {
             uint32_t in_group = 0;
             for (uint32_t q = 0; q < n_ev && best_count < max_best; ++q) {
-                if (ev[q].score != cur) continue;
+                if (S.ev_score(q) != cur) continue;
                 if (in_group >= max_best) break;
                 ++in_group;
-                int bl = (int)(ev[q].cell >> 16);
-                uint32_t bi = ev[q].cell & 0xffffu;
-                const uint32_t spos = POS[start[bl] + bi];
+                const uint32_t cell = S.ev_cell(q);
+                int bl = (int)(cell >> 16);
+                uint32_t bi = cell & 0xffffu;
+                const uint32_t spos = S.pos(bl, bi);
                 if (cur < best_score) {
                     bool rep = false;     // repeats: rpos of any non-first fragment already emitted
                     for (uint32_t a = 0; a < best_count && !rep; ++a)
@@ -531,10 +591,10 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
                 CM_G cm_chain &ch = out[best_count++];
                 uint32_t n = 0;
                 while (true) {
-                    ch.rpos[n] = POS[start[bl] + bi];
+                    ch.rpos[n] = S.pos(bl, bi);
                     ch.qpos[n] = bl * kmer;
                     ++n;
-                    const int32_t pv = w.dp_prev[base[bl] + bi];
+                    const int32_t pv = S.prev(base[bl] + bi);
                     if (pv < 0) break;
                     bl = (int)((uint32_t)pv >> 16);
                     bi = (uint32_t)pv & 0xffffu;
@@ -546,8 +606,8 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
             have = false;
             double nxt = 0;
             for (uint32_t q = 0; q < n_ev; ++q)
-                if (ev[q].score < cur && (!have || ev[q].score > nxt)) {
-                    nxt = ev[q].score;
+                if (S.ev_score(q) < cur && (!have || S.ev_score(q) > nxt)) {
+                    nxt = S.ev_score(q);
                     have = true;
                 }
             cur = nxt;
@@ -558,13 +618,32 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
             for (uint32_t i = 0; i < cnt[ii]; ++i) {
                 if (best_count >= max_best) break;
                 CM_G cm_chain &ch = out[best_count++];
-                ch.rpos[0] = POS[start[ii] + i];
+                ch.rpos[0] = S.pos(ii, i);
                 ch.qpos[0] = ii * kmer;
-                ch.score = (float)w.dp_score[base[ii] + i];
+                ch.score = (float)S.score(base[ii] + i);
                 ch.chain_len = 1;
             }
     }
     return (int)best_count;
+}
+
+CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint32_t *start, const uint32_t *cnt, ChainWork &w, CM_G cm_chain *out) {
+    int kc = n_seeds;
+    while (kc >= 1 && cnt[kc - 1] == 0) --kc;
+    if (kc <= 0) return 0;
+    uint32_t base[MAX_SEEDS + 1];
+    base[0] = 0;
+    unsigned long long pairs = 0;
+    for (int s = 0; s < kc; ++s) {
+        pairs += (unsigned long long)cnt[s] * base[s];      // hits of s x hits of all earlier seeds
+        base[s + 1] = base[s] + cnt[s];
+    }
+    if (pairs <= (unsigned long long)SMALL_W && base[kc] <= (uint32_t)SMALL_W + 1u) {
+        ChainStoreSmall S(c.X.pos, start, cnt, base, kc);
+        return chain_kbest_t(c, seq_len, kc, cnt, base, S, out);
+    }
+    ChainStoreGlobal S(w, c.X.pos, start, base);
+    return chain_kbest_t(c, seq_len, kc, cnt, base, S, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -830,7 +830,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
     // Measured on MI355X (1 M pairs): splitting the heavy problems into their own work-ordered launch is slower
     // (4.6 ms light + 12.3 ms heavy vs 8.2 ms together): the few very long DPs no longer overlap with the bulk.
     // Kept behind this switch until the heavy problems get a wave-cooperative kernel.
-    const bool ordered = false && ranges.size() == 1;
+    const bool ordered = (getenv("CM_CHAIN_SPLIT") != nullptr) && ranges.size() == 1;
     if (ordered) {
         Timer t(ctx, 5);
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;

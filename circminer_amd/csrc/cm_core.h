@@ -426,11 +426,20 @@ struct ChainStoreGlobal {
     ChainWork &w;
     g_u32 POS;
     const uint32_t *start;
-    const uint32_t *base;
+    const uint32_t *cnt_;
+    const uint32_t *base_;
+    uint32_t lb_[MAX_SEEDS];
     CM_G Event *ev;
     uint32_t n_ev, cap_ev;
     bool lost;
-    CM_HD ChainStoreGlobal(ChainWork &ww, g_u32 pos, const uint32_t *st, const uint32_t *bs) : w(ww), POS(pos), start(st), base(bs), ev(nullptr), n_ev(0), cap_ev(0), lost(false) {}
+    CM_HD ChainStoreGlobal(ChainWork &ww, g_u32 pos, const uint32_t *st, const uint32_t *cn, const uint32_t *bs)
+        : w(ww), POS(pos), start(st), cnt_(cn), base_(bs), ev(nullptr), n_ev(0), cap_ev(0), lost(false) {}
+    CM_HD inline uint32_t cnt(int s) const { return cnt_[s]; }
+    CM_HD inline uint32_t base(int s) const { return base_[s]; }
+    CM_HD inline uint32_t total(int kc) const { return base_[kc]; }
+    CM_HD inline void lb_reset(int kc) { for (int k = 0; k < kc; ++k) lb_[k] = 0; }
+    CM_HD inline uint32_t lb(int s) const { return lb_[s]; }
+    CM_HD inline void set_lb(int s, uint32_t v) { lb_[s] = v; }
     CM_HD inline void init(uint32_t n_cells, double v) {
         for (uint32_t x = 0; x < n_cells; ++x) {
             w.dp_score[x] = v;
@@ -475,19 +484,27 @@ struct ChainStoreSmall {
     uint32_t hp[SMALL_W + 2];
     double es[SMALL_W];
     uint32_t ec[SMALL_W];
-    const uint32_t *base;
+    const uint32_t *cnt_;
+    const uint32_t *base_;
+    uint32_t lb_[MAX_SEEDS];
     uint32_t n_ev;
-    CM_HD ChainStoreSmall(g_u32 POS, const uint32_t *start, const uint32_t *cnt, const uint32_t *bs, int kc) : base(bs), n_ev(0) {
+    CM_HD ChainStoreSmall(g_u32 POS, const uint32_t *start, const uint32_t *cn, const uint32_t *bs, int kc) : cnt_(cn), base_(bs), n_ev(0) {
         for (int s = 0; s < kc; ++s)
-            for (uint32_t i = 0; i < cnt[s]; ++i) hp[bs[s] + i] = POS[start[s] + i];
+            for (uint32_t i = 0; i < cn[s]; ++i) hp[bs[s] + i] = POS[start[s] + i];
     }
+    CM_HD inline uint32_t cnt(int s) const { return cnt_[s]; }
+    CM_HD inline uint32_t base(int s) const { return base_[s]; }
+    CM_HD inline uint32_t total(int kc) const { return base_[kc]; }
+    CM_HD inline void lb_reset(int kc) { for (int k = 0; k < kc; ++k) lb_[k] = 0; }
+    CM_HD inline uint32_t lb(int s) const { return lb_[s]; }
+    CM_HD inline void set_lb(int s, uint32_t v) { lb_[s] = v; }
     CM_HD inline void init(uint32_t n_cells, double v) {
         for (uint32_t x = 0; x < n_cells; ++x) {
             sc[x] = v;
             pv[x] = -1;
         }
     }
-    CM_HD inline uint32_t pos(int s, uint32_t i) const { return hp[base[s] + i]; }
+    CM_HD inline uint32_t pos(int s, uint32_t i) const { return hp[base_[s] + i]; }
     CM_HD inline double score(uint32_t x) const { return sc[x]; }
     CM_HD inline int32_t prev(uint32_t x) const { return pv[x]; }
     CM_HD inline void set(uint32_t x, double v, int32_t p) {
@@ -508,33 +525,41 @@ struct ChainStoreSmall {
 
 // seeds: ordinal s has qpos s*kmer, cnt[s] hits (positions through the store).  Returns #chains.
 template <class ST>
-CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, const uint32_t *cnt, const uint32_t *base, ST &S, CM_G cm_chain *out) {
+CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, ST &S, CM_G cm_chain *out) {
     const int kmer = c.P.kmer;
     const uint32_t max_best = (uint32_t)c.P.max_chain_len;
-    S.init(base[kc], (double)kmer);
-    uint32_t lb_ind[MAX_SEEDS];
+    S.init(S.total(kc), (double)kmer);
     uint32_t max_exon_end = 0;
     int ol = -1;
 
     for (int ii = kc - 2; ii >= 0; --ii) {
         const uint32_t read_remain = (uint32_t)(seq_len - ii * kmer - kmer);
-        for (int k = 0; k < kc; ++k) lb_ind[k] = 0;
-        for (uint32_t i = 0; i < cnt[ii]; ++i) {
+        S.lb_reset(kc);
+        const uint32_t cnt_ii = S.cnt(ii), base_ii = S.base(ii);
+        for (uint32_t i = 0; i < cnt_ii; ++i) {
             const int32_t cur_info = (int32_t)S.pos(ii, i);
             const uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
             uint32_t max_lpos_lim = MAXUB;
-            double my_score = S.score(base[ii] + i);
+            double my_score = S.score(base_ii + i);
             for (int jj = ii + 1; jj < kc; ++jj) {
-                const uint32_t pcn = cnt[jj];
-                if (pcn == 0 || lb_ind[jj] >= pcn) continue;
-                if (cur_info + c.P.max_intron < (int32_t)S.pos(jj, lb_ind[jj])) continue;
-                while (lb_ind[jj] < pcn && (int32_t)S.pos(jj, lb_ind[jj]) <= cur_info) ++lb_ind[jj];
-                if (lb_ind[jj] >= pcn) continue;
+                const uint32_t pcn = S.cnt(jj);
+                uint32_t lb = S.lb(jj);
+                if (pcn == 0 || lb >= pcn) continue;
+                uint32_t pinfo = S.pos(jj, lb);
+                if (cur_info + c.P.max_intron < (int32_t)pinfo) continue;
+                while ((int32_t)pinfo <= cur_info) {
+                    if (++lb >= pcn) break;
+                    pinfo = S.pos(jj, lb);
+                }
+                S.set_lb(jj, lb);
+                if (lb >= pcn) continue;
                 if (max_lpos_lim == MAXUB) max_lpos_lim = upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
                 const int distr = (jj - ii) * kmer - kmer;
-                uint32_t j = lb_ind[jj];
-                while (j < pcn && S.pos(jj, j) <= max_lpos_lim) {
-                    const uint32_t pinfo = S.pos(jj, j);
+                const uint32_t base_jj = S.base(jj);
+                uint32_t j = lb;
+                for (; j < pcn; ++j) {
+                    if (j != lb) pinfo = S.pos(jj, j);
+                    if (pinfo > max_lpos_lim) break;
                     int genome_dist, distt, trans_dist;
                     if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
                     else genome_dist = INF_I;
@@ -543,20 +568,18 @@ CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, const uint32_
                     } else if (check_junction(c, seg_start, pinfo, ol, kmer, distr, trans_dist)) {
                         distt = trans_dist;
                     } else {
-                        ++j;
                         continue;
                     }
                     const int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
                     const double beta = 0.1 * (double)(maxd - mind);
                     const double alpha = 2e4 * (double)kmer;
-                    const double t1 = S.score(base[jj] + j) + alpha;     // (prev + alpha) - beta, no contraction
+                    const double t1 = S.score(base_jj + j) + alpha;     // (prev + alpha) - beta, no contraction
                     const double temp_score = t1 - beta;
                     if (temp_score > my_score) {
                         my_score = temp_score;
-                        S.set(base[ii] + i, temp_score, (int32_t)(((uint32_t)jj << 16) | j));
+                        S.set(base_ii + i, temp_score, (int32_t)(((uint32_t)jj << 16) | j));
                         S.push(temp_score, ((uint32_t)ii << 16) | i);
                     }
-                    ++j;
                 }
             }
         }
@@ -594,7 +617,7 @@ CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, const uint32_
                     ch.rpos[n] = S.pos(bl, bi);
                     ch.qpos[n] = bl * kmer;
                     ++n;
-                    const int32_t pv = S.prev(base[bl] + bi);
+                    const int32_t pv = S.prev(S.base(bl) + bi);
                     if (pv < 0) break;
                     bl = (int)((uint32_t)pv >> 16);
                     bi = (uint32_t)pv & 0xffffu;
@@ -615,12 +638,12 @@ CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, const uint32_
     }
     if (best_count == 0) {      // singletons, src/chain.cpp:283-298
         for (int ii = kc - 1; ii >= 0; --ii)
-            for (uint32_t i = 0; i < cnt[ii]; ++i) {
+            for (uint32_t i = 0; i < S.cnt(ii); ++i) {
                 if (best_count >= max_best) break;
                 CM_G cm_chain &ch = out[best_count++];
                 ch.rpos[0] = S.pos(ii, i);
                 ch.qpos[0] = ii * kmer;
-                ch.score = (float)S.score(base[ii] + i);
+                ch.score = (float)S.score(S.base(ii) + i);
                 ch.chain_len = 1;
             }
     }
@@ -640,10 +663,10 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
     }
     if (pairs <= (unsigned long long)SMALL_W && base[kc] <= (uint32_t)SMALL_W + 1u) {
         ChainStoreSmall S(c.X.pos, start, cnt, base, kc);
-        return chain_kbest_t(c, seq_len, kc, cnt, base, S, out);
+        return chain_kbest_t(c, seq_len, kc, S, out);
     }
-    ChainStoreGlobal S(w, c.X.pos, start, base);
-    return chain_kbest_t(c, seq_len, kc, cnt, base, S, out);
+    ChainStoreGlobal S(w, c.X.pos, start, cnt, base);
+    return chain_kbest_t(c, seq_len, kc, S, out);
 }
 
 // ------------------------------------------------------------------------------------------

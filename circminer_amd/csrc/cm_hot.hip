@@ -247,6 +247,274 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
 #endif
 }
 
+// ---- wave-cooperative chaining of heavy problems ----------------------------------------------
+// chain_seeds_sorted_kbest (src/chain.cpp:73-301) for ONE problem per wave.  For slot ii the cells i are
+// independent given the slots > ii, except for the reference's shared cursor lb_ind[jj]
+// (src/chain.cpp:133-160).  That cursor only differs from upper_bound(hits of jj, hit i) when an earlier
+// cell skipped the list with the maxIntronLen test, and the difference is observable only if a later
+// cell's window (max_lpos_lim) reaches a hit more than maxIntronLen away, i.e. only if the annotation
+// has an exon or an exon->next-exon hop longer than maxIntronLen.  cm_load_annotation checks that
+// (Slot::chain_parallel_ok); if it ever fails, heavy problems stay on the sequential kernel.
+// Order of the improvement log = reference insertion order (ii desc, i asc, then (jj, j) asc): each batch
+// of 64 cells is evaluated twice, first to count the improvements per cell, then (after a wave scan) to
+// store them at their final offsets.
+template <class T> __device__ inline T wave_excl_scan(T v, int lane, T &total) {
+    T x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const T y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+struct HeavyChainCtx {
+    const Core *c;
+    CM_L const uint32_t *LP;     // hit positions of every slot, concatenated (LDS)
+    const uint32_t *base, *cnt;  // per slot (uniform)
+    int kc, seq_len;
+    CM_G double *dps;
+    CM_G int32_t *dpp;
+};
+// evaluates cell (ii, i); returns the number of strict improvements; stores them to ev[] when ev != null
+__device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i, CM_G cmc::Event *ev, double &out_score, int32_t &out_prev) {
+    const Core &c = *h.c;
+    const int kmer = c.P.kmer;
+    const uint32_t read_remain = (uint32_t)(h.seq_len - ii * kmer - kmer);
+    const int32_t cur_info = (int32_t)h.LP[h.base[ii] + i];
+    const uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
+    uint32_t max_lpos_lim = cmc::MAXUB, max_exon_end = 0;
+    int ol = -1;
+    double my_score = (double)kmer;
+    int32_t my_prev = -1;
+    uint32_t n = 0;
+    for (int jj = ii + 1; jj < h.kc; ++jj) {
+        const uint32_t pcn = h.cnt[jj];
+        if (pcn == 0) continue;
+        CM_L const uint32_t *pp = h.LP + h.base[jj];
+        uint32_t lo = 0, hi = pcn;                   // first hit of jj strictly right of this hit
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((int32_t)pp[mid] <= cur_info) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= pcn) continue;
+        if (cur_info + c.P.max_intron < (int32_t)pp[lo]) continue;      // nothing within maxIntronLen
+        if (max_lpos_lim == cmc::MAXUB) max_lpos_lim = cmc::upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
+        const int distr = (jj - ii) * kmer - kmer;
+        for (uint32_t j = lo; j < pcn && pp[j] <= max_lpos_lim; ++j) {
+            const uint32_t pinfo = pp[j];
+            int genome_dist, distt, trans_dist;
+            if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
+            else genome_dist = cmc::INF_I;
+            if (cmc::cabs(genome_dist - distr) <= c.P.max_ed) distt = genome_dist;
+            else if (cmc::check_junction(c, seg_start, pinfo, ol, kmer, distr, trans_dist)) distt = trans_dist;
+            else continue;
+            const int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
+            const double beta = 0.1 * (double)(maxd - mind);
+            const double alpha = 2e4 * (double)kmer;
+            const double t1 = h.dps[h.base[jj] + j] + alpha;
+            const double temp_score = t1 - beta;
+            if (temp_score > my_score) {
+                my_score = temp_score;
+                my_prev = (int32_t)(((uint32_t)jj << 16) | j);
+                if (ev) {
+                    ev[n].score = temp_score;
+                    ev[n].cell = ((uint32_t)ii << 16) | i;
+                }
+                ++n;
+            }
+        }
+    }
+    out_score = my_score;
+    out_prev = my_prev;
+    return n;
+}
+
+__global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint64_t pair0, int S, const uint32_t *sstart, const uint32_t *scnt,
+                                                    const unsigned long long *celloff, double *dp_score, int32_t *dp_prev, uint8_t *pool,
+                                                    unsigned long long pool_bytes, unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain,
+                                                    int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm) {
+    extern __shared__ uint32_t lds_words[];
+    CM_L uint32_t *LP = (CM_L uint32_t *)lds_words;
+    const int lane = threadIdx.x;
+    const Core c = cmc::to_core(kc_);
+    const int kmer = c.P.kmer;
+    const uint32_t max_best = (uint32_t)c.P.max_chain_len;
+    const unsigned int n_heavy = *n_perm;
+    for (unsigned int hidx = blockIdx.x; hidx < n_heavy; hidx += gridDim.x) {
+        const uint32_t r = perm[hidx];
+        const uint64_t p = pair0 + (r >> 2);
+        const int mate = (int)((r >> 1) & 1u);
+        const int len = (int)(mate ? rd.off2[p + 1] - rd.off2[p] : rd.off1[p + 1] - rd.off1[p]);
+        uint32_t st[cmc::MAX_SEEDS], cn[cmc::MAX_SEEDS], base[cmc::MAX_SEEDS + 1];
+        int kc = S;
+        for (int s = 0; s < S; ++s) {
+            st[s] = sstart[(uint64_t)r * S + s];
+            cn[s] = scnt[(uint64_t)r * S + s];
+        }
+        while (kc >= 1 && cn[kc - 1] == 0) --kc;
+        base[0] = 0;
+        for (int s = 0; s < kc; ++s) base[s + 1] = base[s] + cn[s];
+        const uint32_t ncell = base[kc];
+        CM_G double *dps = (CM_G double *)(dp_score + celloff[r]);
+        CM_G int32_t *dpp = (CM_G int32_t *)(dp_prev + celloff[r]);
+        // hit positions -> LDS, cells initialised
+        for (int s = 0; s < kc; ++s)
+            for (uint32_t i = lane; i < cn[s]; i += 64) LP[base[s] + i] = c.X.pos[st[s] + i];
+        for (uint32_t x = lane; x < ncell; x += 64) {
+            dps[x] = (double)kmer;
+            dpp[x] = -1;
+        }
+        __threadfence_block();
+        __syncthreads();
+        HeavyChainCtx H{&c, LP, base, cn, kc, len, dps, dpp};
+        CM_G cmc::Event *ev = nullptr;
+        uint32_t n_ev = 0, cap_ev = 0;
+        bool lost = false;
+        for (int ii = kc - 2; ii >= 0; --ii) {
+            for (uint32_t i0 = 0; i0 < cn[ii]; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool on = i < cn[ii];
+                double sc = 0;
+                int32_t pv = -1;
+                const uint32_t mine = on ? heavy_cell(H, ii, i, (CM_G cmc::Event *)nullptr, sc, pv) : 0u;
+                uint32_t total;
+                const uint32_t off = wave_excl_scan(mine, lane, total);
+                if (n_ev + total > cap_ev && !lost) {                 // grow the log (uniform decision)
+                    uint32_t ncap = cap_ev ? cap_ev : 256u;
+                    while (ncap < n_ev + total) ncap *= 4u;
+                    const unsigned long long bytes = (unsigned long long)ncap * sizeof(cmc::Event);
+                    unsigned long long o = 0;
+                    if (lane == 0) o = atomicAdd(pool_cursor, bytes);
+                    o = ((unsigned long long)__shfl((unsigned int)(o >> 32), 0) << 32) | (unsigned long long)__shfl((unsigned int)o, 0);
+                    if (o + bytes > pool_bytes) {
+                        lost = true;
+                        if (lane == 0) atomicOr(err, cmc::ERR_POOL);
+                    } else {
+                        CM_G cmc::Event *ne = (CM_G cmc::Event *)((CM_G uint8_t *)pool + o);
+                        for (uint32_t q = lane; q < n_ev; q += 64) ne[q] = ev[q];
+                        ev = ne;
+                        cap_ev = ncap;
+                    }
+                }
+                if (on) {
+                    if (mine && !lost) heavy_cell(H, ii, i, ev + n_ev + off, sc, pv);
+                    dps[base[ii] + i] = sc;
+                    dpp[base[ii] + i] = pv;
+                }
+                if (!lost) n_ev += total;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // ---- back-tracking (src/chain.cpp:242-298), lane 0 emits; searches are wave-parallel
+        CM_G cm_chain *out = (CM_G cm_chain *)(chains + (uint64_t)r * CM_BESTCHAINLIM);
+        uint32_t best_count = 0;
+        __threadfence_block();
+        __syncthreads();
+        if (n_ev > 0) {
+            double best_score = -1.0;
+            for (uint32_t q = lane; q < n_ev; q += 64) best_score = ev[q].score > best_score ? ev[q].score : best_score;
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double u = __shfl_xor(best_score, o);
+                best_score = u > best_score ? u : best_score;
+            }
+            double cur = best_score;
+            bool have = true;
+            while (have && best_count < max_best) {
+                uint32_t in_group = 0;
+                bool stop_group = false;
+                for (uint32_t q0 = 0; q0 < n_ev && !stop_group && best_count < max_best; q0 += 64) {
+                    const uint32_t q = q0 + lane;
+                    const bool hit = q < n_ev && ev[q].score == cur;
+                    unsigned long long m = __ballot(hit);
+                    while (m && !stop_group && best_count < max_best) {
+                        const int l = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        if (in_group >= max_best) {
+                            stop_group = true;
+                            break;
+                        }
+                        ++in_group;
+                        const uint32_t cell = ev[q0 + l].cell;             // uniform
+                        int bl = (int)(cell >> 16);
+                        uint32_t bi = cell & 0xffffu;
+                        const uint32_t spos = LP[base[bl] + bi];
+                        bool rep = false;
+                        if (cur < best_score) {                            // repeats: non-first fragments already emitted
+                            for (uint32_t a = 0; a < best_count && !rep; ++a) {
+                                const uint32_t cl = out[a].chain_len;
+                                const bool mine2 = (uint32_t)lane >= 1u && (uint32_t)lane < cl && out[a].rpos[lane] == spos;
+                                rep = __ballot(mine2) != 0ull;
+                            }
+                        }
+                        if (rep) continue;
+                        if (lane == 0) {
+                            CM_G cm_chain &ch = out[best_count];
+                            uint32_t n = 0;
+                            while (true) {
+                                ch.rpos[n] = LP[base[bl] + bi];
+                                ch.qpos[n] = bl * kmer;
+                                ++n;
+                                const int32_t pv = dpp[base[bl] + bi];
+                                if (pv < 0) break;
+                                bl = (int)((uint32_t)pv >> 16);
+                                bi = (uint32_t)pv & 0xffffu;
+                            }
+                            ch.score = (float)cur;
+                            ch.chain_len = n;
+                        }
+                        ++best_count;
+                        __threadfence_block();
+                        __syncthreads();
+                    }
+                }
+                // next lower score
+                double nxt = -1.0;
+                bool hv = false;
+                for (uint32_t q = lane; q < n_ev; q += 64) {
+                    const double v = ev[q].score;
+                    if (v < cur && (!hv || v > nxt)) {
+                        nxt = v;
+                        hv = true;
+                    }
+                }
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const double u = __shfl_xor(nxt, o);
+                    const int uh = __shfl_xor((int)hv, o);
+                    if (uh && (!hv || u > nxt)) {
+                        nxt = u;
+                        hv = true;
+                    }
+                }
+                have = hv;
+                cur = nxt;
+            }
+        }
+        if (best_count == 0 && lane == 0) {          // singletons
+            for (int ii = kc - 1; ii >= 0; --ii)
+                for (uint32_t i = 0; i < cn[ii]; ++i) {
+                    if (best_count >= max_best) break;
+                    CM_G cm_chain &ch = out[best_count++];
+                    ch.rpos[0] = LP[base[ii] + i];
+                    ch.qpos[0] = ii * kmer;
+                    ch.score = (float)dps[base[ii] + i];
+                    ch.chain_len = 1;
+                }
+        }
+        best_count = __shfl(best_count, 0);
+        __threadfence_block();
+        __syncthreads();
+        if (lane == 0) {
+            nchain[r] = (int32_t)best_count;
+            int rs = 0;
+            if (best_count > 0) rs = out[0].qpos[0] + (len - (out[0].qpos[out[0].chain_len - 1] + kmer));
+            resid[r] = (uint16_t)(rs < 0 ? 0 : rs);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- light / heavy split of the pair stage -------------------------------------------------
 // A pair whose chain lists can produce many mate pairs and unpaired-chain extensions (reads from
 // repeats: up to 30 x 30 pairs plus 60 full-length extensions) costs 100x the median pair; as one lane
@@ -292,7 +560,8 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(const uint16_t *resid, const i
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
-__global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high) {
+__global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high,
+                                                  unsigned long long light_w, unsigned int light_cells) {
     const uint32_t r = blockIdx.x * BLK + threadIdx.x;
     if (r >= n_prob) return;
     unsigned long long w = 0, suffix = 0;
@@ -304,9 +573,10 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
         if (sraw[(uint64_t)r * S + s] > 0 && c == 0) ++hh;       // get_best_chains high_hits (also for problems k_chain skips)
     }
     high[r] = hh;
-    // class 0 = light (mapped in index order: coalesced seed/cell accesses matter more than balance there),
-    // 1..8 = heavy, mapped by a second launch in work order so that long DPs share waves
-    cls[r] = (int8_t)(suffix == 0 ? -2 : w <= 64 ? 0 : w <= 256 ? 1 : w <= 1024 ? 2 : w <= 4096 ? 3 : w <= 16384 ? 4 : w <= 65536 ? 5 : w <= 262144 ? 6
+    // class 0 = light (one lane each, index order: coalesced seed/cell accesses matter more than balance there),
+    // 1..8 = heavy (one wave each, k_chain_heavy, heaviest class first)
+    const bool light = w <= light_w && suffix <= light_cells;
+    cls[r] = (int8_t)(suffix == 0 ? -2 : light ? 0 : w <= 256 ? 1 : w <= 1024 ? 2 : w <= 4096 ? 3 : w <= 16384 ? 4 : w <= 65536 ? 5 : w <= 262144 ? 6
                                        : w <= 1048576 ? 7 : 8);
 }
 __global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb) {
@@ -636,6 +906,7 @@ __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, i
 // ------------------------------------------------------------------ host side
 struct Slot {
     bool loaded = false, has_annot = false;
+    bool chain_parallel_ok = false;      // see k_chain_heavy: no annotated hop longer than maxIntronLen
     cm_index_view X{};
     cmc::AnnotDev A{};
     std::vector<void *> idx_allocs, ann_allocs;
@@ -791,7 +1062,7 @@ int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_til
     return CM_OK;
 }
 
-int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile) {
+int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, bool parallel_ok) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
@@ -827,14 +1098,18 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             a = b;
         }
     }
-    // Measured on MI355X (1 M pairs): splitting the heavy problems into their own work-ordered launch is slower
-    // (4.6 ms light + 12.3 ms heavy vs 8.2 ms together): the few very long DPs no longer overlap with the bulk.
-    // Kept behind this switch until the heavy problems get a wave-cooperative kernel.
-    const bool ordered = (getenv("CM_CHAIN_SPLIT") != nullptr) && ranges.size() == 1;
-    if (ordered) {
+    // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy),
+    // heaviest class first.  CM_CHAIN_SPLIT=0 keeps everything on the sequential kernel.
+    static const char *split_env = getenv("CM_CHAIN_SPLIT");
+    static const unsigned long long light_w = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 64ull;
+    static const unsigned int light_cells = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 48u;
+    const size_t heavy_lds = (size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t);
+    const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;
+    if (split) {
         Timer t(ctx, 5);
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
-        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high);
+        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high,
+                           light_w, light_cells);
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 0);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
@@ -844,20 +1119,22 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
     for (auto &rg : ranges) {
         unsigned long long base = 0;
         if (rg.first != 0) base = ctx->h_celloff[rg.first];
-        Timer t(ctx, 1);
         const uint32_t n = rg.second - rg.first;
+        if (split) {          // heavy first: its few long problems overlap with the bulk launched behind it
+            Timer t(ctx, 6);
+            if (heavy_lds > 64u * 1024u)
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
+            const uint32_t hb = n < 8192u ? n : 8192u;
+            hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds, ctx->stream, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
+                               ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_err,
+                               ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + 10);
+            ++ctx->launches[6];
+        }
+        Timer t(ctx, 1);
         hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
                            rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
                            ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid,
-                           (const uint32_t *)nullptr, (const unsigned int *)nullptr, ordered ? ctx->d_cls4 : (const int8_t *)nullptr);
-        if (ordered) {          // heavy problems: at most a few % of the tile; grid sized for the worst case, surplus blocks exit at once
-            const uint32_t hb = (n + BLK_CHAIN - 1) / BLK_CHAIN;
-            hipLaunchKernelGGL(k_chain, dim3(hb), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, 0u, n, S,
-                               ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes,
-                               ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + 10,
-                               (const int8_t *)nullptr);
-            ++ctx->launches[1];
-        }
+                           (const uint32_t *)nullptr, (const unsigned int *)nullptr, split ? ctx->d_cls4 : (const int8_t *)nullptr);
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
     }
@@ -996,6 +1273,16 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     }
     // the staging copies are asynchronous: the host vectors must outlive them
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {   // every window bound upper_bound() can return lies within maxIntronLen of the queried hit (k_chain_heavy)
+        const long long mi = ctx->P.max_intron;
+        bool ok = mi >= (long long)ctx->P.max_read_len + ctx->P.max_ed && mi < (1ll << 30);
+        for (uint32_t i = 0; i < av->n_iv && ok; ++i) {
+            if (av->iv_seg_off[i + 1] == av->iv_seg_off[i]) continue;
+            const long long far = std::max<long long>((long long)av->iv_max_next_exon[i] + ctx->P.kmer, (long long)av->iv_max_end[i]);
+            if (far - (long long)av->iv_spos[i] > mi) ok = false;
+        }
+        s.chain_parallel_ok = ok;
+    }
     s.has_annot = true;
     return CM_OK;
 }
@@ -1121,7 +1408,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
-        if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
+        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
         {
             // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
             const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
@@ -1278,7 +1565,7 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_chains, 0, (size_t)nt * 4 * CM_BESTCHAINLIM * sizeof(cm_chain), ctx->stream));
-        if ((rc = run_chain_tile(ctx, core, p0, nt))) return rc;
+        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
         const size_t np = (size_t)nt * 4, o = (size_t)p0 * 4;
         HIPCHK(ctx, hipMemcpyAsync(out_chains + o * CM_BESTCHAINLIM, ctx->d_chains, np * CM_BESTCHAINLIM * sizeof(cm_chain), hipMemcpyDeviceToHost,
                                    ctx->stream));

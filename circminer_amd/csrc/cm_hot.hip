@@ -145,17 +145,15 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
                                                      const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
                                                      int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
                                                      unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain, int32_t *high, int *err,
-                                                     uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm, const int8_t *cls) {
-    // perm == null: index order, skipping problems of a heavy work class when cls != null;
-    // perm != null: the heavy problems, heaviest class first (perm[0 .. *n_perm))
+                                                     uint16_t *resid, const uint32_t *perm, const unsigned int *perm_lo, const unsigned int *perm_hi) {
+    // perm == null: problems r0..r1 in index order;
+    // perm != null: the light problems perm[*perm_lo .. *perm_hi), grouped by work class so that the lanes of a wave carry similar DPs
     uint32_t r = r0 + blockIdx.x * BLK_CHAIN + threadIdx.x;
     if (perm) {
-        if (r >= *n_perm) return;
+        r += *perm_lo;
+        if (r >= *perm_hi) return;
         r = perm[r];
-    } else {
-        if (r >= r1) return;
-        if (cls && cls[r] > 0) return;
-    }
+    } else if (r >= r1) return;
     const Core c = cmc::to_core(kc);
     const uint64_t p = pair0 + (r >> 2);
     int n = 0, hh = 0, rs = 0;
@@ -539,8 +537,10 @@ __device__ inline int pair_class(const uint16_t *resid4, const int32_t *nchain, 
 // k_cls_count: class per pair + per-block class histogram;  k_cls_scan: one workgroup turns the
 // [class][block] histogram into exclusive bases (heaviest light bucket first) and totals;
 // k_cls_place: writes perm[] (light pairs) / hlist[] (heavy pairs) at base + rank inside the block.
+constexpr int CHAIN_LIGHT_CLS = 12;     // chaining classes below this are light
 constexpr int CLS_T = 1024;            // threads per block = 16 waves
-constexpr int N_CLS = N_BUCKETS + 1;
+constexpr int N_CLS = 16;                // classes a sort can use (pairs: 0..7 light + 8 heavy; chaining: 0..11 light + 12..15 heavy)
+constexpr int CTR_SUM = 16, CTR_BASE = 32, CTR_WORDS = 64;
 __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], unsigned int &rank_in_wave, int lane, int wave) {
     // wcnt[w][c] = number of lanes of wave w with class c; rank_in_wave = rank of this lane among its class in its wave
     rank_in_wave = 0;
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(const uint16_t *resid, const i
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
 __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high,
-                                                  unsigned long long light_w, unsigned int light_cells) {
+                                                  unsigned long long light_w, unsigned int light_cells, int32_t *nchain, uint16_t *resid) {
     const uint32_t r = blockIdx.x * BLK + threadIdx.x;
     if (r >= n_prob) return;
     unsigned long long w = 0, suffix = 0;
@@ -573,11 +573,18 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
         if (sraw[(uint64_t)r * S + s] > 0 && c == 0) ++hh;       // get_best_chains high_hits (also for problems k_chain skips)
     }
     high[r] = hh;
-    // class 0 = light (one lane each, index order: coalesced seed/cell accesses matter more than balance there),
-    // 1..8 = heavy (one wave each, k_chain_heavy, heaviest class first)
+    if (suffix == 0) {                  // no retained hit: no chain, and no kernel visits this problem
+        nchain[r] = 0;
+        resid[r] = 0;
+    }
+    // classes 0..11 = light (one lane each, k_chain; grouped so the lanes of a wave carry similar DPs),
+    // 12..15 = heavy (one wave each, k_chain_heavy, heaviest class first)
     const bool light = w <= light_w && suffix <= light_cells;
-    cls[r] = (int8_t)(suffix == 0 ? -2 : light ? 0 : w <= 256 ? 1 : w <= 1024 ? 2 : w <= 4096 ? 3 : w <= 16384 ? 4 : w <= 65536 ? 5 : w <= 262144 ? 6
-                                       : w <= 1048576 ? 7 : 8);
+    const unsigned int n = (unsigned int)suffix;
+    cls[r] = (int8_t)(suffix == 0 ? -2
+                      : light ? (n <= 3 ? 0 : n <= 6 ? 1 : n <= 7 ? 2 : n <= 9 ? 3 : n <= 12 ? 4 : n <= 16 ? 5 : n <= 24 ? 6 : n <= 32 ? 7 : n <= 48 ? 8 : n <= 64 ? 9
+                                 : n <= 96 ? 10 : 11)
+                      : w <= 4096 ? 12 : w <= 65536 ? 13 : w <= 1048576 ? 14 : 15);
 }
 __global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
@@ -592,8 +599,9 @@ __global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t 
         blk_cnt[(size_t)threadIdx.x * nb + blockIdx.x] = tot;
     }
 }
-// ctr[c] = total of class c, ctr[9] = number of light pairs, ctr[10 + c] = base offset of class c in perm[]
-__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int heavy_separate) {
+// ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
+// (highest class first); class `separate` (or none: -1) goes to its own list instead
+__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate) {
     __shared__ unsigned int part[1024];
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
@@ -622,15 +630,15 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
     }
     if (t == 0) {
         unsigned int off = 0;
-        if (!heavy_separate) {                          // class 8 leads the single permutation
-            ctr[10 + N_BUCKETS] = 0;
-            off = tot[N_BUCKETS];
-        } else ctr[10 + N_BUCKETS] = 0;                  // class 8 goes to its own list
-        for (int c = N_BUCKETS - 1; c >= 0; --c) {      // heaviest bucket first
-            ctr[10 + c] = off;
+        for (int c = N_CLS - 1; c >= 0; --c) {          // heaviest class first
+            if (c == separate) {
+                ctr[CTR_BASE + c] = 0;
+                continue;
+            }
+            ctr[CTR_BASE + c] = off;
             off += tot[c];
         }
-        ctr[9] = off;
+        ctr[CTR_SUM] = off;
         for (int c = 0; c < N_CLS; ++c) ctr[c] = tot[c];
     }
 }
@@ -648,7 +656,7 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
         for (int w = 0; w < wave; ++w) before += wcnt[w][k];
         const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
         if (k == N_BUCKETS && hlist) hlist[pos] = t;
-        else perm[ctr[10 + k] + pos] = t;
+        else perm[ctr[CTR_BASE + k] + pos] = t;
     }
 }
 
@@ -1101,17 +1109,17 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
     // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy),
     // heaviest class first.  CM_CHAIN_SPLIT=0 keeps everything on the sequential kernel.
     static const char *split_env = getenv("CM_CHAIN_SPLIT");
-    static const unsigned long long light_w = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 64ull;
-    static const unsigned int light_cells = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 48u;
+    static const unsigned long long light_w = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 256ull;
+    static const unsigned int light_cells = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 96u;
     const size_t heavy_lds = (size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t);
     const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;
     if (split) {
         Timer t(ctx, 5);
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
         hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high,
-                           light_w, light_cells);
+                           light_w, light_cells, ctx->d_nchain, ctx->d_resid);
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 0);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
                            (uint32_t *)nullptr);
         ctx->launches[5] += 4;
@@ -1127,14 +1135,14 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             const uint32_t hb = n < 8192u ? n : 8192u;
             hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds, ctx->stream, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
                                ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_err,
-                               ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + 10);
+                               ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1);
             ++ctx->launches[6];
         }
         Timer t(ctx, 1);
         hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
                            rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
                            ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid,
-                           (const uint32_t *)nullptr, (const unsigned int *)nullptr, split ? ctx->d_cls4 : (const int8_t *)nullptr);
+                           split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cls_ctr + CTR_SUM);
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
     }
@@ -1377,7 +1385,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, 32 * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
@@ -1424,7 +1432,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt,
                                ctx->d_cls, ctx->d_cat);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, N_BUCKETS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
                                ctx->d_hlist);
             ctx->launches[5] += 4;
@@ -1433,7 +1441,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             Timer t(ctx, 2);
             hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
                                ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
-                               str_cap, ctx->d_lane_clk, ctx->d_perm, ctx->d_cls_ctr + 9);
+                               str_cap, ctx->d_lane_clk, ctx->d_perm, ctx->d_cls_ctr + CTR_SUM);
             ++ctx->launches[2];
             }
             {
@@ -1481,7 +1489,7 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_cls, n));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_perm, n * 4));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, 32 * sizeof(unsigned int)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
     }
     if (cap > ctx->collect_cap) {                 // grow-only output staging
         dfree(ctx->d_collect_idx);
@@ -1494,7 +1502,7 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     // stable compaction (block histogram -> scan -> place): ascending pair index, no atomics, no host sort
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, 0);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
                        ctx->d_col_perm, (uint32_t *)nullptr);
     if (cap)

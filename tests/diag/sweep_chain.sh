@@ -1,6 +1,6 @@
 #!/bin/bash
 # sweep of the light/heavy threshold of the chaining stage (diagnostic; run on the GPU box)
-for cfg in "256 96" "64 48" "32 32"; do
+for cfg in "256 96" "1024 128" "4096 256" "16384 512"; do
   set -- $cfg
   CM_CHAIN_LIGHT_W=$1 CM_CHAIN_LIGHT_CELLS=$2 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/sw.json 2>gpurun_out/sw.err || exit 1
   python - "$cfg" <<'PY'

@@ -8,6 +8,7 @@
 // in HBM between rounds; nothing is copied back until cm_reads_download.
 //
 // There is no CPU path in this file: without a HIP device cm_create fails with CM_ENODEV.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -601,12 +602,14 @@ __global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t 
 }
 // ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
 // (highest class first); class `separate` (or none: -1) goes to its own list instead
-__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate) {
+__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used) {
     __shared__ unsigned int part[1024];
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = (nb + 1023u) / 1024u;
-    for (int c = 0; c < N_CLS; ++c) {
+    if (t < N_CLS) tot[t] = 0;
+    __syncthreads();
+    for (int c = 0; c < n_used; ++c) {                  // classes >= n_used are not produced by this caller
         unsigned int *row = blk_cnt + (size_t)c * nb;
         const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
         unsigned int s = 0;
@@ -927,6 +930,7 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 struct cm_ctx {
     cm_params P{};
     hipStream_t stream = nullptr;
+    unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
     std::string err = "";
     Slot slots[MAX_SLOTS];
     // reads
@@ -1084,9 +1088,9 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         ctx->launches[3] += 3;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
     }
-    unsigned long long total = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_celloff + n_prob, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_celloff + n_prob, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long total = ctx->h_pin[0];
     // problem ranges whose DP cells fit the workspace
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
     if (total <= ctx->cells_cap) {
@@ -1119,7 +1123,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high,
                            light_w, light_cells, ctx->d_nchain, ctx->d_resid);
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
                            (uint32_t *)nullptr);
         ctx->launches[5] += 4;
@@ -1150,9 +1154,9 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
 }
 
 int check_dev_err(cm_ctx *ctx) {
-    int e = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&e, ctx->d_err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int e = *(const int *)ctx->h_pin;
     if (e) {
         return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
                     (e & cmc::ERR_TID) ? " more than 64 common transcripts for one mate pair;" : "", (e & ~3) ? " DP string longer than the staging buffer" : "");
@@ -1186,7 +1190,8 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     }
     if (hipMalloc((void **)&ctx->d_pool_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault) != hipSuccess) {
         delete ctx;
         return CM_ENOMEM;
     }
@@ -1214,6 +1219,7 @@ void cm_destroy(cm_ctx *ctx) {
     dfree(ctx->d_pool_cursor);
     dfree(ctx->d_err);
     dfree(ctx->d_counters);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1432,7 +1438,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt,
                                ctx->d_cls, ctx->d_cat);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, N_BUCKETS);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, N_BUCKETS, N_BUCKETS + 1);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
                                ctx->d_hlist);
             ctx->launches[5] += 4;
@@ -1477,10 +1483,18 @@ int cm_reads_reset(cm_ctx *ctx) {
     return CM_OK;
 }
 
+#ifdef CM_TRACE_HOST
+#define TRACE_T0 auto tr_t = std::chrono::steady_clock::now()
+#define TRACE_PT(name) do { auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "[trace] %s %.1f us\n", name, std::chrono::duration<double, std::micro>(n_ - tr_t).count()); tr_t = n_; } while (0)
+#else
+#define TRACE_T0
+#define TRACE_PT(name)
+#endif
 int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n) {
     if (!ctx || !out_n || (cap && (!out_idx || !out_state))) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     *out_n = 0;
+    TRACE_T0;
     const uint64_t n = ctx->n_pairs;
     if (n == 0) return CM_OK;
     if (n > 0xfffffff0ull) return fail(ctx, CM_ELIMIT, "cm_collect_active: too many pairs");
@@ -1502,15 +1516,19 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     // stable compaction (block histogram -> scan -> place): ascending pair index, no atomics, no host sort
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
                        ctx->d_col_perm, (uint32_t *)nullptr);
+    TRACE_PT("pre");
     if (cap)
         hipLaunchKernelGGL(k_gather_active, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
                            (unsigned long long)cap, ctx->d_state, ctx->d_collect_idx, ctx->d_collect_st);
-    unsigned int cnt = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&cnt, ctx->d_col_ctr, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_col_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    TRACE_PT("launch+cnt");
+    const unsigned int cnt = *(const unsigned int *)ctx->h_pin;
+    if (*(const int *)(ctx->h_pin + 1)) return check_dev_err(ctx);
     *out_n = cnt;
     if (cnt > cap) return fail(ctx, CM_ELIMIT, "cm_collect_active: %u active pairs > cap %llu", cnt, (unsigned long long)cap);
     if (cnt) {
@@ -1518,7 +1536,22 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
         HIPCHK(ctx, hipMemcpyAsync(out_state, ctx->d_collect_st, (size_t)cnt * sizeof(cm_mapped_read), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return check_dev_err(ctx);
+    TRACE_PT("data");
+    return CM_OK;
+}
+
+int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return CM_EINVAL;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return CM_OK;
+}
+
+int cm_host_free(cm_ctx *ctx, void *p) {
+    if (!ctx) return CM_EINVAL;
+    if (p) HIPCHK(ctx, hipHostFree(p));
+    return CM_OK;
 }
 
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active) {

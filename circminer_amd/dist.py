@@ -25,10 +25,11 @@ def shard_bounds(n_total: int, rank: int, world: int):
 
 
 def pack_records(global_idx: np.ndarray, states: np.ndarray) -> np.ndarray:
-    rec = np.zeros(len(global_idx), dtype=REC_DTYPE)
-    rec["pair"] = global_idx
-    rec["state"] = states
-    return rec
+    n = len(global_idx)
+    raw = np.empty((n, REC_DTYPE.itemsize), dtype=np.uint8)      # two strided byte copies, not per-field assignment
+    raw[:, :8] = np.ascontiguousarray(global_idx, dtype="<u8").view(np.uint8).reshape(n, 8)
+    raw[:, 8:] = np.ascontiguousarray(states).view(np.uint8).reshape(n, cl.MAPPED_DTYPE.itemsize)
+    return raw.reshape(-1).view(REC_DTYPE)
 
 
 def gather_bsj(records: np.ndarray, device=None):

@@ -144,6 +144,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_sync": (C.c_int, [vp]),
         "cm_reads_reset": (C.c_int, [vp]),
         "cm_collect_active": (C.c_int, [vp, C.c_uint64, vp, vp, pp(C.c_uint64)]),
+        "cm_host_alloc": (C.c_int, [vp, C.c_uint64, pp(vp)]),
+        "cm_host_free": (C.c_int, [vp, vp]),
         "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
         "cm_chain_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "cm_prof_enable": (C.c_int, [vp, C.c_int]),
@@ -166,7 +168,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation"]
 
@@ -222,6 +224,7 @@ class HotPath:
         if rc != 0:
             raise RuntimeError(f"cm_create failed ({rc}): no usable HIP device / bad params")
         self.n = 0
+        self._pinned = []
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -247,15 +250,25 @@ class HotPath:
         self._chk(self.L.cm_reads_reset(self.h), "cm_reads_reset")
 
     def collect_active(self, cap=None):
-        """Active pairs (ascending index) and their carried state; host buffers are reused across calls."""
+        """Active pairs (ascending index) and their carried state, as views of page-locked buffers
+        that the next call overwrites (copy them to keep them)."""
         cap = int(cap if cap is not None else max(self.n, 1))
         if getattr(self, "_col_cap", 0) < cap:
-            self._col_idx = np.empty(cap, np.uint64)
-            self._col_st = np.empty(cap, dtype=MAPPED_DTYPE)
+            self._col_idx = self.host_array(cap, np.uint64)
+            self._col_st = self.host_array(cap, MAPPED_DTYPE)
             self._col_cap = cap
         n = C.c_uint64(0)
         self._chk(self.L.cm_collect_active(self.h, cap, self._col_idx.ctypes.data, self._col_st.ctypes.data, C.byref(n)), "cm_collect_active")
-        return self._col_idx[:n.value].copy(), self._col_st[:n.value].copy()
+        return self._col_idx[:n.value], self._col_st[:n.value]     # views: valid until the next call
+
+    def host_array(self, n, dtype):
+        """numpy array over page-locked memory from cm_host_alloc (freed with the context)."""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        self._chk(self.L.cm_host_alloc(self.h, max(int(n), 1) * dt.itemsize, C.byref(p)), "cm_host_alloc")
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * (max(int(n), 1) * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=int(n))
 
     def download(self):
         st = np.zeros(self.n, dtype=MAPPED_DTYPE)
@@ -298,6 +311,11 @@ class HotPath:
 
     def close(self):
         if self.h:
+            self._col_idx = self._col_st = None
+            self._col_cap = 0
+            for p in self._pinned:
+                self.L.cm_host_free(self.h, p)
+            self._pinned = []
             self.L.cm_destroy(self.h)
             self.h = C.c_void_p()
 

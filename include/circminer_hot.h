@@ -202,6 +202,12 @@ int cm_reads_reset(cm_ctx *ctx);
  * Returns CM_ELIMIT (and the needed count in *out_n) if cap is too small. */
 int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n);
 
+/* Page-locked host memory for the buffers that cross PCIe (read batches, downloaded states, collected
+ * records): the copies in cm_reads_upload / cm_reads_download / cm_collect_active are direct DMA for such
+ * buffers instead of staged pageable copies.  Optional: every entry point also accepts ordinary memory. */
+int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out);
+int cm_host_free(cm_ctx *ctx, void *p);
+
 /* ---------------- finer-grained entry points used by the parity tests ---------------- */
 /* Seeds (GenomeSeeder::split_match_hash, src/match_read.cpp:270-286) of the resident batch:
  * for probe q = ((pair*2 + mate)*2 + orient)*n_slots + s (orient 0 = forward, 1 = reverse

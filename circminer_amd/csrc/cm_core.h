@@ -1965,6 +1965,19 @@ CM_HD inline int leftover_type(int min_ret1, int min_ret2, bool r1_genic, bool r
          : ((min_ret1 == CM_CONCRD) && (min_ret2 == CM_CONCRD)) ? CM_OEA2 : CM_CANDID;
 }
 
+// The unpaired-chain extensions of process_mates (filter.cpp:356-393) feed nothing but leftover_type(), whose
+// value is applied with mr_update_type, i.e. only if it is lower than the type T the pair already has.
+// leftover_type >= CHIFUS; its values below OEANCH need both sides to end without ORPHAN, those below
+// CANDID (CHIFUS, OEA2) need both sides to end CONCRD.  can1 / can2: side still has chains to extend.
+// Returns false when no outcome of the remaining extensions can change mr.type: they are dead work
+// (full-length DPs of spurious chains, typically) and are skipped; results are identical.
+CM_HD inline bool leftovers_matter(int T, int min_ret1, bool can1, int min_ret2, bool can2) {
+    if (T <= CM_CHIFUS) return false;
+    if (T <= CM_CANDID && ((min_ret1 != CM_CONCRD && !can1) || (min_ret2 != CM_CONCRD && !can2))) return false;
+    if (T <= CM_OEANCH && ((min_ret1 == CM_ORPHAN && !can1) || (min_ret2 == CM_ORPHAN && !can2))) return false;
+    return true;
+}
+
 // FilterRead::process_mates (filter.cpp:244-395) with pair_chains (filter.cpp:484-551) fused in:
 // pass 1 evaluates the pairing predicate for every (i, j) (needed up-front for the *_paired
 // flags), pass 2 walks the accepted pairs in i-major order.
@@ -1974,6 +1987,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     const int kmer = c.P.kmer;
     const int saved_type = mr.type;
     int fe[CM_BESTCHAINLIM], re[CM_BESTCHAINLIM];
+    CM_TICK(sm, 0);
     for (int i = 0; i < fwd.n; ++i) fe[i] = overlap(c, fwd.ch[i].rpos[0]);
     for (int j = 0; j < bwd.n; ++j) re[j] = overlap(c, bwd.ch[j].rpos[0]);
     uint32_t ptype[(CM_BESTCHAINLIM * CM_BESTCHAINLIM * 2 + 31) / 32];   // 2 bits per (i,j): 0 none, 1..3 = type+1
@@ -2019,6 +2033,10 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             r2_genic = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
         }
     if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return mr.type;
+    const uint32_t fun = ~fpaired & (fwd.n >= 32 ? 0xffffffffu : ((1u << fwd.n) - 1u));
+    const uint32_t bun = ~bpaired & (bwd.n >= 32 ? 0xffffffffu : ((1u << bwd.n) - 1u));
+    CM_TICK(sm, 10);
+    if (!leftovers_matter(mr.type, min_ret1, min_ret1 != CM_CONCRD && fun != 0, min_ret2, min_ret2 != CM_CONCRD && bun != 0)) return mr.type;
     MM mm1 = mm_init(c);      // deliberately not reset between chains (stale looked_up_* caches, filter.cpp:356-370)
     if (min_ret1 != CM_CONCRD)
         for (int i = 0; i < fwd.n; ++i)
@@ -2030,6 +2048,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
                 overlap_to_epos(c, mm1);
                 r1_genic = (mm1.exons_spos >= 0) || (mm1.exons_epos >= 0);
             }
+    if (!leftovers_matter(mr.type, min_ret1, false, min_ret2, min_ret2 != CM_CONCRD && bun != 0)) return mr.type;
     MM mm2 = mm_init(c);
     if (min_ret2 != CM_CONCRD)
         for (int j = 0; j < bwd.n; ++j)
@@ -2043,6 +2062,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             }
     const int new_type = leftover_type(min_ret1, min_ret2, r1_genic, r2_genic);
     mr_update_type(mr, new_type);
+    CM_TICK(sm, 14);
     return mr.type;
 }
 

@@ -774,6 +774,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     const uint32_t fun = ~fp & (fwd.n >= 32 ? 0xffffffffu : ((1u << fwd.n) - 1u));
     const uint32_t bun = ~bp & (bwd.n >= 32 ? 0xffffffffu : ((1u << bwd.n) - 1u));
     const bool do_f = min_ret1 != CM_CONCRD && fun != 0, do_b = min_ret2 != CM_CONCRD && bun != 0;
+    if (!cmc::leftovers_matter(mr.type, min_ret1, do_f, min_ret2, do_b)) return mr.type;
     int ex = 99, genic = 0;
     {
         const bool back = lane >= 32;

@@ -14,7 +14,7 @@ b = cl.ReadBatch(d.seq1, d.seq2); hp.upload(b); ch, nc, hh = hp.chains(0); nc = 
 hp.reset(); hp.map_round(0, True); hp.sync()
 clk = np.zeros(b.n * 16, np.uint64); assert hp.L.cm_debug_lane_clk(hp.h, clk.ctypes.data) == 0
 st = hp.download()[0]; a = clk.reshape(-1, 16) / 100.0
-names = {1: 'pass1(pairing)', 2: 'pre-ext', 3: 'is_left', 4: 'middle_ed+concord', 5: 'chain_left l', 6: 'chain_left r', 7: 'chain_right r',
+names = {0: 'before process_mates (prologue / previous leftovers)', 14: 'leftover extensions', 1: 'pass1(pairing)', 2: 'pre-ext', 3: 'is_left', 4: 'middle_ed+concord', 5: 'chain_left l', 6: 'chain_left r', 7: 'chain_right r',
          8: 'chain_right l', 9: 'overlaps', 10: 'fold', 11: 'ext: trans loop', 12: 'ext: intron-ret DP', 13: 'tail(leftovers..)', 15: 'TOTAL'}
 cost = nc[:, 0] * nc[:, 3] + nc[:, 2] * nc[:, 1] + nc.sum(1)
 light = cost <= 8

@@ -1809,8 +1809,9 @@ struct Ext {
                 if (diff >= -c.P.band && diff <= c.P.band) {
                     SV ref;
                     if (!pac2char(c, rspos, rlen, ref)) ref = SV{c.X.genome, 0, 1, 2};    // defined as an all-NUL window
-                    if (diff >= 0) mid += one_side_banded(c, sm, q.sub(qspos), qlen, ref, rlen, diff);
-                    else mid += one_side_banded(c, sm, ref, rlen, q.sub(qspos), qlen, -diff);
+                    const SV qs = q.sub(qspos);
+                    const bool qf = diff >= 0;                      // one call site, arguments selected
+                    mid += one_side_banded(c, sm, qf ? qs : ref, qf ? qlen : rlen, qf ? ref : qs, qf ? rlen : qlen, qf ? diff : -diff);
                 }
                 if (mid > edth) return edth + 1;
             }
@@ -1919,8 +1920,8 @@ CM_HD inline void extend_task(const Core &c, const Ext &ext, const CH &F, const 
     r2.dir = -1;
     row = 0;
     is_left = is_left_chain(F, R, frd.len);
-    if (is_left) ok = ext.both_mates(F, R, tids, n_tid, frd, brd, r1, r2);
-    else ok = ext.both_mates(R, F, tids, n_tid, brd, frd, r2, r1);
+    // one call site (see process_read): left mate first, whichever read it is
+    ok = ext.both_mates(is_left ? F : R, is_left ? R : F, tids, n_tid, is_left ? frd : brd, is_left ? brd : frd, is_left ? r1 : r2, is_left ? r2 : r1);
     if (ok) {
         row = chr_row(c, is_left ? r1.spos : r2.spos);
         overlap_to_epos(c, r1); overlap_to_spos(c, r1);
@@ -2089,9 +2090,11 @@ CM_HD inline int process_read(const Core &c, const DpMem &sm, g_u8 s1, int len1,
     const Read r1f{s1, len1, 0}, r1b{s1, len1, 1}, r2f{s2, len2, 0}, r2b{s2, len2, 1};
     const bool first = lhs >= rhs;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        int a;
-        if ((attempt == 0) == first) a = process_mates(c, sm, sets[0], r1f, sets[3], r2b, mr, true, err);    // forward R1 / backward R2
-        else a = process_mates(c, sm, sets[2], r2f, sets[1], r1b, mr, false, err);                            // forward R2 / backward R1
+        // one call site for both orientations (arguments selected, not branched on): the lanes of a wave whose pairs
+        // have opposite orientations stay converged inside process_mates
+        const bool r1_fwd = (attempt == 0) == first;                   // forward R1 / backward R2, else forward R2 / backward R1
+        const int a = process_mates(c, sm, r1_fwd ? sets[0] : sets[2], r1_fwd ? r1f : r2f, r1_fwd ? sets[3] : sets[1], r1_fwd ? r2b : r1b, mr,
+                                    r1_fwd, err);
         if (c.P.scan_level == 0 && a == CM_CONCRD) return CM_CONCRD;
     }
     return mr.type;

@@ -1102,9 +1102,27 @@ CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n,
 
 // Staging + dispatch on the (wave-uniform) band.  `sm` = the lane's two staging buffers.
 #if defined(CM_DIAG) && defined(__HIPCC__)
-struct Tick { unsigned long long last; unsigned long long acc[16]; };
+// Diagnostic section timers.  acc[]: per-lane time between ticks (includes waiting for other lanes).
+// w (LDS, one per wave): w[0] = time of the wave's last tick, w[1+id] += wave time attributed to section id,
+// w[33+id] += that time x lanes arriving at the tick together.
+struct Tick { unsigned long long last; unsigned long long acc[32]; CM_L unsigned long long *w; int wave_on; };
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CM_TICK(sm_, id) do { const unsigned long long n_ = wall_clock64(); (sm_).tk->acc[id] += n_ - (sm_).tk->last; (sm_).tk->last = n_; } while (0)
+__device__ inline void cm_tick(Tick *tk, int id) {
+    const unsigned long long n_ = wall_clock64();
+    tk->acc[id] += n_ - tk->last;
+    tk->last = n_;
+    if (tk->wave_on) {
+        const unsigned long long m = __ballot(1);
+        const unsigned int me = __lane_id();
+        if (me == (unsigned int)(__ffsll((long long)m) - 1)) {
+            const unsigned long long dt = n_ - tk->w[0];
+            tk->w[1 + id] += dt;
+            tk->w[33 + id] += dt * (unsigned long long)__popcll(m);
+            tk->w[0] = n_;
+        }
+    }
+}
+#define CM_TICK(sm_, id) cm_tick((sm_).tk, id)
 #else
 #define CM_TICK(sm_, id) ((void)0)
 #endif
@@ -1145,18 +1163,24 @@ CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &
 }
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
+    CM_TICK(sm, 24);
     if (m >= 1 && n >= m && prefix_mismatches(s, t, m) == 0) {
         CM_STAT(9, 1);
         sc_len = 0;
         indel = 0;
         align_score = m * SC_MAT;
+        CM_TICK(sm, 25);
         return 0;
     }
+    CM_TICK(sm, 26);
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
     stage(s, n, sm.a, 4);
     stage(t, m, sm.b, 5);
-    return c.P.band == 3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
-                         : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+    CM_TICK(sm, 27);
+    const int r = c.P.band == 3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
+                                : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+    CM_TICK(sm, 28);
+    return r;
 }
 
 
@@ -1578,6 +1602,7 @@ struct Ext {
     }
     CM_HD bool middle_step(Memo &memo, const MemoKey &key, uint32_t pos, uint32_t exon_len, const SV &q, uint32_t qlen, int ed_th,
                            AlignRes &best, AlignRes &curr, AlignRes &exon_res, bool right, int &indel) const {
+        CM_TICK(sm, 20);
         const int f = memo_find(memo, key);
         if (f >= 0) {
             const AlignRes &r = memo.v[f];
@@ -1588,6 +1613,7 @@ struct Ext {
             return true;
         }
         const bool ok = extend_middle(pos, exon_len, q, qlen, ed_th, best, curr, exon_res, right);
+        CM_TICK(sm, 21);
         memo_put(memo, key, exon_res);
         if (!ok) return false;
         indel = exon_res.indel;
@@ -1595,15 +1621,19 @@ struct Ext {
     }
     CM_HD void end_step(Memo &memo, const MemoKey &key, uint32_t pos, uint32_t ref_len, const SV &q, int qlen, int ed_th, AlignRes &best,
                         AlignRes &curr, AlignRes &exon_res, bool right) const {
+        CM_TICK(sm, 16);
         const int f = memo_find(memo, key);
         if (f >= 0) {
             const AlignRes &r = memo.v[f];
             if ((curr.ed + r.ed > ed_th) || (r.sclen > c.P.max_sc) || (r.qcovlen - r.sclen < r.sclen)) return;
             ar_update(curr, r.ed, r.sclen, r.pos, r.indel, r.qcovlen, r.score);
             ar_by_score(best, curr, right);
+            CM_TICK(sm, 17);
         } else {
             extend_end(pos, ref_len, q, qlen, ed_th, best, curr, exon_res, right);
+            CM_TICK(sm, 18);
             memo_put(memo, key, exon_res);
+            CM_TICK(sm, 19);
         }
     }
 
@@ -1724,7 +1754,9 @@ struct Ext {
         Memo memo;
         memo.n = 0;
         int it_ind = -1, it_seg = -1;
+        CM_TICK(sm, 22);
         if (n_tid > 0) it_seg = overlap_ind(c, pos, it_ind);
+        CM_TICK(sm, 23);
         for (int i = 0; i < n_tid; ++i) {
             if (right) right_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
             else left_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);

@@ -203,9 +203,14 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
     const int str_stride = str_cap * BLK_PAIR;
 #endif
 #if defined(CM_DIAG)
+    __shared__ unsigned long long tick_w[65];
     cmc::Tick tick;
-    for (int i = 0; i < 16; ++i) tick.acc[i] = 0;
+    for (int i = 0; i < 32; ++i) tick.acc[i] = 0;
     tick.last = wall_clock64();
+    tick.w = (CM_L unsigned long long *)tick_w;
+    tick.wave_on = 1;
+    for (int i = threadIdx.x; i < 65; i += BLK_PAIR) tick_w[i] = i == 0 ? tick.last : 0ull;
+    __syncthreads();
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
@@ -240,6 +245,12 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
     if (lane_clk) {                                           // section timing study: 16 words per pair
         for (int i = 0; i < 15; ++i) lane_clk[p * 16 + i] = tick.acc[i];
         lane_clk[p * 16 + 15] = wall_clock64() - clk0;
+        // wave-level rows behind the per-pair rows (second half of the buffer): [wave][0] = wave time, [wave][1] = lane-weighted
+        const unsigned long long m = __ballot(1);
+        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) {
+            unsigned long long *wr = lane_clk + (unsigned long long)n_tile * 16 + (unsigned long long)blockIdx.x * 64;
+            for (int i = 0; i < 64; ++i) wr[i] = tick_w[1 + i];
+        }
     }
 #else
     if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
@@ -522,17 +533,30 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
 // unpaired-chain extensions; lane 0 folds the outcomes in the reference's order).  Everything else
 // stays one pair per lane in k_pair.
 constexpr int HEAVY_COST = 8;
-constexpr int N_BUCKETS = 8;
-// class of a pair for the pair stage: -2 inactive, -1 heavy (k_pair_heavy), else a bucket of the total
-// residual length of its best chains (bases left to extend = a proxy of its DP work).  k_pair walks the
-// light pairs bucket by bucket so the lanes of a wave carry similar work; results do not depend on order.
-__device__ inline int pair_class(const uint16_t *resid4, const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t t) {
-    if (!active[pair0 + t]) return -2;
-    const int a = nchain[4 * (uint64_t)t], b = nchain[4 * (uint64_t)t + 1], c = nchain[4 * (uint64_t)t + 2], d = nchain[4 * (uint64_t)t + 3];
-    if ((a * d + c * b + a + b + c + d) > HEAVY_COST) return -1;
+constexpr int N_BUCKETS = 7;             // residual-length buckets
+constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_heavy
+// class of a pair for the pair stage: -2 inactive, HEAVY_CLS heavy (k_pair_heavy), else
+// (genic ? 7 : 0) + bucket of the total residual length of its best chains (bases left to extend).
+// genic: some best chain starts inside an annotated exon, i.e. the pair will walk transcripts during extension
+// while the others only extend on the genome.  k_pair walks the light pairs class by class so the lanes of a
+// wave carry similar work; the classes are a heuristic, results do not depend on them.
+// (Measured: a "some residual is inexact" flag as a further key costs as much in k_pair_cls as it saves in k_pair.)
+__device__ inline int pair_class(const Core &c, const cm_chain *chains, const uint16_t *resid4, const int32_t *nchain,
+                                 const uint8_t *active, uint64_t pair0, uint32_t t) {
+    const uint64_t p = pair0 + t;
+    if (!active[p]) return -2;
+    const int32_t *nc = nchain + 4 * (uint64_t)t;
+    const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
+    if ((a * d + cc * b + a + b + cc + d) > HEAVY_COST) return HEAVY_CLS;
     const uint16_t *q = resid4 + 4 * (uint64_t)t;
     const int resid = (int)q[0] + q[1] + q[2] + q[3];
-    return resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : resid < 400 ? 6 : 7;
+    const int bucket = resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : 6;
+    bool genic = false;
+    for (int x = 0; x < 4 && !genic; ++x) {
+        if (nc[x] <= 0) continue;
+        genic = cmc::overlap(c, chains[((uint64_t)t * 4 + x) * CM_BESTCHAINLIM].rpos[0]) >= 0;
+    }
+    return (genic ? N_BUCKETS : 0) + bucket;
 }
 // Atomic-free counting sort of the tile's pairs by class (bucket 0..7, heavy = class 8):
 // k_cls_count: class per pair + per-block class histogram;  k_cls_scan: one workgroup turns the
@@ -540,7 +564,7 @@ __device__ inline int pair_class(const uint16_t *resid4, const int32_t *nchain, 
 // k_cls_place: writes perm[] (light pairs) / hlist[] (heavy pairs) at base + rank inside the block.
 constexpr int CHAIN_LIGHT_CLS = 12;     // chaining classes below this are light
 constexpr int CLS_T = 1024;            // threads per block = 16 waves
-constexpr int N_CLS = 16;                // classes a sort can use (pairs: 0..7 light + 8 heavy; chaining: 0..11 light + 12..15 heavy)
+constexpr int N_CLS = 16;                // classes a sort can use (pairs: 0..13 light + 15 heavy; chaining: 0..11 light + 12..15 heavy)
 constexpr int CTR_SUM = 16, CTR_BASE = 32, CTR_WORDS = 64;
 __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], unsigned int &rank_in_wave, int lane, int wave) {
     // wcnt[w][c] = number of lanes of wave w with class c; rank_in_wave = rank of this lane among its class in its wave
@@ -552,12 +576,13 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
         if (k == c) rank_in_wave = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
     }
 }
-__global__ void __launch_bounds__(BLK) k_pair_cls(const uint16_t *resid, const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile,
-                                                 int8_t *cls, int32_t *cat) {
+__global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, ReadsDev rd, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
+                                                 const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
-    const int k = pair_class(resid, nchain, active, pair0, t);
-    cls[t] = (int8_t)(k == -1 ? N_BUCKETS : k);       // heavy -> class 8, inactive stays -2
+    const Core c = cmc::to_core(kc);
+    const int k = pair_class(c, chains, resid, nchain, active, pair0, t);
+    cls[t] = (int8_t)k;
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
@@ -658,7 +683,7 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
         unsigned int before = 0;
         for (int w = 0; w < wave; ++w) before += wcnt[w][k];
         const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
-        if (k == N_BUCKETS && hlist) hlist[pos] = t;
+        if (k == HEAVY_CLS && hlist) hlist[pos] = t;
         else perm[ctr[CTR_BASE + k] + pos] = t;
     }
 }
@@ -826,6 +851,8 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
 #endif
 #if defined(CM_DIAG)
     cmc::Tick tick{};
+    tick.w = nullptr;
+    tick.wave_on = 0;
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
@@ -1396,7 +1423,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
-        const size_t clk_words = 16;
+        const size_t clk_words = 16 * 2;      // per-pair rows + wave-level rows (k_pair, diag)
 #else
         const size_t clk_words = 1;
 #endif
@@ -1436,10 +1463,10 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
-            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_resid, ctx->d_nchain, ctx->d_active, p0, nt,
-                               ctx->d_cls, ctx->d_cat);
+            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
+                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, N_BUCKETS, N_BUCKETS + 1);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, HEAVY_CLS, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
                                ctx->d_hlist);
             ctx->launches[5] += 4;
@@ -1454,7 +1481,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             {
             Timer t(ctx, 4);
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
-            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + 8,
+            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS,
                                ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
                                ctx->d_counters, str_cap);
             ++ctx->launches[4];
@@ -1622,7 +1649,7 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) {
     if (!ctx || !out || !ctx->d_lane_clk) return CM_EINVAL;
 #if defined(CM_DIAG)
-    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8 * 16, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8 * 32, hipMemcpyDeviceToHost));
 #else
     HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8, hipMemcpyDeviceToHost));
 #endif

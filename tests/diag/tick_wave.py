@@ -1,0 +1,25 @@
+"""Wave-level section accounting of k_pair (diag build): wave time per section and average active lanes."""
+import os, sys, ctypes as C, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ['CM_LIB'] = os.path.join(ROOT, 'tests/_hostemu/libcmhot_diag.so'); os.environ['CM_LANE_CLK'] = '1'
+from circminer_amd import lib as cl, synth
+N = 262144
+d = synth.generate('chr21', n_pairs=N, seed=21)
+open('/tmp/c.gtf', 'w').write(d.gtf_text)
+hi = cl.HostIndex(d.contigs, d.chr_table, '/tmp/c.gtf')
+P = cl.default_params(); hp = cl.HotPath(P); hp.load_contig(0, hi.views[0], hi.annots[0])
+hp.L.cm_debug_lane_clk.argtypes = [C.c_void_p, C.c_void_p]
+b = cl.ReadBatch(d.seq1, d.seq2); hp.upload(b)
+hp.reset(); hp.map_round(0, True); hp.sync()
+clk = np.zeros(b.n * 32, np.uint64); assert hp.L.cm_debug_lane_clk(hp.h, clk.ctypes.data) == 0
+w = clk[b.n * 16:].reshape(-1, 64).astype(np.float64)
+w = w[w.sum(1) > 0]
+wt, lt = w[:, :32].sum(0) / 100.0, w[:, 32:].sum(0) / 100.0
+names = {0: 'process_mates entry (prologue)', 1: 'pass1 (pairing predicate)', 2: 'pre-ext (tids, CH copies)', 3: 'is_left + both_mates entry', 4: 'middle_ed + is_concord',
+         5: 'LL extension', 6: 'RL extension', 7: 'RR extension', 8: 'LR extension', 9: 'overlaps (exon lookups)', 10: 'fold', 11: 'ext: transcript loop (rest)', 16: 'trans walk -> end_step', 17: 'end_step memo hit', 18: 'end_step extend_end (pac2char + DP)', 19: 'end_step memo_put',
+         20: 'trans walk -> middle_step', 21: 'middle_step extend_middle', 22: 'extend_side entry', 24: 'sc: entry (code before the DP call)', 25: 'sc: exact -> closed form', 26: 'sc: inexact compare', 27: 'sc: staging', 28: 'sc: X-drop DP', 23: 'extend_side overlap_ind',
+         12: 'ext: genomic DP', 13: 'tail (finish, stores)', 14: 'leftover extensions'}
+print('waves %d, wave time total %.0f us, mean %.0f us/wave, overall active lanes %.1f' % (len(w), wt.sum(), wt.sum() / len(w), lt.sum() / wt.sum()))
+for k in sorted(names):
+    if wt[k] > 0: print('  %-34s share %5.1f%%   active lanes %5.1f' % (names[k], 100 * wt[k] / wt.sum(), lt[k] / wt[k]))

@@ -542,12 +542,12 @@ constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_
 // wave carry similar work; the classes are a heuristic, results do not depend on them.
 // (Measured: a "some residual is inexact" flag as a further key costs as much in k_pair_cls as it saves in k_pair.)
 __device__ inline int pair_class(const Core &c, const cm_chain *chains, const uint16_t *resid4, const int32_t *nchain,
-                                 const uint8_t *active, uint64_t pair0, uint32_t t) {
+                                 const uint8_t *active, uint64_t pair0, uint32_t t, int heavy_cost) {
     const uint64_t p = pair0 + t;
     if (!active[p]) return -2;
     const int32_t *nc = nchain + 4 * (uint64_t)t;
     const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
-    if ((a * d + cc * b + a + b + cc + d) > HEAVY_COST) return HEAVY_CLS;
+    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) return HEAVY_CLS;
     const uint16_t *q = resid4 + 4 * (uint64_t)t;
     const int resid = (int)q[0] + q[1] + q[2] + q[3];
     const int bucket = resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : 6;
@@ -577,11 +577,11 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
     }
 }
 __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, ReadsDev rd, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
-                                                 const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat) {
+                                                 const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
-    const int k = pair_class(c, chains, resid, nchain, active, pair0, t);
+    const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost);
     cls[t] = (int8_t)k;
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
@@ -738,6 +738,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
         bp |= __shfl_xor(bp, o);
     }
     __syncthreads();
+    CM_TICK(sm, 29);
     int ntask = 0;
     for (int base = 0; base < T; base += 64) {
         const int idx = base + lane;
@@ -768,6 +769,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
             H.res[lane].is_left = il;
         }
         __syncthreads();
+        CM_TICK(sm, 30);
         int early = 0;
         if (lane == 0) {
             const int cnt = (ntask - b0 < 64) ? ntask - b0 : 64;
@@ -785,6 +787,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
         }
         early = __shfl(early, 0);
         __syncthreads();
+        CM_TICK(sm, 31);
         if (early) return CM_CONCRD;
     }
     mr.type = __shfl(mr.type, 0);
@@ -817,6 +820,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
             }
         }
     }
+    CM_TICK(sm, 15);
     const int exf = wave_min(lane < 32 ? ex : 99), exb = wave_min(lane >= 32 ? ex : 99);
     const int gf = __shfl(genic, 0), gb = __shfl(genic, 32);
     if (do_f) {
@@ -834,7 +838,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
 __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
-                                                         int str_cap) {
+                                                         int str_cap, unsigned long long *dbg_rows) {
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
@@ -850,9 +854,13 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
     const int str_stride = str_cap * BLK_PAIR;
 #endif
 #if defined(CM_DIAG)
+    __shared__ unsigned long long tick_w[65];
     cmc::Tick tick{};
-    tick.w = nullptr;
-    tick.wave_on = 0;
+    tick.w = (CM_L unsigned long long *)tick_w;
+    tick.wave_on = 1;
+    tick.last = wall_clock64();
+    for (int i = threadIdx.x; i < 65; i += BLK_PAIR) tick_w[i] = i == 0 ? tick.last : 0ull;
+    __syncthreads();
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
@@ -916,7 +924,12 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
             atomicAdd(&counters[3], 1ull);
         }
         __syncthreads();
+        CM_TICK(sm, 13);
     }
+#if defined(CM_DIAG)
+    if (dbg_rows && lane == 0)
+        for (int i = 0; i < 64; ++i) dbg_rows[(size_t)blockIdx.x * 64 + i] = tick_w[1 + i];
+#endif
 }
 
 __global__ void __launch_bounds__(BLK) k_active_cls(const uint8_t *active, uint64_t n, int8_t *cls) {
@@ -1423,7 +1436,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
-        const size_t clk_words = 16 * 2;      // per-pair rows + wave-level rows (k_pair, diag)
+        const size_t clk_words = 16 * 2 + 1;  // per-pair rows + wave-level rows of k_pair and k_pair_heavy (diag)
 #else
         const size_t clk_words = 1;
 #endif
@@ -1463,8 +1476,9 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
+            static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
-                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat);
+                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, HEAVY_CLS, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
@@ -1483,7 +1497,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
             hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS,
                                ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
-                               ctx->d_counters, str_cap);
+                               ctx->d_counters, str_cap, ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr);
             ++ctx->launches[4];
             }
             HIPCHK(ctx, hipGetLastError());
@@ -1649,7 +1663,7 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) {
     if (!ctx || !out || !ctx->d_lane_clk) return CM_EINVAL;
 #if defined(CM_DIAG)
-    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8 * 32, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8 * 33, hipMemcpyDeviceToHost));
 #else
     HIPCHK(ctx, hipMemcpy(out, ctx->d_lane_clk, ctx->n_pairs * 8, hipMemcpyDeviceToHost));
 #endif

@@ -12,8 +12,10 @@ P = cl.default_params(); hp = cl.HotPath(P); hp.load_contig(0, hi.views[0], hi.a
 hp.L.cm_debug_lane_clk.argtypes = [C.c_void_p, C.c_void_p]
 b = cl.ReadBatch(d.seq1, d.seq2); hp.upload(b)
 hp.reset(); hp.map_round(0, True); hp.sync()
-clk = np.zeros(b.n * 32, np.uint64); assert hp.L.cm_debug_lane_clk(hp.h, clk.ctypes.data) == 0
-w = clk[b.n * 16:].reshape(-1, 64).astype(np.float64)
+clk = np.zeros(b.n * 33, np.uint64); assert hp.L.cm_debug_lane_clk(hp.h, clk.ctypes.data) == 0
+nw = b.n // 64 + 1
+w = clk[b.n * 16: b.n * 16 + nw * 64].reshape(-1, 64).astype(np.float64)
+wh = clk[b.n * 16 + nw * 64: b.n * 16 + nw * 64 + 4096 * 64].reshape(-1, 64).astype(np.float64)
 w = w[w.sum(1) > 0]
 wt, lt = w[:, :32].sum(0) / 100.0, w[:, 32:].sum(0) / 100.0
 names = {0: 'process_mates entry (prologue)', 1: 'pass1 (pairing predicate)', 2: 'pre-ext (tids, CH copies)', 3: 'is_left + both_mates entry', 4: 'middle_ed + is_concord',
@@ -23,3 +25,10 @@ names = {0: 'process_mates entry (prologue)', 1: 'pass1 (pairing predicate)', 2:
 print('waves %d, wave time total %.0f us, mean %.0f us/wave, overall active lanes %.1f' % (len(w), wt.sum(), wt.sum() / len(w), lt.sum() / wt.sum()))
 for k in sorted(names):
     if wt[k] > 0: print('  %-34s share %5.1f%%   active lanes %5.1f' % (names[k], 100 * wt[k] / wt.sum(), lt[k] / wt[k]))
+
+wh = wh[wh.sum(1) > 0]
+wt, lt = wh[:, :32].sum(0) / 100.0, wh[:, 32:].sum(0) / 100.0
+names.update({29: 'heavy: pass1 predicate (parallel)', 30: 'heavy: pair tasks (parallel extend_task)', 31: 'heavy: fold (lane 0)', 15: 'heavy: unpaired-chain extensions', 13: 'heavy: finish'})
+print('k_pair_heavy blocks %d, block time total %.0f us, lanes at ticks %.1f' % (len(wh), wt.sum(), lt.sum() / max(wt.sum(), 1)))
+for k in sorted(names):
+    if wt[k] > 0: print('  %-34s share %5.1f%%   lanes at tick %5.1f' % (names[k], 100 * wt[k] / wt.sum(), lt[k] / wt[k]))

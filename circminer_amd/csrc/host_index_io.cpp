@@ -1,0 +1,501 @@
+// On-disk genome / index formats of stock CircMiner, host side only.
+//
+//   <ref>.packed.fa            FASTA whose records are the packed contigs ">1", ">2", ...: chromosomes
+//                              concatenated with a 50-N spacer while they fit CONTIG_SIZE
+//                              (reference src/genome.cpp:96-146);
+//   <ref>.packed.fa.index.info "contig \t start \t end \t chrName" per chromosome, 0-based start inside its
+//                              packed contig (src/genome.cpp:127-137, read back at :147-167);
+//   <ref>.packed.fa.index      mrsfast hash-table file (src/mrsfast/HashTable.c):
+//       header  u8 magic (2 compact / 3 full table) | u8 WINDOW_SIZE | u8 checkSumLength | u32 maxMemSize
+//               | u32 ioBufferSize | u32 CONTIG_MAX_SIZE | i32 nRecords | {i32 nameLen, name, i32 len} x nRecords
+//               (:106-127; maxMemSize patched at offset 3 by finalizeSavingIHashTable :131-137)
+//       per packed contig  u8 moreFollows | i16 nameLen | name | i32 offset | u32 refLen
+//               | u64 packed[ceil(refLen / 21)] (3 bits per base, first base in bits 62..60)
+//               | u32 nBuckets | { i32 nBytes, varbyte(hvDelta), varbyte(count14) ... } blocks
+//               | (full table only) u32 memSize | GeneralIndex[memSize]                      (:197-254)
+//       GeneralIndex = { u16 checksum; (2 bytes padding); i32 info } = 8 bytes.  A bucket owns count14 + 1
+//       slots: [0].info = number of valid entries, then the entries sorted by (checksum, info = 1-based
+//       start) (:824-839, Sort.c:116-117), then slack slots for 14-mers whose full k-mer is invalid.
+//       The reference never initialises the padding bytes, the header slots' checksum and the slack
+//       slots; this writer zeroes them, the reader ignores them.
+//   varbyte: 7-bit little-endian groups, the last byte carries 0x80 (:74-98).
+//
+// The FASTA loader of the reference lives in the absent mrsfast submodule (RefGenome.c); its contract is
+// fixed by the in-tree callers (HashTable.c:288-293, 618-633): one record = one contig, bases upper-cased,
+// anything but A/C/G/T becomes N, offset 0.
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "circminer_hot.h"
+
+namespace {
+
+constexpr int MIDNCNT = 50;                 // src/genome.cpp:16
+constexpr uint32_t IO_BUFFER = 1u << 24;    // HashTable.c:60
+constexpr uint32_t CONTIG_MAX_SIZE_DEF = 1300000000u;   // src/common.h:82
+
+struct Fasta {
+    std::vector<std::string> id, seq;
+};
+
+// GenomePacker::get_next_chr (src/genome.cpp:73-94): id = first token after '>', every following line
+// contributes its first whitespace-delimited token.
+bool read_fasta(const char *path, Fasta &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    std::string line;
+    int ch;
+    bool have = false;
+    auto flush_line = [&]() {
+        if (line.empty()) return;
+        if (line[0] == '>') {
+            size_t a = 1, b = 1;
+            while (b < line.size() && !isspace((unsigned char)line[b])) ++b;
+            out.id.push_back(line.substr(a, b - a));
+            out.seq.emplace_back();
+            have = true;
+        } else if (have) {
+            size_t a = 0;
+            while (a < line.size() && isspace((unsigned char)line[a])) ++a;
+            size_t b = a;
+            while (b < line.size() && !isspace((unsigned char)line[b])) ++b;
+            out.seq.back().append(line, a, b - a);
+        }
+        line.clear();
+    };
+    while ((ch = fgetc(f)) != EOF) {
+        if (ch == '\n') flush_line();
+        else line.push_back((char)ch);
+    }
+    flush_line();
+    fclose(f);
+    return true;
+}
+
+inline int code3(char ch) {
+    switch (ch) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return 4;
+    }
+}
+
+int encode_varbyte(uint8_t *buf, uint32_t v) {          // HashTable.c:74-83
+    int t = 0;
+    do {
+        buf[t++] = (uint8_t)(v & 127u);
+        v /= 128u;
+    } while (v != 0);
+    buf[t - 1] |= 128u;
+    return t;
+}
+int decode_varbyte(const uint8_t *buf, size_t avail, uint32_t *res) {     // HashTable.c:87-98
+    size_t i = 0;
+    uint32_t r = 0;
+    uint8_t t;
+    do {
+        if (i >= avail || i >= 5) return -1;
+        t = buf[i];
+        r |= (uint32_t)(t & 127u) << (7 * i);
+        ++i;
+    } while ((t & 128u) == 0);
+    *res = r;
+    return (int)i;
+}
+
+template <class T> bool put(FILE *f, const T &v) { return fwrite(&v, sizeof(T), 1, f) == 1; }
+template <class T> bool get(FILE *f, T &v) { return fread(&v, sizeof(T), 1, f) == 1; }
+
+struct Entry {              // GeneralIndex as it is laid out in the file
+    uint16_t checksum;
+    uint16_t pad;
+    int32_t info;
+};
+static_assert(sizeof(Entry) == 8, "GeneralIndex is 8 bytes");
+
+uint32_t io_buffer_size() {           // test hook: a small buffer exercises the block splitting of saveHashTable
+    const char *e = getenv("CM_INDEX_IOBUF");
+    const long v = e ? atol(e) : 0;
+    return v >= 64 ? (uint32_t)v : IO_BUFFER;
+}
+
+}  // namespace
+
+struct cm_index_file {
+    FILE *f = nullptr;
+    int window = 0, checksum_len = 0, full = 0;
+    uint32_t max_mem = 0, io_buf = 0, contig_max = 0;
+    std::vector<std::string> names;
+    std::vector<int32_t> lens;
+    bool done = false;
+};
+
+extern "C" {
+
+int cm_host_pack_genome(const char *fasta_path, const char *packed_fa_path, const char *index_info_path, uint32_t contig_size) {
+    if (!fasta_path || !packed_fa_path || !index_info_path || contig_size == 0) return CM_EINVAL;
+    Fasta fa;
+    if (!read_fasta(fasta_path, fa)) return CM_EINVAL;
+    FILE *fo = fopen(packed_fa_path, "wb"), *fi = fopen(index_info_path, "wb");
+    if (!fo || !fi) {
+        if (fo) fclose(fo);
+        if (fi) fclose(fi);
+        return CM_EINVAL;
+    }
+    const std::string mid(MIDNCNT, 'N');
+    int contig_num = 0;
+    long long cur = 0;            // the reference keeps this in an int (src/genome.cpp:104)
+    for (size_t r = 0; r < fa.id.size(); ++r) {
+        const long long len = (long long)fa.seq[r].size();
+        if (cur == 0 || len + MIDNCNT + cur > (long long)contig_size) {
+            ++contig_num;
+            cur = 0;
+            fprintf(fo, ">%d\n%s\n", contig_num, fa.seq[r].c_str());
+            fprintf(fi, "%d\t%lld\t%lld\t%s\n", contig_num, cur, cur + len, fa.id[r].c_str());
+            cur += len;
+        } else {
+            fprintf(fo, "%s%s\n", mid.c_str(), fa.seq[r].c_str());
+            fprintf(fi, "%d\t%lld\t%lld\t%s\n", contig_num, cur + MIDNCNT, cur + MIDNCNT + len, fa.id[r].c_str());
+            cur += MIDNCNT + len;
+        }
+    }
+    fclose(fo);
+    fclose(fi);
+    return CM_OK;
+}
+
+int cm_host_read_index_info(const char *path, cm_chr_info **out, uint32_t *n) {
+    if (!path || !out || !n) return CM_EINVAL;
+    *out = nullptr;
+    *n = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return CM_EINVAL;
+    std::vector<cm_chr_info> v;
+    unsigned int contig, s, e;
+    char name[4096];
+    while (fscanf(f, "%u %u %u %4095s", &contig, &s, &e, name) == 4) {     // GenomePacker::load_index_info
+        cm_chr_info ci;
+        char *nm = (char *)malloc(strlen(name) + 1);
+        strcpy(nm, name);
+        ci.name = nm;
+        ci.contig_id = contig;
+        ci.start_pos = s;
+        ci.len = e - s;
+        v.push_back(ci);
+    }
+    fclose(f);
+    cm_chr_info *arr = (cm_chr_info *)malloc((v.size() ? v.size() : 1) * sizeof(cm_chr_info));
+    if (!arr) return CM_ENOMEM;
+    for (size_t i = 0; i < v.size(); ++i) arr[i] = v[i];
+    *out = arr;
+    *n = (uint32_t)v.size();
+    return CM_OK;
+}
+
+void cm_host_free_index_info(cm_chr_info *chrs, uint32_t n) {
+    if (!chrs) return;
+    for (uint32_t i = 0; i < n; ++i) free((void *)chrs[i].name);
+    free(chrs);
+}
+
+int cm_host_write_index(const char *packed_fa_path, const char *index_path, int32_t kmer, int compact, int n_threads) {
+    if (!packed_fa_path || !index_path || kmer < CM_WINDOW_SIZE || kmer > CM_WINDOW_SIZE + 8) return CM_EINVAL;
+    Fasta fa;
+    if (!read_fasta(packed_fa_path, fa) || fa.id.empty()) return CM_EINVAL;
+    for (auto &s : fa.seq)                                   // loadRefGenome contract: upper-case, non-ACGT -> N
+        for (auto &ch : s) {
+            const char u = (char)toupper((unsigned char)ch);
+            ch = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : 'N';
+        }
+    FILE *f = fopen(index_path, "wb");
+    if (!f) return CM_EINVAL;
+    const uint8_t magic = compact ? 2 : 3, W = CM_WINDOW_SIZE;
+    const int8_t c = (int8_t)(kmer - CM_WINDOW_SIZE);
+    uint32_t max_mem = 0;
+    const uint32_t io_buf = io_buffer_size(), cmax = CONTIG_MAX_SIZE_DEF;
+    bool ok = put(f, magic) && put(f, W) && put(f, c) && put(f, max_mem) && put(f, io_buf) && put(f, cmax);
+    const int32_t nrec = (int32_t)fa.id.size();
+    ok = ok && put(f, nrec);
+    for (int32_t r = 0; r < nrec && ok; ++r) {
+        const int32_t nl = (int32_t)fa.id[r].size(), len = (int32_t)fa.seq[r].size();
+        ok = put(f, nl) && fwrite(fa.id[r].data(), 1, (size_t)nl, f) == (size_t)nl && put(f, len);
+    }
+    const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
+    std::vector<uint32_t> cnt14(nb);
+    std::vector<uint8_t> buf(io_buf);
+    int rc = CM_OK;
+    for (int32_t r = 0; r < nrec && ok && rc == CM_OK; ++r) {
+        const std::string &g = fa.seq[r];
+        const uint32_t n = (uint32_t)g.size();
+        const uint8_t more = (r + 1 < nrec) ? 1 : 0;
+        const int16_t nl = (int16_t)fa.id[r].size();
+        const int32_t off = 0;
+        ok = put(f, more) && put(f, nl) && fwrite(fa.id[r].data(), 1, (size_t)nl, f) == (size_t)nl && put(f, off) && put(f, n);
+        // compressSequence: 21 bases per word, 3 bits each, first base in bits 62..60, last word left-aligned
+        const uint32_t nw = n / 21 + (n % 21 != 0);
+        std::vector<uint64_t> packed(nw, 0);
+        for (uint32_t i = 0; i < n; ++i) packed[i / 21] |= (uint64_t)code3(g[i]) << (60 - 3 * (i % 21));
+        ok = ok && (nw == 0 || fwrite(packed.data(), 8, nw, f) == nw);
+        // count pass (HashTable.c:317-338): every 14-mer window without N
+        std::fill(cnt14.begin(), cnt14.end(), 0u);
+        uint32_t nbuckets = 0;
+        {
+            uint32_t hv = 0;
+            int run = 0;
+            const uint32_t mask = (uint32_t)(nb - 1);
+            for (uint32_t i = 0; i < n; ++i) {
+                const int v = code3(g[i]);
+                if (v == 4) {
+                    run = 0;
+                    hv = 0;
+                    continue;
+                }
+                hv = ((hv << 2) | (uint32_t)v) & mask;
+                if (++run >= CM_WINDOW_SIZE && cnt14[hv]++ == 0) ++nbuckets;
+            }
+        }
+        ok = ok && put(f, nbuckets);
+        uint64_t mem = 0;
+        {
+            uint32_t k = 0, prev = 0;
+            for (uint64_t h = 0; h < nb && ok; ++h) {
+                if (!cnt14[h]) continue;
+                mem += (uint64_t)cnt14[h] + 1;
+                k += (uint32_t)encode_varbyte(buf.data() + k, (uint32_t)(h - prev));
+                prev = (uint32_t)h;
+                k += (uint32_t)encode_varbyte(buf.data() + k, cnt14[h]);
+                if (k > io_buf - 10) {
+                    const int32_t kk = (int32_t)k;
+                    ok = put(f, kk) && fwrite(buf.data(), 1, k, f) == k;
+                    k = 0;
+                }
+            }
+            if (k && ok) {
+                const int32_t kk = (int32_t)k;
+                ok = put(f, kk) && fwrite(buf.data(), 1, k, f) == k;
+            }
+        }
+        if (mem > 0xffffffffull) {
+            rc = CM_ELIMIT;
+            break;
+        }
+        if ((uint32_t)mem > max_mem) max_mem = (uint32_t)mem;
+        if (!compact && ok) {
+            cm_index_view iv{};
+            rc = cm_host_build_index((const uint8_t *)g.data(), n, kmer, r, n_threads, &iv);
+            if (rc != CM_OK) break;
+            const uint32_t memsz = (uint32_t)mem;
+            ok = put(f, memsz);
+            std::vector<Entry> slab;
+            slab.reserve(1u << 16);
+            for (uint64_t h = 0; h < nb && ok; ++h) {
+                if (!cnt14[h]) continue;
+                const uint32_t a = iv.bucket_off[h], b = iv.bucket_off[h + 1];
+                slab.push_back(Entry{0, 0, (int32_t)(b - a)});
+                for (uint32_t i = a; i < b; ++i) slab.push_back(Entry{iv.checksum[i], 0, (int32_t)iv.pos[i]});
+                for (uint32_t i = b - a; i < cnt14[h]; ++i) slab.push_back(Entry{0, 0, 0});
+                if (slab.size() >= (1u << 16)) {
+                    ok = fwrite(slab.data(), sizeof(Entry), slab.size(), f) == slab.size();
+                    slab.clear();
+                }
+            }
+            if (ok && !slab.empty()) ok = fwrite(slab.data(), sizeof(Entry), slab.size(), f) == slab.size();
+            cm_host_free_index(&iv);
+        }
+    }
+    if (ok && rc == CM_OK) {
+        ok = fseek(f, 3, SEEK_SET) == 0 && put(f, max_mem);           // finalizeSavingIHashTable
+    }
+    fclose(f);
+    if (rc != CM_OK) return rc;
+    return ok ? CM_OK : CM_EINVAL;
+}
+
+int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kmer, int32_t *is_full, uint32_t *n_records) {
+    if (!index_path || !out) return CM_EINVAL;
+    *out = nullptr;
+    FILE *f = fopen(index_path, "rb");
+    if (!f) return CM_EINVAL;
+    cm_index_file *x = new cm_index_file();
+    x->f = f;
+    uint8_t magic = 0, W = 0;
+    int8_t c = 0;
+    int32_t nrec = 0;
+    bool ok = get(f, magic) && get(f, W) && get(f, c) && get(f, x->max_mem) && get(f, x->io_buf) && get(f, x->contig_max) && get(f, nrec);
+    if (!ok || (magic != 2 && magic != 3) || W != CM_WINDOW_SIZE || c < 0 || c > 8 || nrec < 0) {   // checkHashTable :485-509
+        fclose(f);
+        delete x;
+        return CM_EINVAL;
+    }
+    for (int32_t r = 0; r < nrec && ok; ++r) {
+        int32_t nl = 0, len = 0;
+        ok = get(f, nl) && nl >= 0 && nl < 4096;
+        std::string nm((size_t)(ok ? nl : 0), '\0');
+        ok = ok && (nl == 0 || fread(&nm[0], 1, (size_t)nl, f) == (size_t)nl) && get(f, len);
+        x->names.push_back(nm);
+        x->lens.push_back(len);
+    }
+    if (!ok) {
+        fclose(f);
+        delete x;
+        return CM_EINVAL;
+    }
+    x->window = W;
+    x->checksum_len = c;
+    x->full = magic == 3;
+    if (kmer) *kmer = W + c;
+    if (is_full) *is_full = x->full;
+    if (n_records) *n_records = (uint32_t)nrec;
+    *out = x;
+    return CM_OK;
+}
+
+// Loads the next packed contig (loadHashTable, HashTable.c:971-1098): genome decoded to ASCII
+// (pac2char_whole_contig, src/match_read.cpp:301-332) and the table in the flattened layout of
+// cm_index_view.  Returns CM_OK and *loaded = 1, or *loaded = 0 after the last contig.
+// The view (including its genome) is released with cm_host_free_loaded_contig.
+int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded) {
+    if (!x || !out || !loaded) return CM_EINVAL;
+    *loaded = 0;
+    if (x->done) return CM_OK;
+    FILE *f = x->f;
+    uint8_t more = 0;
+    if (!get(f, more)) {
+        x->done = true;
+        return CM_OK;
+    }
+    int16_t nl = 0;
+    int32_t off = 0;
+    uint32_t n = 0;
+    char name[4096];
+    if (!get(f, nl) || nl < 0 || nl >= 4096 || (nl && fread(name, 1, (size_t)nl, f) != (size_t)nl) || !get(f, off) || !get(f, n)) return CM_EINVAL;
+    name[nl] = 0;
+    const uint32_t nw = n / 21 + (n % 21 != 0);
+    std::vector<uint64_t> packed(nw);
+    if (nw && fread(packed.data(), 8, nw, f) != nw) return CM_EINVAL;
+    uint8_t *g = (uint8_t *)malloc((size_t)n + 1);
+    if (!g) return CM_ENOMEM;
+    for (uint32_t i = 0; i < n; ++i) g[i] = (uint8_t)"ACGTNNNN"[(packed[i / 21] >> (60 - 3 * (i % 21))) & 7u];
+    g[n] = 0;
+    uint32_t nbuckets = 0;
+    if (!get(f, nbuckets)) {
+        free(g);
+        return CM_EINVAL;
+    }
+    const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
+    std::vector<uint32_t> hvs, cnts;
+    hvs.reserve(nbuckets);
+    cnts.reserve(nbuckets);
+    std::vector<uint8_t> buf;
+    uint64_t hv = 0, mem = 0;
+    for (uint32_t i = 0; i < nbuckets;) {
+        int32_t bytes = 0;
+        if (!get(f, bytes) || bytes <= 0) {
+            free(g);
+            return CM_EINVAL;
+        }
+        buf.resize((size_t)bytes);
+        if (fread(buf.data(), 1, (size_t)bytes, f) != (size_t)bytes) {
+            free(g);
+            return CM_EINVAL;
+        }
+        size_t idx = 0;
+        while (idx < (size_t)bytes) {
+            uint32_t d = 0, cn = 0;
+            int a = decode_varbyte(buf.data() + idx, (size_t)bytes - idx, &d);
+            if (a < 0) { free(g); return CM_EINVAL; }
+            idx += (size_t)a;
+            a = decode_varbyte(buf.data() + idx, (size_t)bytes - idx, &cn);
+            if (a < 0) { free(g); return CM_EINVAL; }
+            idx += (size_t)a;
+            hv += d;
+            if (hv >= nb) { free(g); return CM_EINVAL; }
+            hvs.push_back((uint32_t)hv);
+            cnts.push_back(cn);
+            mem += (uint64_t)cn + 1;
+            ++i;
+        }
+    }
+    const int kmer = x->window + x->checksum_len;
+    const int contig_num = atoi(name) - 1;            // contigNum of the mapping loop, src/circminer.cpp:266-267
+    int rc = CM_OK;
+    if (x->full) {
+        uint32_t memsz = 0;
+        if (!get(f, memsz) || memsz != mem) {
+            free(g);
+            return CM_EINVAL;
+        }
+        std::vector<Entry> tab(memsz);
+        if (memsz && fread(tab.data(), sizeof(Entry), memsz, f) != memsz) {
+            free(g);
+            return CM_EINVAL;
+        }
+        uint32_t *boff = (uint32_t *)calloc(nb + 1, sizeof(uint32_t));
+        uint64_t total = 0, cur = 0;
+        bool ok = boff != nullptr;
+        for (size_t b = 0; b < hvs.size() && ok; ++b) {
+            const int32_t c = tab[cur].info;
+            ok = c >= 0 && (uint32_t)c <= cnts[b];
+            boff[hvs[b] + 1] = ok ? (uint32_t)c : 0u;
+            total += ok ? (uint32_t)c : 0u;
+            cur += (uint64_t)cnts[b] + 1;
+        }
+        uint16_t *cs = (uint16_t *)malloc((total ? total : 1) * sizeof(uint16_t));
+        uint32_t *ps = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
+        if (!ok || !cs || !ps) {
+            free(boff);
+            free(cs);
+            free(ps);
+            free(g);
+            return ok ? CM_ENOMEM : CM_EINVAL;
+        }
+        for (uint64_t h = 0; h < nb; ++h) boff[h + 1] += boff[h];
+        cur = 0;
+        for (size_t b = 0; b < hvs.size(); ++b) {
+            const uint32_t c = (uint32_t)tab[cur].info, w = boff[hvs[b]];
+            for (uint32_t e = 0; e < c; ++e) {
+                cs[w + e] = tab[cur + 1 + e].checksum;
+                ps[w + e] = (uint32_t)tab[cur + 1 + e].info;
+            }
+            cur += (uint64_t)cnts[b] + 1;
+        }
+        out->contig_num = contig_num;
+        out->ref_len = n;
+        out->genome = g;
+        out->bucket_off = boff;
+        out->checksum = cs;
+        out->pos = ps;
+        out->n_entries = total;
+    } else {
+        rc = cm_host_build_index(g, n, kmer, contig_num, n_threads, out);     // calculateHashTableOnFly + sortHashTable
+        if (rc != CM_OK) {
+            free(g);
+            return rc;
+        }
+    }
+    if (!more) x->done = true;
+    *loaded = 1;
+    return CM_OK;
+}
+
+void cm_host_free_loaded_contig(cm_index_view *iv) {
+    if (!iv) return;
+    free((void *)iv->genome);
+    iv->genome = nullptr;
+    cm_host_free_index(iv);
+}
+
+void cm_host_close_index(cm_index_file *x) {
+    if (!x) return;
+    if (x->f) fclose(x->f);
+    delete x;
+}
+
+}  // extern "C"

@@ -157,6 +157,14 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_host_build_annotation": (C.c_int, [C.c_char_p, pp(ChrInfo), C.c_uint32, u32p, C.c_uint32, C.c_int32,
                                                pp(AnnotView)]),
         "cm_host_free_annotation": (None, [pp(AnnotView), C.c_uint32]),
+        "cm_host_pack_genome": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]),
+        "cm_host_read_index_info": (C.c_int, [C.c_char_p, pp(pp(ChrInfo)), pp(C.c_uint32)]),
+        "cm_host_free_index_info": (None, [pp(ChrInfo), C.c_uint32]),
+        "cm_host_write_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int, C.c_int]),
+        "cm_host_open_index": (C.c_int, [C.c_char_p, pp(vp), pp(C.c_int32), pp(C.c_int32), pp(C.c_uint32)]),
+        "cm_host_next_contig": (C.c_int, [vp, C.c_int, pp(IndexView), pp(C.c_int)]),
+        "cm_host_free_loaded_contig": (None, [pp(IndexView)]),
+        "cm_host_close_index": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -170,7 +178,9 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
-                    "cm_host_free_annotation"]
+                    "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
+                    "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
+                    "cm_host_close_index"]
 
 
 class HostIndex:
@@ -211,6 +221,64 @@ class HostIndex:
             self.close()
         except Exception:
             pass
+
+
+def pack_genome(fasta: str, contig_size: int = CM_CONTIG_SIZE):
+    """FASTA -> <fasta>.packed.fa + <fasta>.packed.fa.index.info (stock CircMiner file names); returns both paths."""
+    packed, info = fasta + ".packed.fa", fasta + ".packed.fa.index.info"
+    rc = load().cm_host_pack_genome(fasta.encode(), packed.encode(), info.encode(), contig_size)
+    if rc != 0:
+        raise RuntimeError(f"cm_host_pack_genome failed ({rc})")
+    return packed, info
+
+
+def write_index(packed_fa: str, kmer: int = 20, compact: bool = False, n_threads: int = 8) -> str:
+    """packed FASTA -> <packed_fa>.index in the mrsfast file format stock CircMiner reads."""
+    idx = packed_fa + ".index"
+    rc = load().cm_host_write_index(packed_fa.encode(), idx.encode(), kmer, int(compact), n_threads)
+    if rc != 0:
+        raise RuntimeError(f"cm_host_write_index failed ({rc})")
+    return idx
+
+
+class IndexFile:
+    """Iterates the packed contigs of a stock index file as IndexView objects (one mapping round each).
+    The view handed out is valid until the next iteration step / close()."""
+
+    def __init__(self, path: str, n_threads: int = 8):
+        self.L = load()
+        self.h = C.c_void_p()
+        kmer, full, nrec = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
+        rc = self.L.cm_host_open_index(path.encode(), C.byref(self.h), C.byref(kmer), C.byref(full), C.byref(nrec))
+        if rc != 0:
+            raise RuntimeError(f"cm_host_open_index failed ({rc}): {path}")
+        self.kmer, self.full, self.n_records, self.n_threads = kmer.value, bool(full.value), nrec.value, n_threads
+        self._cur = None
+
+    def __iter__(self):
+        return self
+
+    def _drop(self):
+        if self._cur is not None:
+            self.L.cm_host_free_loaded_contig(C.byref(self._cur))
+            self._cur = None
+
+    def __next__(self) -> IndexView:
+        self._drop()
+        iv, loaded = IndexView(), C.c_int(0)
+        rc = self.L.cm_host_next_contig(self.h, self.n_threads, C.byref(iv), C.byref(loaded))
+        if rc != 0:
+            raise RuntimeError(f"cm_host_next_contig failed ({rc})")
+        if not loaded.value:
+            raise StopIteration
+        self._cur = iv
+        return iv
+
+    def close(self):
+        self._drop()
+        if self.h:
+            self.L.cm_host_close_index(self.h)
+            self.h = C.c_void_p()
 
 
 class HotPath:

@@ -256,6 +256,31 @@ int cm_host_build_annotation(const char *gtf_path, const cm_chr_info *chrs, uint
                              cm_annot_view *out);
 void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs);
 
+/* ---------------- on-disk genome / index formats of stock CircMiner ------ */
+/* FASTA -> <ref>.packed.fa + <ref>.packed.fa.index.info (GenomePacker::pack_genome,
+ * src/genome.cpp:96-146): chromosomes concatenated with a 50-N spacer while they fit contig_size
+ * (DEF_CONTIG_SIZE = CM_CONTIG_SIZE in the reference). */
+int cm_host_pack_genome(const char *fasta_path, const char *packed_fa_path, const char *index_info_path,
+                        uint32_t contig_size);
+/* rows of .index.info (GenomePacker::load_index_info, src/genome.cpp:147-167); names are owned by the
+ * array: release with cm_host_free_index_info. */
+int cm_host_read_index_info(const char *path, cm_chr_info **out, uint32_t *n);
+void cm_host_free_index_info(cm_chr_info *chrs, uint32_t n);
+/* packed FASTA -> mrsfast index file: full table (generateHashTableOnDisk, src/mrsfast/HashTable.c:257-380,
+ * magic 3) or compact (generateHashTable, :383-474, magic 2: the table is rebuilt at load time). */
+int cm_host_write_index(const char *packed_fa_path, const char *index_path, int32_t kmer, int compact,
+                        int n_threads);
+/* Reader (checkHashTable / initLoadingHashTable / loadHashTable, HashTable.c:485-509, 618-700, 971-1098):
+ * open parses the header; every cm_host_next_contig call loads the next packed contig -- genome decoded to
+ * ASCII and the table flattened into a cm_index_view ready for cm_load_contig -- and sets *loaded = 0
+ * after the last one.  Views are released with cm_host_free_loaded_contig. */
+typedef struct cm_index_file cm_index_file;
+int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kmer, int32_t *is_full,
+                       uint32_t *n_records);
+int cm_host_next_contig(cm_index_file *f, int n_threads, cm_index_view *out, int *loaded);
+void cm_host_free_loaded_contig(cm_index_view *iv);
+void cm_host_close_index(cm_index_file *f);
+
 #ifdef __cplusplus
 }
 #endif

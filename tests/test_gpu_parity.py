@@ -143,3 +143,38 @@ def test_config5_stress_params(tmp_path_factory):
     from conftest import DataSet
     ds = DataSet(tmp_path_factory.mktemp("k22s"), "small", 8000, 37, kmer=22)
     _run_all_rounds(ds, cl.default_params(kmer=22, seed_lim=1000, max_ed=8, scan_level=2))
+
+
+def test_mapping_from_index_files_matches_in_memory_index(ds_tiny2r, tmp_path):
+    """contigs loaded from a stock-format index file (full and compact) map exactly like the
+    in-memory builder's views (two packed contigs = two rounds)."""
+    ds = ds_tiny2r
+    packed = str(tmp_path / "ref.fa.packed.fa")
+    with open(packed, "w") as f:
+        for i, c in enumerate(ds.d.contigs):
+            f.write(f">{i + 1}\n{c.tobytes().decode()}\n")
+    P = cl.default_params(kmer=ds.kmer)
+
+    def run(views_iter):
+        hp = cl.HotPath(P)
+        hp.upload(ds.batch)
+        n = 0
+        for ci, iv in enumerate(views_iter):
+            assert iv.contig_num == ci
+            hp.load_contig(ci, iv, ds.hi.annots[ci])
+            hp.map_round(ci, ci == ds.hi.n_contigs - 1)
+            hp.sync()
+            n += 1
+        assert n == ds.hi.n_contigs
+        out = hp.download()
+        hp.close()
+        return out
+
+    ref = run(iter(ds.hi.views))
+    for compact in (False, True):
+        idx = cl.write_index(packed, kmer=ds.kmer, compact=compact, n_threads=4)
+        f = cl.IndexFile(idx, n_threads=4)
+        assert f.kmer == ds.kmer and f.full == (not compact) and f.n_records == ds.hi.n_contigs
+        got = run(f)
+        f.close()
+        assert got[0].tobytes() == ref[0].tobytes() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all()

@@ -1,0 +1,272 @@
+"""on-disk genome / index formats (host code in circminer_amd/csrc/host_index_io.cpp).
+
+The reference cannot be built here, so the files are checked against an independent Python statement of
+the layout SURVEY.md §8(f) N1 records (validated there against an index written by stock CircMiner):
+little-endian, GeneralIndex unpacks as `<Hxxi`, memSize == sum(count14 + 1), decoded 3-bit genome ==
+packed FASTA, every genome k-mer sits at (checksum, 1-based start) inside its bucket's sorted valid range.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from circminer_amd import lib as cl
+
+W = 14
+
+
+def _write_fasta(path, recs, width=60):
+    with open(path, "w") as f:
+        for name, seq in recs:
+            f.write(f">{name} some description\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+def _rand_seq(rng, n, n_rate=0.0, lower=False):
+    s = rng.choice(list("ACGT"), n)
+    if n_rate:
+        s[rng.random(n) < n_rate] = "N"
+    s = "".join(s)
+    return s.lower() if lower else s
+
+
+def py_pack(recs, contig_size):
+    """src/genome.cpp:96-146 restated: (packed records, info rows)."""
+    packed, info, cur, num = [], [], 0, 0
+    for name, seq in recs:
+        if cur == 0 or len(seq) + 50 + cur > contig_size:
+            num += 1
+            cur = 0
+            packed.append([str(num), seq])
+            info.append((num, cur, cur + len(seq), name))
+            cur += len(seq)
+        else:
+            packed[-1][1] += "N" * 50 + seq
+            info.append((num, cur + 50, cur + 50 + len(seq), name))
+            cur += 50 + len(seq)
+    return packed, info
+
+
+def parse_index(path):
+    """Independent parser of the mrsfast index file (layout of SURVEY.md §8(f) N1)."""
+    b = open(path, "rb").read()
+    o = 0
+
+    def take(fmt):
+        nonlocal o
+        v = struct.unpack_from("<" + fmt, b, o)
+        o += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    hdr = dict(zip(("magic", "W", "c", "max_mem", "io_buf", "contig_max", "n_rec"), take("BBbIIIi")))
+    hdr["records"] = []
+    for _ in range(hdr["n_rec"]):
+        nl = take("i")
+        name = b[o:o + nl].decode()
+        o += nl
+        hdr["records"].append((name, take("i")))
+    contigs = []
+    while o < len(b):
+        more, nl = take("Bh")
+        name = b[o:o + nl].decode()
+        o += nl
+        off, n = take("iI")
+        nw = n // 21 + (n % 21 != 0)
+        words = np.frombuffer(b, "<u8", nw, o)
+        o += 8 * nw
+        codes = ((words[:, None] >> (60 - 3 * np.arange(21, dtype=np.uint64))[None, :]) & np.uint64(7)).reshape(-1)[:n]
+        genome = "".join(np.array(list("ACGTN"))[codes.astype(int)])
+        nbuckets = take("I")
+        hv, buckets, n_blocks = 0, [], 0
+        while len(buckets) < nbuckets:
+            nbytes = take("i")
+            blk = b[o:o + nbytes]
+            o += nbytes
+            n_blocks += 1
+            i = 0
+            vals = []
+            while i < nbytes:
+                v, sh = 0, 0
+                while True:
+                    t = blk[i]
+                    i += 1
+                    v |= (t & 127) << sh
+                    sh += 7
+                    if t & 128:
+                        break
+                vals.append(v)
+            for d, cnt in zip(vals[0::2], vals[1::2]):
+                hv += d
+                buckets.append((hv, cnt))
+        table = None
+        if hdr["magic"] == 3:
+            mem = take("I")
+            table = np.frombuffer(b, np.dtype([("checksum", "<u2"), ("pad", "<u2"), ("info", "<i4")]), mem, o)
+            o += 8 * mem
+        contigs.append(dict(more=more, name=name, off=off, n=n, genome=genome, buckets=buckets, table=table, n_blocks=n_blocks))
+        if not more:
+            break
+    assert o == len(b)
+    return hdr, contigs
+
+
+def _code(s):
+    v = 0
+    for ch in s:
+        v = v * 4 + "ACGT".index(ch)
+    return v
+
+
+@pytest.fixture(scope="module")
+def L(built):
+    return cl.load()
+
+
+@pytest.fixture(scope="module")
+def genome_files(L, tmp_path_factory):
+    d = tmp_path_factory.mktemp("n1")
+    rng = np.random.default_rng(5)
+    recs = [("chrA", _rand_seq(rng, 4000)), ("chrB", _rand_seq(rng, 2500, n_rate=0.01)), ("chrC", _rand_seq(rng, 3000, lower=True)),
+            ("chrD", _rand_seq(rng, 700)), ("chrE", "ACGT" * 300 + _rand_seq(rng, 500))]
+    fa = str(d / "ref.fa")
+    _write_fasta(fa, recs)
+    packed, info = fa + ".packed.fa", fa + ".packed.fa.index.info"
+    assert L.cm_host_pack_genome(fa.encode(), packed.encode(), info.encode(), 7000) == 0
+    return dict(dir=d, recs=recs, fa=fa, packed=packed, info=info, contig_size=7000)
+
+
+def test_pack_genome_and_info(L, genome_files):
+    want_packed, want_info = py_pack(genome_files["recs"], genome_files["contig_size"])
+    assert len(want_packed) == 2 and len(want_info) == 5              # A+B | C+D+E: both the spacer and the overflow rule are exercised
+    got = open(genome_files["packed"]).read()
+    # the packer writes one line per chromosome (the spacer leads the line), records are ">N"
+    lines = got.split("\n")
+    recs, cur = [], None
+    for ln in lines:
+        if ln.startswith(">"):
+            cur = [ln[1:], ""]
+            recs.append(cur)
+        elif ln:
+            cur[1] += ln
+    assert recs == want_packed
+    rows = [tuple(r.split("\t")) for r in open(genome_files["info"]).read().strip().split("\n")]
+    assert rows == [(str(a), str(b), str(c), d) for a, b, c, d in want_info]
+    # read back through the C reader
+    arr, n = C.POINTER(cl.ChrInfo)(), C.c_uint32(0)
+    assert L.cm_host_read_index_info(genome_files["info"].encode(), C.byref(arr), C.byref(n)) == 0
+    assert [(arr[i].contig_id, arr[i].start_pos, arr[i].len, arr[i].name.decode()) for i in range(n.value)] == \
+           [(a, b, c - b, d) for a, b, c, d in want_info]
+    L.cm_host_free_index_info(arr, n)
+
+
+def _load_all(L, path, n_threads=2):
+    h, kmer, full, nrec = C.c_void_p(), C.c_int32(0), C.c_int32(0), C.c_uint32(0)
+    assert L.cm_host_open_index(path.encode(), C.byref(h), C.byref(kmer), C.byref(full), C.byref(nrec)) == 0
+    out = []
+    while True:
+        iv, loaded = cl.IndexView(), C.c_int(0)
+        assert L.cm_host_next_contig(h, n_threads, C.byref(iv), C.byref(loaded)) == 0
+        if not loaded.value:
+            break
+        nb = 4 ** W
+        off = np.ctypeslib.as_array(iv.bucket_off, (nb + 1,)).copy()
+        n = int(iv.n_entries)
+        out.append(dict(contig=iv.contig_num, ref_len=iv.ref_len, genome=bytes(np.ctypeslib.as_array(iv.genome, (iv.ref_len,))),
+                        off=off, cs=np.ctypeslib.as_array(iv.checksum, (max(n, 1),))[:n].copy(),
+                        pos=np.ctypeslib.as_array(iv.pos, (max(n, 1),))[:n].copy()))
+        L.cm_host_free_loaded_contig(C.byref(iv))
+    L.cm_host_close_index(h)
+    return kmer.value, full.value, nrec.value, out
+
+
+@pytest.mark.parametrize("kmer", [20, 22, 14])
+def test_full_index_layout_and_round_trip(L, genome_files, kmer, monkeypatch):
+    monkeypatch.setenv("CM_INDEX_IOBUF", "4096")          # small IO buffer: the count stream splits into many blocks
+    idx = str(genome_files["dir"] / f"full{kmer}.index")
+    assert L.cm_host_write_index(genome_files["packed"].encode(), idx.encode(), kmer, 0, 2) == 0
+    hdr, contigs = parse_index(idx)
+    want_packed, _ = py_pack(genome_files["recs"], genome_files["contig_size"])
+    want_seq = [("".join(ch if ch in "ACGT" else "N" for ch in s.upper())) for _, s in want_packed]
+    assert (hdr["magic"], hdr["W"], hdr["c"], hdr["io_buf"], hdr["contig_max"]) == (3, 14, kmer - 14, 4096, 1300000000)
+    assert hdr["records"] == [(str(i + 1), len(s)) for i, s in enumerate(want_seq)]
+    assert [c["more"] for c in contigs] == [1] * (len(want_seq) - 1) + [0]
+    c = kmer - W
+    rng = np.random.default_rng(kmer)
+    max_mem = 0
+    for ci, con in enumerate(contigs):
+        g = want_seq[ci]
+        assert con["name"] == str(ci + 1) and con["off"] == 0 and con["genome"] == g
+        assert con["n_blocks"] > 1
+        # counts = number of N-free 14-mer windows per hash value
+        cnt14 = {}
+        for i in range(len(g) - W + 1):
+            w = g[i:i + W]
+            if "N" not in w:
+                cnt14[_code(w)] = cnt14.get(_code(w), 0) + 1
+        assert con["buckets"] == sorted(cnt14.items())
+        tab = con["table"]
+        assert len(tab) == sum(v + 1 for v in cnt14.values())
+        max_mem = max(max_mem, len(tab))
+        start = {}
+        o = 0
+        for hv, cnt in con["buckets"]:
+            start[hv] = o
+            n_valid = int(tab[o]["info"])
+            ent = tab[o + 1:o + 1 + n_valid]
+            assert 0 <= n_valid <= cnt
+            key = ent["checksum"].astype(np.int64) * (1 << 32) + ent["info"]
+            assert (np.diff(key) > 0).all()                  # sorted by (checksum, position), no duplicates
+            o += cnt + 1
+        # every valid k-mer is where the probe side will look for it
+        n_valid_total = 0
+        for i in range(len(g) - kmer + 1):
+            km = g[i:i + kmer]
+            if "N" in km:
+                continue
+            n_valid_total += 1
+            if rng.random() < 0.05:
+                hv, ck = _code(km[:W]), (_code(km[W:]) if c else 0)
+                o = start[hv]
+                ent = tab[o + 1:o + 1 + int(tab[o]["info"])]
+                assert ((ent["checksum"] == ck) & (ent["info"] == i + 1)).sum() == 1
+        assert n_valid_total == sum(int(tab[start[hv]]["info"]) for hv, _ in con["buckets"])
+    assert hdr["max_mem"] == max_mem
+    # reader: same flattened view as the in-memory builder on the same genome
+    k2, full, nrec, views = _load_all(L, idx)
+    assert (k2, full, nrec) == (kmer, 1, len(want_seq))
+    for ci, v in enumerate(views):
+        g = want_seq[ci].encode()
+        assert v["contig"] == ci and v["genome"] == g          # contigNum = atoi(name) - 1, src/circminer.cpp:267
+        ref = cl.IndexView()
+        garr = np.frombuffer(g, np.uint8)
+        assert L.cm_host_build_index(cl.ptr(garr, cl.u8p), len(g), kmer, ci + 1, 2, C.byref(ref)) == 0
+        n = int(ref.n_entries)
+        assert n == len(v["pos"])
+        assert (np.ctypeslib.as_array(ref.bucket_off, (4 ** W + 1,)) == v["off"]).all()
+        assert (np.ctypeslib.as_array(ref.checksum, (max(n, 1),))[:n] == v["cs"]).all()
+        assert (np.ctypeslib.as_array(ref.pos, (max(n, 1),))[:n] == v["pos"]).all()
+        L.cm_host_free_index(C.byref(ref))
+
+
+def test_compact_index_rebuilds_the_same_table(L, genome_files):
+    full, compact = str(genome_files["dir"] / "f.index"), str(genome_files["dir"] / "c.index")
+    assert L.cm_host_write_index(genome_files["packed"].encode(), full.encode(), 20, 0, 2) == 0
+    assert L.cm_host_write_index(genome_files["packed"].encode(), compact.encode(), 20, 1, 2) == 0
+    hdr, contigs = parse_index(compact)
+    assert hdr["magic"] == 2 and all(c["table"] is None for c in contigs)
+    assert os.path.getsize(compact) < os.path.getsize(full)
+    a, b = _load_all(L, full), _load_all(L, compact)
+    assert a[0] == b[0] == 20 and (a[1], b[1]) == (1, 0)
+    for x, y in zip(a[3], b[3]):
+        assert x["genome"] == y["genome"] and (x["off"] == y["off"]).all() and (x["cs"] == y["cs"]).all() and (x["pos"] == y["pos"]).all()
+
+
+def test_reader_rejects_garbage(L, tmp_path):
+    p = tmp_path / "bad.index"
+    p.write_bytes(b"\x07\x0e\x06" + b"\0" * 64)
+    h = C.c_void_p()
+    assert L.cm_host_open_index(str(p).encode(), C.byref(h), None, None, None) != 0
+    assert L.cm_host_open_index(str(tmp_path / "missing").encode(), C.byref(h), None, None, None) != 0

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 OUT = os.path.join(CSRC, "libcmhot.so")
-SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp"]
+SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp"]
 DEPS = SOURCES + ["cm_core.h", os.path.join("..", "..", "include", "circminer_hot.h")]
 
 
@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}")
         objs.append(o)
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread", "-lz"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)

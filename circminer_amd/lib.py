@@ -82,6 +82,11 @@ class ChrInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("contig_id", C.c_uint32), ("start_pos", C.c_uint32), ("len", C.c_uint32)]
 
 
+class FastqBatch(C.Structure):
+    _fields_ = [("reads", Reads), ("qual1", u8p), ("qual2", u8p), ("names1", C.c_void_p), ("names2", C.c_void_p),
+                ("name_off1", u64p), ("name_off2", u64p), ("prior", C.c_void_p)]
+
+
 def ptr(a: np.ndarray, t):
     return a.ctypes.data_as(t)
 
@@ -165,6 +170,13 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_host_next_contig": (C.c_int, [vp, C.c_int, pp(IndexView), pp(C.c_int)]),
         "cm_host_free_loaded_contig": (None, [pp(IndexView)]),
         "cm_host_close_index": (None, [vp]),
+        "cm_fastq_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, C.c_int32, pp(vp)]),
+        "cm_fastq_next": (C.c_int, [vp, C.c_uint64, pp(FastqBatch)]),
+        "cm_fastq_close": (None, [vp]),
+        "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
+        "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_writer_close": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -180,7 +192,8 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
-                    "cm_host_close_index"]
+                    "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
+                    "cm_write_pam", "cm_writer_close"]
 
 
 class HostIndex:
@@ -278,6 +291,100 @@ class IndexFile:
         self._drop()
         if self.h:
             self.L.cm_host_close_index(self.h)
+            self.h = C.c_void_p()
+
+
+def chr_array(chr_table):
+    """ChrInfo array from rows (name, contig_id (1-based), start_pos, len) -- the rows of .index.info."""
+    arr = (ChrInfo * max(len(chr_table), 1))()
+    for i, (name, contig, start, ln) in enumerate(chr_table):
+        arr[i] = ChrInfo(name.encode() if isinstance(name, str) else name, contig, start, ln)
+    return arr
+
+
+class ParsedBatch:
+    """One batch from FastqReader: `.c`/`.n` like ReadBatch (goes to HotPath.upload), `.prior` = carried states or None."""
+
+    def __init__(self, fb: FastqBatch):
+        self.fb = fb
+        self.c = fb.reads
+        self.n = int(fb.reads.n_pairs)
+        self.prior = None
+        if fb.prior:
+            self.prior = np.ctypeslib.as_array(C.cast(fb.prior, C.POINTER(C.c_uint8)), (self.n * MAPPED_DTYPE.itemsize,)).view(MAPPED_DTYPE).copy()
+
+    def max_len(self) -> int:
+        o1 = np.ctypeslib.as_array(self.c.off1, (self.n + 1,))
+        o2 = np.ctypeslib.as_array(self.c.off2, (self.n + 1,))
+        return int(max(np.diff(o1).max(initial=0), np.diff(o2).max(initial=0)))
+
+    def name(self, i: int, mate: int = 1) -> str:
+        base, off = (self.fb.names1, self.fb.name_off1) if mate == 1 else (self.fb.names2, self.fb.name_off2)
+        return C.string_at(base + off[i]).decode()
+
+    def seq(self, i: int, mate: int = 1) -> bytes:
+        s, o = (self.c.seq1, self.c.off1) if mate == 1 else (self.c.seq2, self.c.off2)
+        return bytes(np.ctypeslib.as_array(s, (int(o[self.n]),))[int(o[i]):int(o[i + 1])])
+
+    def qual(self, i: int, mate: int = 1) -> bytes:
+        q, o = (self.fb.qual1, self.c.off1) if mate == 1 else (self.fb.qual2, self.c.off2)
+        return bytes(np.ctypeslib.as_array(q, (int(o[self.n]),))[int(o[i]):int(o[i + 1])])
+
+
+class FastqReader:
+    """Paired FASTQ (plain / gzip) -> batches in the cm_reads layout; a batch is valid until the next one is read."""
+
+    def __init__(self, r1: str, r2: str, chr_table=(), max_ed: int = 4):
+        self.L = load()
+        self._chrs = chr_array(list(chr_table))
+        self.h = C.c_void_p()
+        rc = self.L.cm_fastq_open(r1.encode(), r2.encode(), self._chrs, len(chr_table), max_ed, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"cm_fastq_open failed ({rc})")
+
+    def next_batch(self, max_pairs: int):
+        fb = FastqBatch()
+        rc = self.L.cm_fastq_next(self.h, max_pairs, C.byref(fb))
+        if rc != 0:
+            raise RuntimeError(f"cm_fastq_next failed ({rc}): malformed FASTQ")
+        return ParsedBatch(fb) if fb.reads.n_pairs else None
+
+    def close(self):
+        if self.h:
+            self.L.cm_fastq_close(self.h)
+            self.h = C.c_void_p()
+
+
+class RecordWriter:
+    """PAM (path2=None) or remain-FASTQ pair writer in the reference's formats."""
+
+    def __init__(self, path1: str, path2=None, chr_table=()):
+        self.L = load()
+        self._chrs = chr_array(list(chr_table))
+        self.h = C.c_void_p()
+        rc = self.L.cm_writer_open(path1.encode(), path2.encode() if path2 else None, self._chrs, len(chr_table), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"cm_writer_open failed ({rc})")
+
+    def _call(self, fn, batch: ParsedBatch, states: np.ndarray, sel):
+        st = np.ascontiguousarray(states)
+        sp, ns = None, 0
+        if sel is not None:
+            sel = np.ascontiguousarray(sel, dtype=np.uint64)
+            sp, ns = sel.ctypes.data, len(sel)
+        rc = fn(self.h, C.byref(batch.fb), st.ctypes.data, sp, ns)
+        if rc != 0:
+            raise RuntimeError(f"writer failed ({rc})")
+
+    def write_remain(self, batch, states, sel=None):
+        self._call(self.L.cm_write_remain, batch, states, sel)
+
+    def write_pam(self, batch, states, sel=None):
+        self._call(self.L.cm_write_pam, batch, states, sel)
+
+    def close(self):
+        if self.h:
+            self.L.cm_writer_close(self.h)
             self.h = C.c_void_p()
 
 

@@ -281,6 +281,38 @@ int cm_host_next_contig(cm_index_file *f, int n_threads, cm_index_view *out, int
 void cm_host_free_loaded_contig(cm_index_view *iv);
 void cm_host_close_index(cm_index_file *f);
 
+/* ---------------- FASTQ ingest, carry-over header, PAM / remain writers ---------- */
+/* One batch of parsed pairs in the layout cm_reads_upload takes.  All pointers belong to the parser and stay
+ * valid until the next cm_fastq_next / cm_fastq_close.  names*: NUL-terminated read names (first header token,
+ * trailing "/x" cut: FASTQParser::extract_map_info, src/fastq_parser.cpp:178-198), name i at names + name_off[i].
+ * prior: the MatchedRead each pair carried in its 23-token header (fill_map_info, :200-269) or NULL when no
+ * pair of the batch carried one (fresh reads: cm_reads_upload's default state). */
+typedef struct cm_fastq_batch {
+    cm_reads reads;
+    const uint8_t *qual1, *qual2;        /* same offsets as reads.seq1 / reads.seq2 */
+    const char *names1, *names2;
+    const uint64_t *name_off1, *name_off2;
+    const cm_mapped_read *prior;
+} cm_fastq_batch;
+typedef struct cm_fastq cm_fastq;
+/* plain or gzip FASTQ (gzread, as src/fastq_parser.cpp:84-98); chrs = rows of .index.info (chromosome
+ * names of the carried headers -> chr_id); max_ed = maxEd of the run (state of unmapped carried reads). */
+int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed,
+                  cm_fastq **out);
+int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);   /* out->reads.n_pairs == 0 at the end */
+void cm_fastq_close(cm_fastq *f);
+
+/* Writers.  cm_write_remain = FilterRead::write_read_category PE (src/filter.cpp:413-455) into
+ * <out>_<round>_remain_R1.fastq / _R2.fastq; cm_write_pam = SAMOutput::write_pam_rec_pe
+ * (src/output.cpp:279-299) into <out>.mapping.pam (path2 = NULL).  sel = indices of the pairs to write
+ * (NULL: all): map_reads writes PAM rows for (skip || last round) and remain records for the pairs
+ * cm_collect_active returns (src/circminer.cpp:386-397). */
+typedef struct cm_writer cm_writer;
+int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs, uint32_t n_chr, cm_writer **out);
+int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
+int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
+void cm_writer_close(cm_writer *w);
+
 #ifdef __cplusplus
 }
 #endif

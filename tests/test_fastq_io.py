@@ -1,0 +1,161 @@
+"""FASTQ ingest, the 23-token carry-over header, PAM and remain-FASTQ writers
+(circminer_amd/csrc/host_fastq.cpp) against Python restatements of the reference's formats
+(src/fastq_parser.cpp:178-269, src/filter.cpp:413-455, src/output.cpp:279-299)."""
+import gzip
+
+import numpy as np
+import pytest
+
+from circminer_amd import lib as cl
+
+MAPPED = {0, 1, 2, 3, 4, 7, 5}
+CHRS = [("chr1", 1, 0, 5000), ("chr2", 1, 5050, 3000), ("chrX", 2, 0, 4000)]
+
+
+def _fastq(path, names, seqs, quals, opener=open):
+    with opener(path, "wt") as f:
+        for n, s, q in zip(names, seqs, quals):
+            f.write(f"@{n}\n{s}\n+\n{q}\n")
+
+
+def _rand_reads(rng, n, lo=30, hi=151):
+    seqs, quals = [], []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi))
+        seqs.append("".join(rng.choice(list("ACGTNacgt"), L)))
+        quals.append("".join(chr(int(x)) for x in rng.integers(35, 74, L)))
+    return seqs, quals
+
+
+def py_remain_header(name, m, chrs):
+    """write_read_category (PE), src/filter.cpp:413-449."""
+    if int(m["type"]) in MAPPED:
+        cn = chrs[int(m["chr_id"])][0] if m["chr_id"] >= 0 else "-"
+        shift = chrs[int(m["chr_id"])][2] if m["chr_id"] >= 0 else 0
+        gspos = int(m["contig_num"]) * 1100000000 + int(m["spos_r1"]) + shift
+        return (f"@{name} {gspos} {m['type']} {cn} {m['spos_r1']} {m['epos_r1']} {m['mlen_r1']} {m['qspos_r1']} {m['qepos_r1']} "
+                f"{'+' if m['r1_forward'] else '-'} {m['ed_r1']} {cn} {m['spos_r2']} {m['epos_r2']} {m['mlen_r2']} {m['qspos_r2']} "
+                f"{m['qepos_r2']} {'+' if m['r2_forward'] else '-'} {m['ed_r2']} {m['tlen']} {m['junc_num']} {int(bool(m['gm_compatible']))} {m['contig_num']}")
+    return f"@{name} * {m['type']}" + " *" * 20
+
+
+def py_pam_row(name, m, chrs):
+    """write_pam_rec_pe, src/output.cpp:279-299 (note: 21 placeholders for an unmapped pair, 20 fields for a mapped one)."""
+    if int(m["type"]) in MAPPED:
+        cn = chrs[int(m["chr_id"])][0] if m["chr_id"] >= 0 else "-"
+        f = [name, cn, m["spos_r1"], m["epos_r1"], m["mlen_r1"], m["qspos_r1"], m["qepos_r1"], "+" if m["r1_forward"] else "-", m["ed_r1"],
+             cn, m["spos_r2"], m["epos_r2"], m["mlen_r2"], m["qspos_r2"], m["qepos_r2"], "+" if m["r2_forward"] else "-", m["ed_r2"],
+             m["tlen"], m["junc_num"], int(bool(m["gm_compatible"])), m["type"]]
+        return "\t".join(str(x) for x in f)
+    return name + "\t*" * 21 + f"\t{m['type']}"
+
+
+def _rand_states(rng, n, max_ed=4):
+    st = np.zeros(n, dtype=cl.MAPPED_DTYPE)
+    for i in range(n):
+        t = int(rng.integers(0, 14))
+        m = st[i]
+        if t in MAPPED:
+            m["type"] = t
+            m["chr_id"] = int(rng.integers(0, len(CHRS)))
+            for k in ("spos_r1", "spos_r2", "epos_r1", "epos_r2"):
+                m[k] = int(rng.integers(1, 4000))
+            for k in ("qspos_r1", "qspos_r2", "qepos_r1", "qepos_r2", "mlen_r1", "mlen_r2"):
+                m[k] = int(rng.integers(1, 151))
+            m["ed_r1"], m["ed_r2"] = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            m["tlen"] = int(rng.integers(-50, 5000))
+            m["junc_num"] = int(rng.integers(0, 4))
+            m["r1_forward"], m["r2_forward"], m["gm_compatible"] = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            m["contig_num"] = CHRS[int(m["chr_id"])][1] - 1
+        else:                                  # what finish_round / fill_map_info leave for an unmapped type
+            m["type"] = t
+            m["ed_r1"] = m["ed_r2"] = max_ed + 1
+            m["tlen"] = 1000000000
+            m["chr_id"] = -1
+            m["r1_forward"] = m["r2_forward"] = 1
+    return st
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_parse_fresh_reads(built, tmp_path, gz):
+    rng = np.random.default_rng(7)
+    n = 2500
+    s1, q1 = _rand_reads(rng, n)
+    s2, q2 = _rand_reads(rng, n)
+    names1 = [f"read{i}/1 extra comment" if i % 3 == 0 else (f"r{i}/1" if i % 3 == 1 else f"x{i}") for i in range(n)]
+    names2 = [nm.replace("/1", "/2") for nm in names1]
+    p1, p2 = str(tmp_path / ("a_1.fq" + (".gz" if gz else ""))), str(tmp_path / ("a_2.fq" + (".gz" if gz else "")))
+    op = gzip.open if gz else open
+    _fastq(p1, names1, s1, q1, op)
+    _fastq(p2, names2, s2, q2, op)
+    rd = cl.FastqReader(p1, p2, CHRS)
+    got = 0
+    while True:
+        b = rd.next_batch(700)
+        if b is None:
+            break
+        assert b.prior is None                                  # fresh reads: the default first-round state
+        for i in range(b.n):
+            g = got + i
+            want = names1[g].split(" ")[0]
+            want = want[:-2] if len(want) >= 2 and want[-2] == "/" else want
+            assert b.name(i) == want and b.name(i, 2) == want
+            assert b.seq(i).decode() == s1[g] and b.seq(i, 2).decode() == s2[g]
+            assert b.qual(i).decode() == q1[g] and b.qual(i, 2).decode() == q2[g]
+        got += b.n
+    assert got == n
+    rd.close()
+
+
+def test_remain_and_pam_formats_round_trip(built, tmp_path):
+    rng = np.random.default_rng(11)
+    n = 1200
+    s1, q1 = _rand_reads(rng, n)
+    s2, q2 = _rand_reads(rng, n)
+    names = [f"pair{i}" for i in range(n)]
+    p1, p2 = str(tmp_path / "in_1.fq"), str(tmp_path / "in_2.fq")
+    _fastq(p1, [x + "/1" for x in names], s1, q1)
+    _fastq(p2, [x + "/2" for x in names], s2, q2)
+    rd = cl.FastqReader(p1, p2, CHRS)
+    b = rd.next_batch(n)
+    st = _rand_states(rng, n)
+    sel = np.sort(rng.choice(n, 800, replace=False)).astype(np.uint64)
+    r1, r2, pam = str(tmp_path / "out_1_remain_R1.fastq"), str(tmp_path / "out_1_remain_R2.fastq"), str(tmp_path / "out.mapping.pam")
+    w = cl.RecordWriter(r1, r2, CHRS)
+    w.write_remain(b, st, sel)
+    w.close()
+    w = cl.RecordWriter(pam, None, CHRS)
+    w.write_pam(b, st)
+    w.close()
+    # formats
+    for path, seqs, quals in ((r1, s1, q1), (r2, s2, q2)):
+        lines = open(path).read().split("\n")
+        assert lines[-1] == "" and len(lines) == 4 * len(sel) + 1
+        for k, i in enumerate(sel):
+            i = int(i)
+            assert lines[4 * k] == py_remain_header(names[i], st[i], CHRS)
+            assert lines[4 * k + 1:4 * k + 4] == [seqs[i], "+", quals[i]]
+            assert len(lines[4 * k].split(" ")) == 23
+    rows = open(pam).read().split("\n")
+    assert rows[-1] == "" and rows[:-1] == [py_pam_row(names[i], st[i], CHRS) for i in range(n)]
+    # the carried state survives the file round trip bit for bit
+    rd2 = cl.FastqReader(r1, r2, CHRS)
+    b2 = rd2.next_batch(n)
+    assert b2.n == len(sel) and b2.prior is not None
+    assert b2.prior.tobytes() == st[sel.astype(np.int64)].tobytes()
+    for k in (0, len(sel) // 2, len(sel) - 1):
+        assert b2.name(k) == names[int(sel[k])] and b2.seq(k, 2).decode() == s2[int(sel[k])]
+    rd.close()
+    rd2.close()
+
+
+def test_malformed_fastq_is_an_error_not_a_crash(built, tmp_path):
+    p1, p2 = str(tmp_path / "bad_1.fq"), str(tmp_path / "bad_2.fq")
+    open(p1, "w").write("@a\nACGT\n+\nIIII\n@b\nACGT\n-\nIIII\n")
+    open(p2, "w").write("@a\nACGT\n+\nIIII\n@b\nACGT\n+\nIII\n")
+    rd = cl.FastqReader(p1, p2)
+    with pytest.raises(RuntimeError):
+        rd.next_batch(10)
+    rd.close()
+    with pytest.raises(RuntimeError):
+        cl.FastqReader(str(tmp_path / "missing_1.fq"), p2)

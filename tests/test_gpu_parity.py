@@ -178,3 +178,60 @@ def test_mapping_from_index_files_matches_in_memory_index(ds_tiny2r, tmp_path):
         got = run(f)
         f.close()
         assert got[0].tobytes() == ref[0].tobytes() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
+
+
+def test_two_rounds_through_remain_fastq_files(ds_tiny2r, tmp_path):
+    """the reference's way of carrying pairs between rounds (remain FASTQ + 23-token header,
+    src/filter.cpp:413-455 -> src/fastq_parser.cpp:200-269) gives the same final states as the resident batch."""
+    ds = ds_tiny2r
+    P = cl.default_params(kmer=ds.kmer)
+    n = ds.batch.n
+    chrs = ds.d.chr_table
+    # the input as FASTQ files
+    p1, p2 = str(tmp_path / "in_1.fq"), str(tmp_path / "in_2.fq")
+    for path, arr, mate in ((p1, ds.d.seq1, 1), (p2, ds.d.seq2, 2)):
+        with open(path, "w") as f:
+            for i in range(n):
+                s = arr[i].tobytes().decode()
+                f.write(f"@pair{i}/{mate}\n{s}\n+\n{'I' * len(s)}\n")
+    # A: resident batch, both rounds
+    hp = cl.HotPath(P)
+    for ci in range(2):
+        hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
+    hp.upload(ds.batch)
+    hp.map_round(0, False)
+    hp.map_round(1, True)
+    stA, catA, actA = hp.download()
+    # B: round 1 from the FASTQ files, survivors through remain files, round 2 from those
+    rd = cl.FastqReader(p1, p2, chrs, P.max_ed)
+    b = rd.next_batch(n + 10)
+    assert b.n == n and b.prior is None
+    hp.upload(b)
+    hp.map_round(0, False)
+    st1, cat1, act1 = hp.download()
+    idx, stc = hp.collect_active()
+    idx = idx.copy()
+    r1, r2 = str(tmp_path / "o_1_remain_R1.fastq"), str(tmp_path / "o_1_remain_R2.fastq")
+    w = cl.RecordWriter(r1, r2, chrs)
+    w.write_remain(b, st1, idx)
+    w.close()
+    pam = str(tmp_path / "o.mapping.pam")
+    wp = cl.RecordWriter(pam, None, chrs)
+    wp.write_pam(b, st1, np.nonzero(act1 == 0)[0])            # pairs retired by round 1 (skip)
+    rd.close()
+    rd2 = cl.FastqReader(r1, r2, chrs, P.max_ed)
+    b2 = rd2.next_batch(n + 10)
+    assert b2.n == len(idx) and b2.prior is not None and b2.prior.tobytes() == st1[idx.astype(np.int64)].tobytes()
+    hp.upload(b2, b2.prior)
+    hp.map_round(1, True)
+    st2, cat2, act2 = hp.download()
+    wp.write_pam(b2, st2)                                      # last round: every remaining pair is printed
+    wp.close()
+    rd2.close()
+    hp.close()
+    ii = idx.astype(np.int64)
+    assert st2.tobytes() == stA[ii].tobytes() and (cat2 == catA[ii]).all() and (act2 == actA[ii]).all()
+    done = np.nonzero(act1 == 0)[0]
+    assert stA[done].tobytes() == st1[done].tobytes()
+    rows = open(pam).read().strip().split("\n")
+    assert len(rows) == n and sorted(r.split("\t")[0] for r in rows) == sorted(f"pair{i}" for i in range(n))

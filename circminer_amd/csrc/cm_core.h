@@ -237,22 +237,26 @@ struct Probe {
 };
 CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
     Probe r{0u, 0u, 0u};
-    const int cl = c.P.kmer - CM_WINDOW_SIZE;
+    // hashVal / checkSumVal without branches (a 4-way switch per base made k_seed scalar-ALU bound): a base is
+    // valid iff it is upper-case A/C/G/T *after* the orientation's transform -- the forward strand is taken as
+    // is, the reverse strand went through FASTQParser::set_comp, which also upper-cases (src/fastq_parser.cpp:141-153)
     int hv = 0, cv = 0;
-    for (int i = 0; i < CM_WINDOW_SIZE; ++i) {
-        int b = base_code_strict(s.at(qpos + i));
-        if (b < 0) return r;
-        hv = (hv << 2) | b;
+    uint32_t bad = 0;
+    const uint32_t rc = s.mode == 1 ? 1u : 0u;
+    for (int i = 0; i < c.P.kmer; ++i) {
+        uint32_t u = s.mode == 2 ? 0u : (uint32_t)s.p[s.off + (qpos + i) * s.step];
+        u = rc ? (u & 0xDFu) : u;
+        bad |= (uint32_t)!((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T'));
+        uint32_t code = ((u >> 1) ^ (u >> 2)) & 3u;                  // A 0, C 1, G 2, T 3
+        code = rc ? 3u - code : code;
+        if (i < CM_WINDOW_SIZE) hv = (hv << 2) | (int)code;
+        else cv = (cv << 2) | (int)code;
     }
-    for (int i = 0; i < cl; ++i) {
-        int b = base_code_strict(s.at(qpos + CM_WINDOW_SIZE + i));
-        if (b < 0) return r;
-        cv = (cv << 2) | b;
-    }
+    if (bad) return r;
+    const int target = (int)(int16_t)cv;     // int16 quirk, src/match_read.cpp:77
     const uint32_t b0 = c.X.bucket_off[hv], b1 = c.X.bucket_off[hv + 1];
     if (b1 == b0) return r;
     const g_u16 it = c.X.checksum + b0;
-    const int target = (int)(int16_t)cv;     // int16 quirk, src/match_read.cpp:77
     uint32_t lb = 1, ub = b1 - b0, mid;
     while (lb < ub) {
         mid = (lb + ub) / 2;

@@ -235,3 +235,11 @@ def test_two_rounds_through_remain_fastq_files(ds_tiny2r, tmp_path):
     assert stA[done].tobytes() == st1[done].tobytes()
     rows = open(pam).read().strip().split("\n")
     assert len(rows) == n and sorted(r.split("\t")[0] for r in rows) == sorted(f"pair{i}" for i in range(n))
+
+
+def test_multi_tile_batches_match_the_oracle(ds_small, monkeypatch):
+    """Several launch groups per round (CM_TILE_PAIRS): the per-tile workspaces, the task pipeline of the mid
+    pairs and the second stream are reused tile after tile; results must not depend on the tiling."""
+    monkeypatch.setenv("CM_TILE_PAIRS", "4096")
+    P = cl.default_params(kmer=ds_small.kmer)
+    _run_all_rounds(ds_small, P)

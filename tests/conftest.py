@@ -47,6 +47,8 @@ def emu(built):
     E.emu_edit_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int)]
     E.emu_drop_sc.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int, pp(C.c_int), pp(C.c_int), pp(C.c_int)]
     E.emu_one_side.argtypes = [pp(cl.Params), vp, C.c_int, vp, C.c_int, C.c_int]
+    E.emu_leftovers_matter.argtypes = [C.c_int] * 5
+    E.emu_leftover_type.argtypes = [C.c_int] * 4
     return E
 
 

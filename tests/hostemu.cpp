@@ -184,6 +184,8 @@ int emu_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, i
     if (left) return cmc::local_alignment_sc(c, sm, a.rev(n), n, b.rev(m), m, *sclen, *indel, *score);
     return cmc::local_alignment_sc(c, sm, a, n, b, m, *sclen, *indel, *score);
 }
+int emu_leftovers_matter(int T, int min_ret1, int can1, int min_ret2, int can2) { return cmc::leftovers_matter(T, min_ret1, can1 != 0, min_ret2, can2 != 0) ? 1 : 0; }
+int emu_leftover_type(int min_ret1, int min_ret2, int g1, int g2) { return cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0); }
 int emu_one_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int w) {
     Core c{};
     c.P = *P;

@@ -116,3 +116,24 @@ def test_dp_bodies_fuzz(emu):
             s3 = A[rng.integers(0, 4, max(n3, 1))]
             t3 = np.ascontiguousarray(np.concatenate([s3[:n3], A[rng.integers(0, 4, w + 1)]])[:n3 + w + 1])
             assert O.oracle_one_side(s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w) == emu.emu_one_side(C.byref(P), s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w)
+
+
+def test_skipped_leftover_extensions_are_dead_work(emu):
+    """leftovers_matter() == false must imply that no outcome of the unpaired-chain extensions can change
+    mr.type: leftover_type() is applied with mr_update_type (type only ever decreases), an extension can only
+    lower a side's min_ret to CONCRD / CANDID / ORPHAN (chain_both_sides' return values) and flip its genic flag."""
+    import itertools
+    CONCRD, CANDID, ORPHAN = 0, 9, 11
+    rets = (CONCRD, CANDID, ORPHAN)
+    skipped = 0
+    for T, m1, m2, can1, can2 in itertools.product(range(14), rets, rets, (0, 1), (0, 1)):
+        # the reference only extends a side whose min_ret is not CONCRD yet
+        c1, c2 = can1 and m1 != CONCRD, can2 and m2 != CONCRD
+        if emu.emu_leftovers_matter(T, m1, int(c1), m2, int(c2)):
+            continue
+        skipped += 1
+        f1 = {min(m1, e) for e in rets} if c1 else {m1}
+        f2 = {min(m2, e) for e in rets} if c2 else {m2}
+        for a, b, g1, g2 in itertools.product(f1, f2, (0, 1), (0, 1)):
+            assert emu.emu_leftover_type(a, b, g1, g2) >= T, (T, m1, m2, can1, can2, a, b, g1, g2)
+    assert skipped > 100

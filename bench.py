@@ -75,8 +75,8 @@ def cpu_baseline(P, hi, batch, target_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="chr21")
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=21)
@@ -138,16 +138,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    hp.prof(True)                      # timers on during warm-up too: their HIP events are created once and recycled
+    # Setup, not warm-up: the first launches allocate the kernels' private segments and lazily created runtime
+    # objects, and the device shows one ~7 ms stall within its first ~100 ms of work (tests/diag/step_times.py);
+    # prime until that is behind us so that the W warm-up and K timed steps see the steady state.
+    for _ in range(4):
+        step()
     for _ in range(args.warmup):
         step()
     fence()
-    hp.prof(True)
     hp.prof_reset()
     t = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         rec = step()
+        marks.append(time.perf_counter() - t)
     fence()
     dt = time.perf_counter() - t
+    if os.environ.get("CM_BENCH_TRACE"):
+        print("step marks (ms):", [round(m * 1e3, 2) for m in marks], "end", round(dt * 1e3, 2), file=sys.stderr)
     ms, launches, counters = hp.prof_get()
     hp.prof(False)
     if world > 1:

@@ -1411,6 +1411,7 @@ struct cm_ctx {
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_free;           // timing events are recycled: creating them is slow and comes in bursts
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -1463,6 +1464,14 @@ void free_reads(cm_ctx *c) {
     c->tile = 0;
 }
 
+static hipEvent_t take_event(cm_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->ev_free.empty()) {
+        e = c->ev_free.back();
+        c->ev_free.pop_back();
+    } else (void)hipEventCreate(&e);
+    return e;
+}
 struct Timer {
     cm_ctx *c;
     int cls;
@@ -1471,8 +1480,8 @@ struct Timer {
     hipStream_t st;
     Timer(cm_ctx *ctx, int k, hipStream_t stream = nullptr) : c(ctx), cls(k), on(ctx->prof), st(stream ? stream : ctx->stream) {
         if (on) {
-            (void)hipEventCreate(&r.a);
-            (void)hipEventCreate(&r.b);
+            r.a = take_event(c);
+            r.b = take_event(c);
             r.cls = cls;
             (void)hipEventRecord(r.a, st);
         }
@@ -1657,6 +1666,9 @@ void cm_destroy(cm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->P.device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamSynchronize(ctx->stream2);
+    for (auto e : ctx->ev_free) (void)hipEventDestroy(e);
+    ctx->ev_free.clear();
     for (auto &r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -2134,8 +2146,8 @@ int cm_prof_reset(cm_ctx *ctx) {
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &r : ctx->recs) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        ctx->ev_free.push_back(r.a);
+        ctx->ev_free.push_back(r.b);
     }
     ctx->recs.clear();
     for (int i = 0; i < 8; ++i) {
@@ -2154,8 +2166,8 @@ int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) {
     for (auto &r : ctx->recs) {
         float t = 0;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ctx->ms[r.cls] += (double)t;
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        ctx->ev_free.push_back(r.a);
+        ctx->ev_free.push_back(r.b);
     }
     ctx->recs.clear();
     for (int i = 0; i < 8; ++i) {

@@ -719,18 +719,20 @@ CM_HD inline bool cand_less(const Cand &a, const Cand &b) {     // AlignCandid::
 // else 4 in the first string and 5 in the second, so "other" never matches anything — N vs N
 // included, src/align.cpp:745-759) into a private buffer, already in the order the DP walks them
 // (the left-hand variants stage reversed views).  On the GPU the buffer is LDS, word-interleaved
-// across the 64 lanes of the wave (byte i of lane l lives in word (i/4)*64 + l), so concurrent
+// across the 64 lanes of the wave (code i of lane l lives in word (i/8)*64 + l), so concurrent
 // per-lane accesses fall in distinct banks; on the host build it is a plain array.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_STAGE_PRIVATE)
 constexpr int LSTRIDE = 64;
 #else
 constexpr int LSTRIDE = 1;
 #endif
+// Codes are < 8, so the buffer keeps them as nibbles, eight per 32-bit word (half the LDS of a byte per code:
+// the staging buffers are what limits the pair kernels to two waves per SIMD otherwise).  `cap` counts
+// characters; the storage is cap / 8 + 1 words (window() may touch one word past the last code).
 struct LBuf {
     CM_S uint8_t *b;
     int cap;
-    CM_HD inline uint8_t get(int i) const { return b[(i >> 2) * (4 * LSTRIDE) + (i & 3)]; }
-    CM_HD inline uint32_t word(int w) const {                 // staged bytes 4w .. 4w+3, little-endian
+    CM_HD inline uint32_t word(int w) const {                 // codes 8w .. 8w+7, code 8w in the low nibble
 #if defined(__HIP_DEVICE_COMPILE__)
         return ((CM_S const uint32_t *)b)[w * LSTRIDE];
 #else
@@ -739,14 +741,26 @@ struct LBuf {
         return x;
 #endif
     }
-    // 5 consecutive staged bytes starting at index `at` (0 <= at, at + 7 < capacity): byte r in bits 8r..8r+7
+    CM_HD inline uint8_t get(int i) const { return (uint8_t)((word(i >> 3) >> (4 * (i & 7))) & 0xFu); }
+    // 8 consecutive codes starting at index `at` (0 <= at <= cap - 8), one per byte: code at+r in bits 8r..8r+7
     CM_HD inline uint64_t window(int at) const {
-        const int w = at >> 2;
-        const uint64_t lo = word(w), hi = word(w + 1);
-        return ((hi << 32) | lo) >> (8 * (at & 3));
+        const int w = at >> 3;
+        const uint64_t two = ((uint64_t)word(w + 1) << 32) | (uint64_t)word(w);
+        uint64_t x = (uint32_t)(two >> (4 * (at & 7)));      // 8 nibbles
+        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+        x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+        return x;
     }
-    CM_HD inline void put(int i, uint8_t v) const { b[(i >> 2) * (4 * LSTRIDE) + (i & 3)] = v; }
+    CM_HD inline void put(int i, uint8_t v) const {           // host staging only (the device stores whole words)
+        uint32_t x;
+        __builtin_memcpy(&x, (const uint8_t *)b + 4 * (i >> 3) * LSTRIDE, 4);
+        x = (x & ~(0xFu << (4 * (i & 7)))) | ((uint32_t)(v & 0xFu) << (4 * (i & 7)));
+        __builtin_memcpy((uint8_t *)b + 4 * (i >> 3) * LSTRIDE, &x, 4);
+    }
 };
+// four one-byte codes -> four nibbles (16 bits)
+CM_HD inline uint32_t pack_nibbles(uint32_t x) { return (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u); }
 // 4 ASCII bases -> 4 one-byte codes (SWAR).  A/a 0, C/c 1, T/t 2, G/g 3 (= (ch >> 1) & 3 of the
 // upper-cased byte; only equality of codes matters to the DPs), complement = code ^ 2, any other
 // byte -> `other`.
@@ -790,13 +804,12 @@ CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
     CM_STAT(8, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
     CM_S uint32_t *dw = (CM_S uint32_t *)d.b;
-    const int nw = (n + 3) >> 2;
-    for (int w0 = 0; w0 < nw; w0 += 4) {
+    const int nw = (n + 7) >> 3;                   // words of eight codes
+    for (int w0 = 0; w0 < nw; w0 += 2) {
         uint32_t q[4];
-        load_codes16(v, w0, other, q);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (w0 + k < nw) dw[(w0 + k) * LSTRIDE] = q[k];
+        load_codes16(v, 2 * w0, other, q);         // characters 8*w0 .. 8*w0+15
+        dw[w0 * LSTRIDE] = pack_nibbles(q[0]) | (pack_nibbles(q[1]) << 16);
+        if (w0 + 1 < nw) dw[(w0 + 1) * LSTRIDE] = pack_nibbles(q[2]) | (pack_nibbles(q[3]) << 16);
     }
 #else
     for (int i = 0; i < n; ++i) d.put(i, v.mode == 2 ? other : code1(v.p[v.off + i * v.step], v.mode == 1, other));

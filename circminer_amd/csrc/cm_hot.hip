@@ -33,7 +33,9 @@ constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (wo
 constexpr int BLK = 256;
 constexpr int BLK_CHAIN = 64;
 constexpr int BLK_PAIR = 64;
-constexpr int STAGE_WORDS = 80;                  // private staging: 320 chars per string (max_read_len 300 + band + slack)
+constexpr int STAGE_WORDS = 42;                  // private staging (CM_STAGE_PRIVATE): 328 chars per string as nibbles (max_read_len 300 + band + slack)
+// bytes one staged string of `cap` characters takes per lane (cm_core.h LBuf: eight codes per word + one spare word)
+__host__ __device__ constexpr int lbuf_bytes(int cap) { return (cap / 8 + 1) * 4; }
 
 struct ReadsDev {
     const uint8_t *seq1, *seq2;
@@ -186,7 +188,10 @@ __global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, cons
     resid[r] = (uint16_t)(rs < 0 ? 0 : rs);
 }
 
-__global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+#ifndef CM_PAIR_WAVES
+#define CM_PAIR_WAVES 3       // waves per SIMD the pair kernels are compiled for (LDS: 2 x lbuf_bytes x 64 per wave)
+#endif
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
                                                    int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
                                                    const uint32_t *perm, const unsigned int *n_light) {
@@ -195,12 +200,12 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair(KCore kc, ReadsDev rd, uin
 #if defined(CM_STAGE_PRIVATE)
     uint32_t stage_words[2 * STAGE_WORDS];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
-    str_cap = 4 * STAGE_WORDS;
-    const int str_stride = str_cap;
+    str_cap = 8 * (STAGE_WORDS - 1);
+    const int str_stride = 4 * STAGE_WORDS;
 #else
     extern __shared__ uint32_t lds_words[];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
-    const int str_stride = str_cap * BLK_PAIR;
+    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
 #endif
 #if defined(CM_DIAG)
     __shared__ unsigned long long tick_w[65];
@@ -849,12 +854,12 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
     uint32_t stage_words[2 * STAGE_WORDS];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
     const int lds_stage_bytes = 0;
-    str_cap = 4 * STAGE_WORDS;
-    const int str_stride = str_cap;
+    str_cap = 8 * (STAGE_WORDS - 1);
+    const int str_stride = 4 * STAGE_WORDS;
 #else
     CM_S uint8_t *lane_base = base + 4 * lane;
-    const int lds_stage_bytes = 2 * str_cap * BLK_PAIR;
-    const int str_stride = str_cap * BLK_PAIR;
+    const int lds_stage_bytes = 2 * lbuf_bytes(str_cap) * BLK_PAIR;
+    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
 #endif
 #if defined(CM_DIAG)
     __shared__ unsigned long long tick_w[65];
@@ -1154,13 +1159,13 @@ __global__ void __launch_bounds__(BLK) k_mid_plan(KCore kc, ReadsDev rd, uint64_
     }
 }
 
-__global__ void __launch_bounds__(BLK_PAIR, 2) k_mid_tasks(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_mid_tasks(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
                                                         const int32_t *high, int *err, int str_cap, int stage) {
     // stage 0: the first pair task of every pair (the reference stops at the first CONCRD pair, usually this one);
     // stage 1: the remaining tasks of the pairs whose first task did not end the attempt
     extern __shared__ uint32_t lds_words[];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
-    const int str_stride = str_cap * BLK_PAIR;
+    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
 #if defined(CM_DIAG)
     cmc::Tick tick{};
     tick.w = nullptr;
@@ -1286,11 +1291,11 @@ __global__ void __launch_bounds__(BLK) k_mid_overflow(const unsigned int *n_mid,
     hlist[atomicAdd(n_heavy, 1u)] = P.t;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR, 2) k_mid_unpair(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_mid_unpair(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
                                                          const int32_t *high, int *err, int str_cap) {
     extern __shared__ uint32_t lds_words[];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
-    const int str_stride = str_cap * BLK_PAIR;
+    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
 #if defined(CM_DIAG)
     cmc::Tick tick{};
     tick.w = nullptr;
@@ -1900,12 +1905,12 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
         if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
         if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
         {
-            // str_cap: chars per staged string (multiple of 4); LDS = 2 strings x str_cap bytes x 64 lanes
-            const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 3) / 4) * 4;
+            // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
+            const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 7) / 8) * 8;
 #if defined(CM_STAGE_PRIVATE)
             const size_t lds_bytes = 0;
 #else
-            const size_t lds_bytes = (size_t)2 * str_cap * BLK_PAIR;
+            const size_t lds_bytes = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
 #endif
             const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
             {

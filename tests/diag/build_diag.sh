@@ -5,9 +5,9 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="$ROOT/tests/_hostemu"; mkdir -p "$OUT"
-for f in cm_hot.hip host_index.cpp host_annot.cpp; do
+for f in cm_hot.hip host_index.cpp host_annot.cpp host_index_io.cpp host_fastq.cpp; do
   /opt/rocm/bin/hipcc -c -O3 -std=c++17 -fPIC -ffp-contract=off ${DIAG_FLAGS--DCM_DIAG} --offload-arch=gfx950 -I"$ROOT/include" -I"$ROOT/circminer_amd/csrc" \
       "$ROOT/circminer_amd/csrc/$f" -o "$OUT/${DIAG_NAME-diag}_${f%.*}.o"
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libcmhot_${DIAG_NAME-diag}.so" "$OUT/${DIAG_NAME-diag}"_*.o -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libcmhot_${DIAG_NAME-diag}.so" "$OUT/${DIAG_NAME-diag}"_*.o -lpthread -lz
 echo "$OUT/libcmhot_${DIAG_NAME-diag}.so"

@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KERNELS = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_chain_heavy", "k_mid"]
+KERNELS = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_chain_heavy"]
 
 
 def algorithmic_bytes(counters):
@@ -38,7 +38,7 @@ def algorithmic_bytes(counters):
     extension is charged the survey's upper bound of four 170-byte reference windows (1360 B)
     plus the 96-byte result record."""
     probes, touches, hits, pair_rounds = counters
-    return [16 * probes + 8 * touches + 300 * pair_rounds, 8 * hits, (1360 + 96) * pair_rounds, 0, 0, 0, 0, 0]
+    return [16 * probes + 8 * touches + 300 * pair_rounds, 8 * hits, (1360 + 96) * pair_rounds, 0, 0, 0, 0]
 
 
 def cpu_baseline(P, hi, batch, target_s=15.0):
@@ -168,9 +168,9 @@ def main():
         total_pairs = args.pairs * world * args.steps
         value = total_pairs / dt
         ab = algorithmic_bytes(counters)
-        # the pair stage = class kernels + k_pair (light pairs, one per lane) with k_mid_* (task pipeline) and k_pair_heavy
-        # (one per wave) running concurrently on a second stream: class [2] is timed from the k_pair launch to the join,
-        # its algorithmic bytes cover all pair-rounds; classes [4], [6], [7] are the overlapped kernels' own times
+        # the pair stage = class kernels + k_pair (light pairs, one per lane) with k_pair_heavy (one pair per wave) running
+        # concurrently on a second stream: class [2] is timed from the k_pair launch to the join, its algorithmic
+        # bytes cover all pair-rounds; classes [4], [6] are the overlapped kernels' own times
         stage_ms = [ms[0], ms[1], ms[2] + ms[5]]        # heavy / mid kernels run on a second stream inside [1] / [2]
         dom = int(np.argmax(stage_ms))
         avg_ms = stage_ms[dom] / max(launches[dom], 1)
@@ -193,11 +193,11 @@ def main():
                                    f"{hi.n_contigs} round(s), defaults (BASELINE.json configs[1])",
                        "pairs_per_gpu": args.pairs, "rounds": hi.n_contigs, "bsj_records": int(len(rec)),
                        "prep_seconds": round(prep_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_mid+k_pair_heavy+k_classify" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_pair_heavy+k_classify" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches[dom],
                          "algorithmic_bytes_per_launch": ab[dom] / max(launches[dom], 1)},
-            "kernels": {KERNELS[i]: {"ms_total": ms[i], "launches": launches[i], "algorithmic_bytes": ab[i]} for i in range(8)},
+            "kernels": {KERNELS[i]: {"ms_total": ms[i], "launches": launches[i], "algorithmic_bytes": ab[i]} for i in range(7)},
             "counters": {"probes": counters[0], "search_touches": counters[1], "hits_consumed": counters[2], "pair_rounds": counters[3]},
         }
         if world == 1 and not args.no_cpu_baseline:

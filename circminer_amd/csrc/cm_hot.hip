@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_c(unsigned long long *out, cons
     if (i < n) out[i] += bsum[i / SCAN_ELEMS];
 }
 
-__global__ void __launch_bounds__(BLK_CHAIN) k_chain(KCore kc, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
+#ifndef CM_CHAIN_WAVES
+#define CM_CHAIN_WAVES 5
+#endif
+__global__ void __launch_bounds__(BLK_CHAIN, CM_CHAIN_WAVES) k_chain(KCore kc, ReadsDev rd, const uint8_t *active, uint64_t pair0, uint32_t r0, uint32_t r1, int S,
                                                      const uint32_t *sstart, const uint32_t *scnt, const uint32_t *sraw,
                                                      const unsigned long long *celloff, unsigned long long cellbase, double *dp_score,
                                                      int32_t *dp_prev, uint8_t *pool, unsigned long long pool_bytes,
@@ -540,8 +543,6 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
 constexpr int HEAVY_COST = 8;
 constexpr int N_BUCKETS = 7;             // residual-length buckets
 constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_heavy (one wave each)
-constexpr int MID_CLS = 14;              // heavy pairs with few candidate chain pairs: task pipeline (k_mid_*)
-constexpr int MID_MAX_T_CLS = 64;        // = MID_MAX_T
 // class of a pair for the pair stage: -2 inactive, HEAVY_CLS heavy (k_pair_heavy), else
 // (genic ? 7 : 0) + bucket of the total residual length of its best chains (bases left to extend).
 // genic: some best chain starts inside an annotated exon, i.e. the pair will walk transcripts during extension
@@ -549,12 +550,12 @@ constexpr int MID_MAX_T_CLS = 64;        // = MID_MAX_T
 // wave carry similar work; the classes are a heuristic, results do not depend on them.
 // (Measured: a "some residual is inexact" flag as a further key costs as much in k_pair_cls as it saves in k_pair.)
 __device__ inline int pair_class(const Core &c, const cm_chain *chains, const uint16_t *resid4, const int32_t *nchain,
-                                 const uint8_t *active, uint64_t pair0, uint32_t t, int heavy_cost, bool mid_on) {
+                                 const uint8_t *active, uint64_t pair0, uint32_t t, int heavy_cost) {
     const uint64_t p = pair0 + t;
     if (!active[p]) return -2;
     const int32_t *nc = nchain + 4 * (uint64_t)t;
     const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
-    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) return (a * d <= MID_MAX_T_CLS && cc * b <= MID_MAX_T_CLS && mid_on) ? MID_CLS : HEAVY_CLS;
+    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) return HEAVY_CLS;
     const uint16_t *q = resid4 + 4 * (uint64_t)t;
     const int resid = (int)q[0] + q[1] + q[2] + q[3];
     const int bucket = resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : 6;
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, ReadsDev rd, const c
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
-    const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost & 0xffff, (heavy_cost >> 16) != 0);
+    const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost);
     cls[t] = (int8_t)k;
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
     }
 }
 __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t n_tile, const unsigned int *blk_base, uint32_t nb,
-                                                     const unsigned int *ctr, uint32_t *perm, uint32_t *hlist, uint32_t *mlist) {
+                                                     const unsigned int *ctr, uint32_t *perm, uint32_t *hlist) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
     const int k = t < n_tile ? (int)cls[t] : -2;
@@ -691,7 +692,6 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
         for (int w = 0; w < wave; ++w) before += wcnt[w][k];
         const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
         if (k == HEAVY_CLS && hlist) hlist[pos] = t;
-        else if (k == MID_CLS && mlist) mlist[pos] = t;
         else perm[ctr[CTR_BASE + k] + pos] = t;
     }
 }
@@ -940,398 +940,6 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
 #endif
 }
 
-// ---- task pipeline for "mid" pairs ------------------------------------------------------------
-// Most pairs classified heavy carry only a dozen chains: one wave per pair (k_pair_heavy) leaves ~61 lanes
-// idle.  Pairs with at most MID_MAX_T candidate chain pairs per orientation are therefore mapped by a pipeline
-// of small kernels whose expensive steps run one *task* per lane, tasks of all mid pairs packed densely:
-//   k_mid_plan   (lane = pair)  pairing predicate of the current attempt -> pair tasks (i, j)
-//   k_mid_tasks  (lane = task)  extend_task
-//   k_mid_fold   (lane = pair)  fold_task in (i, j) order (early CONCRD), decides the unpaired-chain extensions
-//   k_mid_unpair (lane = task)  chain_both_sides of one unpaired chain
-//   k_mid_plan   (next phase)   leftover_type, next attempt / finish_round
-// The functions are the ones process_mates / mates_wave use; only the order of *independent* work changes
-// (every accepted pair task of an attempt is extended before the fold decides how many were needed).
-// A pair whose tasks do not fit the task buffers is appended to the heavy list and mapped by k_pair_heavy
-// from its untouched input state.
-constexpr int MID_MAX_T = 64;
-struct MidPair {
-    cm_mapped_read mr;
-    uint32_t t;                 // pair index inside the tile
-    int32_t st;                 // final category, -1 while running, -2 handed to k_pair_heavy
-    uint32_t task_base, ntask, un_base, n_un;
-    uint32_t fp, bp;
-    int32_t min_ret1, min_ret2;
-    uint8_t g1, g2, attempt, first, r1_fwd;
-    uint8_t leftover;           // the attempt reached the leftover stage (leftover_type applies)
-    uint8_t returned;           // the attempt produced process_mates' return value (= mr.type)
-    uint8_t written;            // finish_round done
-    uint8_t need_rest;          // the first pair task did not end the attempt: fold the others too
-    uint8_t pad[3];
-};
-struct MidTask { uint32_t m; uint16_t i, j; uint32_t code; };
-struct MidUn { uint32_t m; uint8_t back, ci, k, pad; };
-struct MidUnRes { int32_t ex, genic; };
-struct MidBufs {
-    MidPair *pairs;
-    MidTask *tasks;
-    HRes *res;
-    MidUn *un;
-    MidUnRes *unres;
-    uint32_t *first;            // indices of the first pair task of every pair (extended before the others)
-    unsigned int *ctr;          // of the current attempt: [0] pair tasks, [1] unpaired tasks, [2] first tasks
-    uint32_t task_cap, un_cap;
-};
-
-struct MidSets {
-    cmc::ChainSet sets[4];
-    int hh[4];
-    cmc::g_u8 s1, s2;
-    int len1, len2;
-};
-__device__ inline void mid_sets(const ReadsDev &rd, uint64_t pair0, uint32_t t, const cm_chain *chains, const int32_t *nchain, const int32_t *high, MidSets &S) {
-    const uint64_t p = pair0 + t;
-    const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
-    S.len1 = (int)(a1 - a0);
-    S.len2 = (int)(b1 - b0);
-    S.s1 = (cmc::g_u8)(rd.seq1 + a0);
-    S.s2 = (cmc::g_u8)(rd.seq2 + b0);
-    for (int x = 0; x < 4; ++x) {
-        const uint64_t r = (uint64_t)t * 4 + x;
-        S.sets[x].ch = (cmc::g_chain)(chains + r * CM_BESTCHAINLIM);
-        S.sets[x].n = nchain[r];
-        S.hh[x] = high[r];
-    }
-}
-// Tasks per wave: a wave's time is roughly the sum of the distinct paths its lanes take, and these launches rarely
-// fill the chip, so the tasks are spread over all the waves of the grid (4..64 lanes in use per wave).
-__device__ inline uint32_t mid_group(uint32_t n, uint32_t n_blocks) {
-    uint32_t g = (n + n_blocks - 1) / n_blocks;
-    g = g < 4u ? 4u : g;
-    uint32_t p2 = 4u;
-    while (p2 < g && p2 < 64u) p2 <<= 1;
-    return p2;
-}
-// chain sets / reads of the attempt (process_read, src/filter.cpp:201-240)
-__device__ inline void mid_attempt(const MidSets &S, bool r1_fwd, cmc::ChainSet &fwd, cmc::Read &frd, cmc::ChainSet &bwd, cmc::Read &brd) {
-    fwd = r1_fwd ? S.sets[0] : S.sets[2];
-    bwd = r1_fwd ? S.sets[3] : S.sets[1];
-    frd = r1_fwd ? cmc::Read{S.s1, S.len1, 0} : cmc::Read{S.s2, S.len2, 0};
-    brd = r1_fwd ? cmc::Read{S.s2, S.len2, 1} : cmc::Read{S.s1, S.len1, 1};
-}
-
-// phase 0: start; phase 1 / 2: close attempt 0 / 1 (leftover_type), then plan the next attempt or finish the pair
-__global__ void __launch_bounds__(BLK) k_mid_plan(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *mlist, const unsigned int *n_mid, MidBufs B,
-                                                 const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
-                                                 uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters, int phase,
-                                                 uint32_t *hlist, unsigned int *n_heavy) {
-    const uint32_t m = blockIdx.x * BLK + threadIdx.x;
-    if (m >= *n_mid) return;
-    const Core c = cmc::to_core(kc);
-    MidPair &P = B.pairs[m];
-    MidSets S;
-    if (phase == 0) {
-        P.t = mlist[m];
-        P.mr = state[pair0 + P.t];
-        P.st = -1;
-        P.attempt = 0;
-        P.ntask = P.n_un = 0;
-        P.leftover = P.returned = P.written = P.need_rest = 0;
-    }
-    if (P.st == -2) return;
-    mid_sets(rd, pair0, P.t, chains, nchain, high, S);
-    const uint64_t p = pair0 + P.t;
-    if (phase == 0) {
-        const int n1 = S.sets[0].n + S.sets[1].n, n2 = S.sets[2].n + S.sets[3].n;
-        if (n1 + n2 <= 0) {
-            P.st = ((S.hh[0] + S.hh[1] > 0) && (S.hh[2] + S.hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
-            cmc::mr_update_type(P.mr, P.st);
-        } else if (n1 <= 0 || n2 <= 0) {
-            P.st = CM_OEANCH;
-            cmc::mr_update_type(P.mr, P.st);
-        } else {
-            const float fc1 = S.sets[0].n > 0 ? S.sets[0].ch[0].score : 0.f, bc1 = S.sets[1].n > 0 ? S.sets[1].ch[0].score : 0.f;
-            const float fc2 = S.sets[2].n > 0 ? S.sets[2].ch[0].score : 0.f, bc2 = S.sets[3].n > 0 ? S.sets[3].ch[0].score : 0.f;
-            P.first = (fc1 + bc2) >= (fc2 + bc1);
-        }
-    } else if (P.st < 0) {
-        // close the attempt: unpaired-chain outcomes -> leftover_type (mates_wave tail)
-        int min_ret1 = P.min_ret1, min_ret2 = P.min_ret2, g1 = P.g1, g2 = P.g2;
-        if (P.n_un) {
-            int exf = 99, exb = 99, gf = 0, gb = 0;
-            bool do_f = false, do_b = false;
-            for (uint32_t u = 0; u < P.n_un; ++u) {
-                const MidUn &U = B.un[P.un_base + u];
-                const MidUnRes &R = B.unres[P.un_base + u];
-                if (U.back) {
-                    do_b = true;
-                    exb = R.ex < exb ? R.ex : exb;
-                    if (U.k == 0) gb = R.genic;
-                } else {
-                    do_f = true;
-                    exf = R.ex < exf ? R.ex : exf;
-                    if (U.k == 0) gf = R.genic;
-                }
-            }
-            if (do_f) {
-                min_ret1 = exf < min_ret1 ? exf : min_ret1;
-                g1 = gf;
-            }
-            if (do_b) {
-                min_ret2 = exb < min_ret2 ? exb : min_ret2;
-                g2 = gb;
-            }
-            cmc::mr_update_type(P.mr, cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0));
-        } else if (P.leftover) {         // the attempt reached the leftover stage without extensions to run
-            cmc::mr_update_type(P.mr, cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0));
-        }
-        if (c.P.scan_level == 0 && P.mr.type == CM_CONCRD && P.returned) P.st = CM_CONCRD;
-        if (P.st < 0) {
-            if (phase == 2) P.st = P.mr.type;
-            else P.attempt = 1;
-        }
-    }
-    if (P.st >= 0) {                     // finish_round + write-back (once)
-        if (!P.written) {
-            uint8_t act = 1;
-            cm_mapped_read mr = P.mr;
-            cmc::finish_round(c, P.st, is_last, S.len1, S.len2, mr, act);
-            state[p] = mr;
-            active[p] = act;
-            cat[p] = P.st;
-            atomicAdd(&counters[3], 1ull);
-            P.written = 1;
-        }
-        P.ntask = P.n_un = 0;
-        return;
-    }
-    if (phase == 2) return;
-    // ---- plan the attempt: pairing predicate (pair_chains fused into process_mates, pass 1)
-    P.r1_fwd = (P.attempt == 0) == (P.first != 0);
-    cmc::ChainSet fwd, bwd;
-    cmc::Read frd, brd;
-    mid_attempt(S, P.r1_fwd != 0, fwd, frd, bwd, brd);
-    const int kmer = c.P.kmer;
-    const int saved_type = P.mr.type;
-    int fe[CM_BESTCHAINLIM], re[CM_BESTCHAINLIM];
-    for (int i = 0; i < fwd.n; ++i) fe[i] = cmc::overlap(c, fwd.ch[i].rpos[0]);
-    for (int j = 0; j < bwd.n; ++j) re[j] = cmc::overlap(c, bwd.ch[j].rpos[0]);
-    uint32_t ptype[(MID_MAX_T * 2 + 31) / 32 + 1];
-    for (unsigned x = 0; x < sizeof(ptype) / sizeof(ptype[0]); ++x) ptype[x] = 0;
-    uint32_t tids[cmc::MAX_TID];
-    uint32_t fp = 0, bp = 0, nt = 0;
-    for (int i = 0; i < fwd.n; ++i)
-        for (int j = 0; j < bwd.n; ++j) {
-            const cmc::CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-            const uint32_t code = cmc::pair_code(c, F, R, fe[i], re[j], saved_type, tids, (cmc::g_err)err);
-            if (code) {
-                const int idx = i * bwd.n + j;
-                ptype[idx >> 4] |= code << ((idx & 15) * 2);
-                fp |= 1u << i;
-                bp |= 1u << j;
-                ++nt;
-            }
-        }
-    P.fp = fp;
-    P.bp = bp;
-    P.ntask = nt;
-    P.n_un = 0;
-    P.min_ret1 = P.min_ret2 = CM_ORPHAN;
-    P.g1 = P.g2 = 0;
-    P.leftover = P.returned = P.need_rest = 0;
-    P.task_base = 0;
-    if (nt) {
-        const uint32_t base = atomicAdd(&B.ctr[0], nt);
-        if (base + nt > B.task_cap) {            // does not fit: k_pair_heavy maps this pair from scratch
-            P.st = -2;
-            P.ntask = 0;
-            hlist[atomicAdd(n_heavy, 1u)] = P.t;
-            return;
-        }
-        P.task_base = base;
-        uint32_t w = base;
-        for (int i = 0; i < fwd.n; ++i)
-            for (int j = 0; j < bwd.n; ++j) {
-                const int idx = i * bwd.n + j;
-                const uint32_t code = (ptype[idx >> 4] >> ((idx & 15) * 2)) & 3u;
-                if (code) B.tasks[w++] = MidTask{m, (uint16_t)i, (uint16_t)j, code};
-            }
-        B.first[atomicAdd(&B.ctr[2], 1u)] = base;
-    }
-}
-
-__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_mid_tasks(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
-                                                        const int32_t *high, int *err, int str_cap, int stage) {
-    // stage 0: the first pair task of every pair (the reference stops at the first CONCRD pair, usually this one);
-    // stage 1: the remaining tasks of the pairs whose first task did not end the attempt
-    extern __shared__ uint32_t lds_words[];
-    CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
-    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
-#if defined(CM_DIAG)
-    cmc::Tick tick{};
-    tick.w = nullptr;
-    tick.wave_on = 0;
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
-#else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
-#endif
-    const uint32_t n_all = B.ctr[0] < B.task_cap ? B.ctr[0] : B.task_cap;
-    const uint32_t n = stage == 0 ? B.ctr[2] : n_all;
-    const Core c = cmc::to_core(kc);
-    const cmc::Ext ext(c, sm);
-    const int kmer = c.P.kmer;
-    const uint32_t G = mid_group(n, gridDim.x);
-    if (threadIdx.x >= G) return;
-    for (uint32_t k = blockIdx.x * G + threadIdx.x; k < n; k += gridDim.x * G) {
-        const uint32_t x = stage == 0 ? B.first[k] : k;
-        const MidTask T = B.tasks[x];
-        const MidPair &P = B.pairs[T.m];
-        if (P.st != -1) continue;
-        if (stage == 1 && (!P.need_rest || x == P.task_base)) continue;
-        MidSets S;
-        mid_sets(rd, pair0, P.t, chains, nchain, high, S);
-        cmc::ChainSet fwd, bwd;
-        cmc::Read frd, brd;
-        mid_attempt(S, P.r1_fwd != 0, fwd, frd, bwd, brd);
-        uint32_t tids[cmc::MAX_TID];
-        int n_tid = 0;
-        if (T.code == 1) n_tid = cmc::common_tids(c, cmc::overlap(c, fwd.ch[T.i].rpos[0]), cmc::overlap(c, bwd.ch[T.j].rpos[0]), tids, (cmc::g_err)err);
-        const cmc::CH F{fwd.ch + T.i, kmer}, R{bwd.ch + T.j, kmer};
-        cmc::MM r1, r2;
-        bool il, ok;
-        int row;
-        cmc::extend_task(c, ext, F, R, tids, n_tid, frd, brd, r1, r2, il, ok, row);
-        HRes &o = B.res[x];
-        o.r1 = r1;
-        o.r2 = r2;
-        o.row = row;
-        o.pair_type = (int)T.code - 1;
-        o.ok = ok;
-        o.is_left = il;
-    }
-}
-
-__global__ void __launch_bounds__(BLK) k_mid_fold(KCore kc, const unsigned int *n_mid, MidBufs B, const int32_t *nchain, int stage) {
-    const uint32_t m = blockIdx.x * BLK + threadIdx.x;
-    if (m >= *n_mid) return;
-    MidPair &P = B.pairs[m];
-    if (P.st != -1) return;
-    if (stage == 1 && !P.need_rest) return;
-    const Core c = cmc::to_core(kc);
-    cm_mapped_read mr = P.mr;
-    int min_ret1 = P.min_ret1, min_ret2 = P.min_ret2, g1 = P.g1, g2 = P.g2;
-    bool early = false;
-    const uint32_t y0 = stage == 0 ? 0u : 1u, y1 = stage == 0 ? (P.ntask < 1u ? P.ntask : 1u) : P.ntask;
-    for (uint32_t y = y0; y < y1; ++y) {
-        const HRes &h = B.res[P.task_base + y];
-        const cmc::MM r1 = h.r1, r2 = h.r2;
-        if (cmc::fold_task(c, r1, r2, h.is_left != 0, h.ok != 0, h.row, h.pair_type, P.r1_fwd != 0, mr)) {
-            early = true;
-            break;
-        }
-        min_ret1 = r1.type < min_ret1 ? r1.type : min_ret1;
-        min_ret2 = r2.type < min_ret2 ? r2.type : min_ret2;
-        g1 = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
-        g2 = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
-    }
-    P.mr = mr;
-    P.min_ret1 = min_ret1;
-    P.min_ret2 = min_ret2;
-    P.g1 = (uint8_t)g1;
-    P.g2 = (uint8_t)g2;
-    P.n_un = 0;
-    P.leftover = 0;
-    P.need_rest = 0;
-    P.returned = 1;                      // every exit of process_mates returns mr.type (or CONCRD from inside the loop)
-    if (early) {                          // process_mates returned CONCRD from inside the loop
-        if (c.P.scan_level == 0) P.st = CM_CONCRD;       // fold_task only returns true at scan level 0
-        return;
-    }
-    if (stage == 0 && P.ntask > 1) {      // more pair tasks to extend and fold before the attempt can close
-        P.need_rest = 1;
-        P.returned = 0;
-        return;
-    }
-    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return;
-    // unpaired-chain extensions (filter.cpp:356-385)
-    const uint32_t t4 = P.t * 4u;
-    const int fn = P.r1_fwd ? nchain[t4 + 0] : nchain[t4 + 2], bn = P.r1_fwd ? nchain[t4 + 3] : nchain[t4 + 1];
-    const uint32_t fun = ~P.fp & (fn >= 32 ? 0xffffffffu : ((1u << fn) - 1u));
-    const uint32_t bun = ~P.bp & (bn >= 32 ? 0xffffffffu : ((1u << bn) - 1u));
-    const bool do_f = min_ret1 != CM_CONCRD && fun != 0, do_b = min_ret2 != CM_CONCRD && bun != 0;
-    if (!cmc::leftovers_matter(mr.type, min_ret1, do_f, min_ret2, do_b)) return;
-    P.leftover = 1;                      // leftover_type applies even when nothing is left to extend
-    const uint32_t nu = (do_f ? (uint32_t)__popc(fun) : 0u) + (do_b ? (uint32_t)__popc(bun) : 0u);
-    if (nu == 0) return;
-    const uint32_t base = atomicAdd(&B.ctr[1], nu);
-    if (base + nu > B.un_cap) {
-        P.st = -3;                       // resolved by k_mid_overflow
-        return;
-    }
-    P.un_base = base;
-    P.n_un = nu;
-    uint32_t w = base;
-    if (do_f) {
-        int k = 0;
-        for (uint32_t mm = fun; mm; mm &= mm - 1) B.un[w++] = MidUn{m, 0, (uint8_t)(__ffs((int)mm) - 1), (uint8_t)(k++), 0};
-    }
-    if (do_b) {
-        int k = 0;
-        for (uint32_t mm = bun; mm; mm &= mm - 1) B.un[w++] = MidUn{m, 1, (uint8_t)(__ffs((int)mm) - 1), (uint8_t)(k++), 0};
-    }
-}
-
-// pairs whose unpaired tasks did not fit (st == -3): hand them to k_pair_heavy
-__global__ void __launch_bounds__(BLK) k_mid_overflow(const unsigned int *n_mid, MidBufs B, uint32_t *hlist, unsigned int *n_heavy) {
-    const uint32_t m = blockIdx.x * BLK + threadIdx.x;
-    if (m >= *n_mid) return;
-    MidPair &P = B.pairs[m];
-    if (P.st != -3) return;
-    P.st = -2;
-    P.ntask = P.n_un = 0;
-    hlist[atomicAdd(n_heavy, 1u)] = P.t;
-}
-
-__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_mid_unpair(KCore kc, ReadsDev rd, uint64_t pair0, MidBufs B, const cm_chain *chains, const int32_t *nchain,
-                                                         const int32_t *high, int *err, int str_cap) {
-    extern __shared__ uint32_t lds_words[];
-    CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
-    const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
-#if defined(CM_DIAG)
-    cmc::Tick tick{};
-    tick.w = nullptr;
-    tick.wave_on = 0;
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
-#else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
-#endif
-    const uint32_t n = B.ctr[1] < B.un_cap ? B.ctr[1] : B.un_cap;
-    const Core c = cmc::to_core(kc);
-    const cmc::Ext ext(c, sm);
-    const uint32_t G = mid_group(n, gridDim.x);
-    if (threadIdx.x >= G) return;
-    for (uint32_t x = blockIdx.x * G + threadIdx.x; x < n; x += gridDim.x * G) {
-        const MidUn U = B.un[x];
-        const MidPair &P = B.pairs[U.m];
-        if (P.st != -1) continue;
-        MidSets S;
-        mid_sets(rd, pair0, P.t, chains, nchain, high, S);
-        cmc::ChainSet fwd, bwd;
-        cmc::Read frd, brd;
-        mid_attempt(S, P.r1_fwd != 0, fwd, frd, bwd, brd);
-        const cmc::CH ch{(U.back ? bwd.ch : fwd.ch) + U.ci, c.P.kmer};
-        cmc::MM mm = cmc::mm_init(c);
-        MidUnRes r;
-        r.ex = ext.chain_both_sides(ch, U.back ? brd : frd, mm, U.back ? -1 : 1);
-        r.genic = 0;
-        if (U.k == 0) {
-            cmc::overlap_to_spos(c, mm);
-            cmc::overlap_to_epos(c, mm);
-            r.genic = (mm.exons_spos >= 0) || (mm.exons_epos >= 0);
-        }
-        B.unres[x] = r;
-    }
-}
-
 __global__ void __launch_bounds__(BLK) k_active_cls(const uint8_t *active, uint64_t n, int8_t *cls) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i < n) cls[i] = active[i] ? 0 : -2;
@@ -1371,7 +979,7 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 struct cm_ctx {
     cm_params P{};
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // heavy / mid work of a stage, concurrent with the light kernel on `stream`
+    hipStream_t stream2 = nullptr;            // heavy work of a stage, concurrent with the light kernel on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
     std::string err = "";
@@ -1405,8 +1013,7 @@ struct cm_ctx {
     int8_t *d_col_cls = nullptr;
     uint32_t *d_col_perm = nullptr;
     unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
-    uint32_t *d_hlist = nullptr, *d_mlist = nullptr;
-    MidBufs mid{};                 // task pipeline of the mid pairs (k_mid_*)
+    uint32_t *d_hlist = nullptr;
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -1463,7 +1070,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_mlist); dfree(c->mid.pairs); dfree(c->mid.tasks); dfree(c->mid.res); dfree(c->mid.un); dfree(c->mid.unres); dfree(c->mid.first); dfree(c->mid.ctr);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
@@ -1579,7 +1186,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr);
+                           (uint32_t *)nullptr);
         ctx->launches[5] += 4;
     }
     for (auto &rg : ranges) {
@@ -1863,15 +1470,6 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_mlist, (size_t)tile * 4));
-    ctx->mid.task_cap = ctx->mid.un_cap = tile < (1u << 20) ? (tile < 4096u ? 4096u : tile) : (1u << 20);
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.pairs, (size_t)tile * sizeof(MidPair)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.tasks, (size_t)ctx->mid.task_cap * sizeof(MidTask)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.res, (size_t)ctx->mid.task_cap * sizeof(HRes)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.un, (size_t)ctx->mid.un_cap * sizeof(MidUn)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.unres, (size_t)ctx->mid.un_cap * sizeof(MidUnRes)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.first, (size_t)tile * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->mid.ctr, 4 * sizeof(unsigned int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
@@ -1916,43 +1514,19 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
-            static const int mid_on = !(getenv("CM_MID") && getenv("CM_MID")[0] == '0');
-            static const int heavy_cost = (getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST) | (mid_on << 16);
+            static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
                                ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, (1 << HEAVY_CLS) | (1 << MID_CLS), N_CLS);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
-                               ctx->d_hlist, ctx->d_mlist);
+                               ctx->d_hlist);
             ctx->launches[5] += 4;
             }
-            // The mid / heavy pairs go to the second stream: their kernels are short dependency chains (a wave's latency
-            // each) that fit into the slots the light kernel leaves, instead of queueing behind it.
+            // The heavy pairs go to the second stream: one wave per pair fits into the slots the light kernel leaves
+            // instead of queueing behind it.
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            {   // mid pairs: two attempts x (plan, first task, fold, other tasks, fold, unpaired) + the closing plan
-            hipStream_t s2 = ctx->stream2;
-            Timer t(ctx, 7, s2);
-            const unsigned *n_mid = ctx->d_cls_ctr + MID_CLS;
-            unsigned *n_heavy = ctx->d_cls_ctr + HEAVY_CLS;
-            const dim3 gp((nt + BLK - 1) / BLK), gt(nt < 2048u * BLK_PAIR ? (nt + BLK_PAIR - 1) / BLK_PAIR : 2048u);
-            for (int phase = 0; phase < 3; ++phase) {
-                HIPCHK(ctx, hipMemsetAsync(ctx->mid.ctr, 0, 4 * sizeof(unsigned int), s2));
-                hipLaunchKernelGGL(k_mid_plan, gp, dim3(BLK), 0, s2, core, rd, p0, ctx->d_mlist, n_mid, ctx->mid, ctx->d_chains, ctx->d_nchain,
-                                   ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, phase, ctx->d_hlist,
-                                   n_heavy);
-                if (phase == 2) break;
-                for (int stage = 0; stage < 2; ++stage) {
-                    hipLaunchKernelGGL(k_mid_tasks, gt, dim3(BLK_PAIR), lds_bytes, s2, core, rd, p0, ctx->mid, ctx->d_chains, ctx->d_nchain,
-                                       ctx->d_high, ctx->d_err, str_cap, stage);
-                    hipLaunchKernelGGL(k_mid_fold, gp, dim3(BLK), 0, s2, core, n_mid, ctx->mid, ctx->d_nchain, stage);
-                }
-                hipLaunchKernelGGL(k_mid_overflow, gp, dim3(BLK), 0, s2, n_mid, ctx->mid, ctx->d_hlist, n_heavy);
-                hipLaunchKernelGGL(k_mid_unpair, gt, dim3(BLK_PAIR), lds_bytes, s2, core, rd, p0, ctx->mid, ctx->d_chains, ctx->d_nchain, ctx->d_high,
-                                   ctx->d_err, str_cap);
-            }
-            ctx->launches[7] += 15;
-            }
             {
             Timer t(ctx, 4, ctx->stream2);
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
@@ -2030,7 +1604,7 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
-                       ctx->d_col_perm, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                       ctx->d_col_perm, (uint32_t *)nullptr);
     TRACE_PT("pre");
     if (cap)
         hipLaunchKernelGGL(k_gather_active, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,

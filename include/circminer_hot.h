@@ -226,7 +226,8 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 /* ---------------- timing hooks for bench.py (HIP events on the ctx stream) ---------------- */
 /* Milliseconds spent in each kernel class since the last cm_prof_reset(), and launch counts:
  * [0]=k_seed [1]=k_chain (light problems) [2]=k_pair (light pairs) [3]=k_scan_* [4]=k_pair_heavy
- * [5]=class / counting-sort kernels [6]=k_chain_heavy [7]=k_mid_* (task pipeline of the mid pairs). */
+ * [5]=class / counting-sort kernels [6]=k_chain_heavy [7]=0.  [1] and [2] are timed up to the join with the second
+ * stream, on which the heavy kernels [6] / [4] run concurrently. */
 int cm_prof_enable(cm_ctx *ctx, int on);
 int cm_prof_reset(cm_ctx *ctx);
 int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]);

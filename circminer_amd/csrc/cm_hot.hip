@@ -706,7 +706,7 @@ struct HeavyLds {
     CM_L uint8_t *codes;     // pairing predicate per (i, j), i-major          [900]
     CM_L uint16_t *list;     // accepted (i, j) in order                        [900]
     CM_L int *fe, *re;       // exon interval of each chain's first fragment    [32] + [32]
-    CM_L HRes *res;          // [64]
+    CM_G HRes *res;          // [64], this block's slice of a global buffer (LDS is what limits this kernel's occupancy)
 };
 
 __device__ inline int nth_set_bit(uint32_t m, int k) {
@@ -843,10 +843,10 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     return mr.type;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
-                                                         int str_cap, unsigned long long *dbg_rows) {
+                                                         int str_cap, unsigned long long *dbg_rows, HRes *hres) {
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
@@ -875,8 +875,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 2) k_pair_heavy(KCore kc, ReadsDev r
 #endif
     CM_L uint8_t *q = base + lds_stage_bytes;
     HeavyLds H;
-    H.res = (CM_L HRes *)q;
-    q += ((sizeof(HRes) * 64 + 15) / 16) * 16;
+    H.res = (CM_G HRes *)(hres + (size_t)blockIdx.x * 64);
     H.fe = (CM_L int *)q;
     H.re = H.fe + 32;
     q += 64 * sizeof(int);
@@ -1014,6 +1013,7 @@ struct cm_ctx {
     uint32_t *d_col_perm = nullptr;
     unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
     uint32_t *d_hlist = nullptr;
+    HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -1070,7 +1070,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
@@ -1470,6 +1470,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hres, (size_t)4096 * 64 * sizeof(HRes)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
@@ -1510,7 +1511,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
 #else
             const size_t lds_bytes = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
 #endif
-            const size_t lds_heavy = lds_bytes + ((sizeof(HRes) * 64 + 15) / 16) * 16 + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
+            const size_t lds_heavy = lds_bytes + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
@@ -1532,7 +1533,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
             hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS,
                                ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
-                               ctx->d_counters, str_cap, ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr);
+                               ctx->d_counters, str_cap, ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres);
             ++ctx->launches[4];
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));

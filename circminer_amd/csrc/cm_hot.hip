@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(BLK_CHAIN, CM_CHAIN_WAVES) k_chain(KCore kc, R
 }
 
 #ifndef CM_PAIR_WAVES
-#define CM_PAIR_WAVES 3       // waves per SIMD the pair kernels are compiled for (LDS: 2 x lbuf_bytes x 64 per wave)
+#define CM_PAIR_WAVES 4       // waves per SIMD the pair kernels are compiled for (128 VGPRs; LDS: 2 x lbuf_bytes x 64 per wave)
 #endif
 __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
@@ -1505,7 +1505,8 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
         if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
         {
             // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
-            const int str_cap = ((ctx->max_len + ctx->P.band + 4 + 7) / 8) * 8;
+            // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
+            const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
 #if defined(CM_STAGE_PRIVATE)
             const size_t lds_bytes = 0;
 #else

@@ -47,11 +47,7 @@ extern "C" unsigned long long cm_stats[16];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CM_G __attribute__((address_space(1)))
 #define CM_L __attribute__((address_space(3)))
-#if defined(CM_STAGE_PRIVATE)
-#define CM_S __attribute__((address_space(5)))      // DP staging buffers in private (scratch) memory
-#else
-#define CM_S CM_L                                   // DP staging buffers in LDS, word-interleaved per lane
-#endif
+#define CM_S CM_L                                   // DP staging buffers: LDS, word-interleaved per lane
 #else
 #define CM_G
 #define CM_L
@@ -172,26 +168,11 @@ CM_HD inline int cabs(int a) { return a < 0 ? -a : a; }
 // string views: reads (either orientation, any slice, optionally reversed), genome windows,
 // and the all-NUL window that pac2char(start == 0) yields in the reference.
 // ------------------------------------------------------------------------------------------
-CM_HD inline uint8_t comp_base(uint8_t ch) {      // FASTQParser::set_comp, src/fastq_parser.cpp:141-153
-    switch (ch) {
-        case 'A': case 'a': return 'T';
-        case 'C': case 'c': return 'G';
-        case 'G': case 'g': return 'C';
-        case 'T': case 't': return 'A';
-        case 'N': case 'n': return 'N';
-        default: return 0;
-    }
-}
 struct SV {
     g_u8 p;
     int32_t off;
     int32_t step;     // +1 / -1
     int32_t mode;     // 0 plain, 1 complemented, 2 all-NUL
-    CM_HD inline uint8_t at(int i) const {
-        if (mode == 2) return 0;
-        uint8_t x = p[off + i * step];
-        return mode == 1 ? comp_base(x) : x;
-    }
     CM_HD inline SV sub(int a) const { return SV{p, off + a * step, step, mode}; }          // view starting at a
     CM_HD inline SV rev(int m) const { return SV{p, off + (m - 1) * step, -step, mode}; }   // first m chars reversed
 };
@@ -202,30 +183,6 @@ struct Read {             // one mate in one orientation
     CM_HD inline SV view() const { return rc ? SV{p, len - 1, -1, 1} : SV{p, 0, 1, 0}; }
 };
 
-CM_HD inline int base_code_strict(uint8_t ch) {   // hashVal / checkSumVal alphabet: upper-case only
-    switch (ch) {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T': return 3;
-        default: return -1;
-    }
-}
-CM_HD inline int base_code_ci(uint8_t ch) {       // ScoreMatrix::init alphabet, src/align.cpp:745-759
-    switch (ch) {
-        case 'A': case 'a': return 0;
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        default: return -1;
-    }
-}
-CM_HD inline bool same_base(uint8_t a, uint8_t b) {
-    int x = base_code_ci(a);
-    return x >= 0 && x == base_code_ci(b);
-}
-CM_HD inline int diff_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? 0 : 1; }
-CM_HD inline int score_ch(uint8_t a, uint8_t b) { return same_base(a, b) ? SC_MAT : SC_MIS; }
 
 // ------------------------------------------------------------------------------------------
 // K1 body: one k-mer probe (A1-A3)
@@ -721,7 +678,7 @@ CM_HD inline bool cand_less(const Cand &a, const Cand &b) {     // AlignCandid::
 // (the left-hand variants stage reversed views).  On the GPU the buffer is LDS, word-interleaved
 // across the 64 lanes of the wave (code i of lane l lives in word (i/8)*64 + l), so concurrent
 // per-lane accesses fall in distinct banks; on the host build it is a plain array.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CM_STAGE_PRIVATE)
+#if defined(__HIP_DEVICE_COMPILE__)
 constexpr int LSTRIDE = 64;
 #else
 constexpr int LSTRIDE = 1;

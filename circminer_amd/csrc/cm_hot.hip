@@ -33,7 +33,6 @@ constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (wo
 constexpr int BLK = 256;
 constexpr int BLK_CHAIN = 64;
 constexpr int BLK_PAIR = 64;
-constexpr int STAGE_WORDS = 42;                  // private staging (CM_STAGE_PRIVATE): 328 chars per string as nibbles (max_read_len 300 + band + slack)
 // bytes one staged string of `cap` characters takes per lane (cm_core.h LBuf: eight codes per word + one spare word)
 __host__ __device__ constexpr int lbuf_bytes(int cap) { return (cap / 8 + 1) * 4; }
 
@@ -200,16 +199,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
                                                    const uint32_t *perm, const unsigned int *n_light) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
-#if defined(CM_STAGE_PRIVATE)
-    uint32_t stage_words[2 * STAGE_WORDS];
-    CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
-    str_cap = 8 * (STAGE_WORDS - 1);
-    const int str_stride = 4 * STAGE_WORDS;
-#else
     extern __shared__ uint32_t lds_words[];
     CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * threadIdx.x;
     const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
-#endif
 #if defined(CM_DIAG)
     __shared__ unsigned long long tick_w[65];
     cmc::Tick tick;
@@ -584,7 +576,7 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
         if (k == c) rank_in_wave = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
     }
 }
-__global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, ReadsDev rd, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
+__global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
                                                  const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
@@ -850,17 +842,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
-#if defined(CM_STAGE_PRIVATE)
-    uint32_t stage_words[2 * STAGE_WORDS];
-    CM_S uint8_t *lane_base = (CM_S uint8_t *)stage_words;
-    const int lds_stage_bytes = 0;
-    str_cap = 8 * (STAGE_WORDS - 1);
-    const int str_stride = 4 * STAGE_WORDS;
-#else
     CM_S uint8_t *lane_base = base + 4 * lane;
     const int lds_stage_bytes = 2 * lbuf_bytes(str_cap) * BLK_PAIR;
     const int str_stride = lbuf_bytes(str_cap) * BLK_PAIR;
-#endif
 #if defined(CM_DIAG)
     __shared__ unsigned long long tick_w[65];
     cmc::Tick tick{};
@@ -1507,17 +1491,13 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
             // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
             const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
-#if defined(CM_STAGE_PRIVATE)
-            const size_t lds_bytes = 0;
-#else
             const size_t lds_bytes = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
-#endif
             const size_t lds_heavy = lds_bytes + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
             static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
-            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
+            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
                                ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost);
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);

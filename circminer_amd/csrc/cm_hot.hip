@@ -86,33 +86,30 @@ __global__ void __launch_bounds__(BLK) k_seed(KCore kc, ReadsDev rd, const uint8
 constexpr int SCAN_T = 256;
 constexpr int SCAN_ELEMS = 1024;       // 4 per thread
 __global__ void __launch_bounds__(SCAN_T) k_scan_a(const uint32_t *scnt, int S, uint32_t n, unsigned long long *out, unsigned long long *bsum) {
+    // element k * SCAN_T + t of the block belongs to thread t: consecutive lanes read consecutive problems
+    // (28-byte stride, the S loads of a lane reuse its sectors) instead of four problems per lane
     __shared__ unsigned long long sh[SCAN_T];
-    const uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
-    uint32_t v[4];
-    unsigned long long t = 0;
+    const uint32_t base = blockIdx.x * SCAN_ELEMS;
+    unsigned long long run = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SCAN_ELEMS / SCAN_T; ++k) {
+        const uint32_t r = base + k * SCAN_T + threadIdx.x;
         uint32_t c = 0;
-        if (base + k < n)
-            for (int s = 0; s < S; ++s) c += scnt[(uint64_t)(base + k) * S + s];
-        v[k] = c;
-        t += c;
-    }
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    for (int d = 1; d < SCAN_T; d <<= 1) {
-        const unsigned long long x = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0ull;
+        if (r < n)
+            for (int s = 0; s < S; ++s) c += scnt[(uint64_t)r * S + s];
+        sh[threadIdx.x] = c;
         __syncthreads();
-        sh[threadIdx.x] += x;
+        for (int d = 1; d < SCAN_T; d <<= 1) {
+            const unsigned long long x = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0ull;
+            __syncthreads();
+            sh[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (r < n) out[r] = run + sh[threadIdx.x] - c;
+        run += sh[SCAN_T - 1];
         __syncthreads();
     }
-    unsigned long long run = threadIdx.x ? sh[threadIdx.x - 1] : 0ull;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == SCAN_T - 1) bsum[blockIdx.x] = sh[SCAN_T - 1];
+    if (threadIdx.x == 0) bsum[blockIdx.x] = run;
 }
 __global__ void __launch_bounds__(1024) k_scan_b(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
     __shared__ unsigned long long part[1024];

@@ -87,3 +87,54 @@ def first_diff(a, b):
         if a[i].tobytes() != b[i].tobytes():
             return i, a[i], b[i]
     return None
+
+
+class _Shim:
+    """DataSet-like wrapper: same index / annotation, another read batch."""
+
+    def __init__(self, ds, batch):
+        self.d, self.hi, self.kmer, self.batch = ds.d, ds.hi, ds.kmer, batch
+
+
+@pytest.fixture(scope="session")
+def ds_dirty(ds_tiny2r):
+    """Edge cases of the read side on the two-contig data set: ragged lengths (0 .. 300 bp, i.e. no seed at all up to
+    15 seeds), N runs, lower-case stretches (valid for the DPs, invalid for forward-strand seeds, valid again on the
+    reverse strand after FASTQParser::set_comp), reads cut inside a seed, one mate much shorter than the other."""
+    d = ds_tiny2r.d
+    rng = np.random.default_rng(99)
+    n = 600
+    src = rng.integers(0, d.seq1.shape[0], n)
+    s1, s2, l1, l2 = [], [], [], []
+
+    def mangle(read, i):
+        r = read.copy()
+        k = i % 12
+        if k == 0:
+            r = r[:0]                                   # empty read
+        elif k == 1:
+            r = r[:int(rng.integers(1, 20))]            # shorter than one seed
+        elif k == 2:
+            r = r[:int(rng.integers(20, 40))]           # exactly one seed
+        elif k == 3:
+            r = r[:int(rng.integers(41, 150))]          # cut inside a seed
+        elif k == 4:
+            a = int(rng.integers(0, 120)); r[a:a + int(rng.integers(1, 25))] = ord("N")
+        elif k == 5:
+            a = int(rng.integers(0, 100)); r[a:a + 40] = np.frombuffer(bytes(r[a:a + 40]).lower(), np.uint8)
+        elif k == 6:
+            r = np.frombuffer(bytes(r).lower(), np.uint8).copy()
+        elif k == 7:
+            r = np.concatenate([r, r])                  # 300 bp: 15 seeds per orientation
+        elif k == 8:
+            r = np.concatenate([r, r[:int(rng.integers(1, 140))]])
+        elif k == 9:
+            r[int(rng.integers(0, 150))] = ord("n")
+        return r
+
+    for i in range(n):
+        a, b = mangle(d.seq1[src[i]], i), mangle(d.seq2[src[i]], (i * 7 + 3) % 12 + 12 * (i % 5 == 0) * 0)
+        s1.append(a); s2.append(b); l1.append(len(a)); l2.append(len(b))
+    batch = cl.ReadBatch(np.concatenate(s1) if sum(l1) else np.zeros(0, np.uint8), np.concatenate(s2) if sum(l2) else np.zeros(0, np.uint8),
+                         np.array(l1), np.array(l2))
+    return _Shim(ds_tiny2r, batch)

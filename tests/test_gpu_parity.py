@@ -243,3 +243,21 @@ def test_multi_tile_batches_match_the_oracle(ds_small, monkeypatch):
     monkeypatch.setenv("CM_TILE_PAIRS", "4096")
     P = cl.default_params(kmer=ds_small.kmer)
     _run_all_rounds(ds_small, P)
+
+
+def test_ragged_and_dirty_reads(ds_dirty):
+    """empty / sub-seed / ragged / 300-bp reads, N runs and lower-case stretches (see conftest.ds_dirty)"""
+    _run_all_rounds(ds_dirty, cl.default_params(kmer=ds_dirty.kmer))
+    _run_all_rounds(ds_dirty, cl.default_params(kmer=ds_dirty.kmer, scan_level=2, max_ed=6))
+
+
+def test_empty_batch_is_a_no_op(ds_tiny):
+    hp = cl.HotPath(cl.default_params())
+    hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
+    b = cl.ReadBatch(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int64))
+    hp.upload(b)
+    hp.map_round(0, True)
+    st, cat, act = hp.download()
+    idx, stc = hp.collect_active()
+    assert len(st) == len(cat) == len(act) == len(idx) == 0
+    hp.close()

@@ -57,6 +57,12 @@ def test_map_rounds_param_variants(emu, ds_tiny2r, kw):
     _emu_rounds(emu, ds_tiny2r, cl.default_params(**kw))
 
 
+def test_ragged_and_dirty_reads(emu, ds_dirty):
+    """empty / sub-seed / ragged / 300-bp reads, N runs and lower-case stretches (see conftest.ds_dirty)"""
+    _emu_rounds(emu, ds_dirty, cl.default_params())
+    _emu_rounds(emu, ds_dirty, cl.default_params(scan_level=2, max_ed=6))
+
+
 def test_k22_int16_checksum_quirk(emu, tmp_path_factory):
     """k=22: the reference compares an int16 target with the uint16 checksum (match_read.cpp:77), so
     k-mers whose checksum >= 0x8000 are never found.  Oracle and device code both reproduce it."""

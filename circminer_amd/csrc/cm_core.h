@@ -1998,7 +1998,8 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     for (int i = 0; i < fwd.n; ++i) fe[i] = overlap(c, fwd.ch[i].rpos[0]);
     for (int j = 0; j < bwd.n; ++j) re[j] = overlap(c, bwd.ch[j].rpos[0]);
     uint32_t ptype[(CM_BESTCHAINLIM * CM_BESTCHAINLIM * 2 + 31) / 32];   // 2 bits per (i,j): 0 none, 1..3 = type+1
-    for (unsigned x = 0; x < sizeof(ptype) / sizeof(ptype[0]); ++x) ptype[x] = 0;
+    const int n_ptype = fwd.n > 0 ? (((fwd.n - 1) * CM_BESTCHAINLIM + bwd.n) >> 4) + 1 : 0;      // words the loops below touch
+    for (int x = 0; x < n_ptype; ++x) ptype[x] = 0;
     uint32_t fpaired = 0, bpaired = 0;
     uint32_t tids[MAX_TID];
     for (int i = 0; i < fwd.n; ++i)

@@ -296,6 +296,8 @@ PRESETS = {
     "tiny2r": ([120_000, 90_000], 60.0, 150_000, 6),           # two packed contigs -> two rounds
     "small": ([2_000_000, 1_500_000, 1_000_000], 25.0, 1_100_000_000, 120),
     "chr21": ([46_700_000], 5.5, 1_100_000_000, 2000),         # BASELINE.json configs[1]
+    # one full-size packed contig (hg38 chr1-5 lengths, 1.06 Gbp): the scale of one round of configs[2..4]
+    "contig1g": ([248_000_000, 242_000_000, 198_000_000, 190_000_000, 181_000_000], 5.5, 1_100_000_000, 40000),
 }
 
 

@@ -318,9 +318,6 @@ CM_HD inline uint32_t upper_bound_lookup(const Core &c, uint32_t spos, uint32_t 
     return 0;
 }
 CM_HD inline uint32_t upper_bound(const Core &c, uint32_t spos, uint32_t mlen, uint32_t rlen, uint32_t &max_end, int &ol) {
-#ifdef CM_EXP_NOLOOKUP
-    max_end = 0; ol = -1; return spos + rlen + (uint32_t)c.P.max_ed;
-#endif
     if (bit_at(c.A.near_border_bits, c.A.n_bits, spos)) return upper_bound_lookup(c, spos, mlen, rlen, max_end, ol);
     max_end = 0;
     ol = -1;

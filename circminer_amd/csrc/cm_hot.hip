@@ -283,7 +283,8 @@ struct HeavyChainCtx {
     CM_G int32_t *dpp;
 };
 // evaluates cell (ii, i); returns the number of strict improvements; stores them to ev[] when ev != null
-__device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i, CM_G cmc::Event *ev, double &out_score, int32_t &out_prev) {
+__device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i, CM_G cmc::Event *ev, double &out_score, int32_t &out_prev,
+                                     double &e0, double &e1) {
     const Core &c = *h.c;
     const int kmer = c.P.kmer;
     const uint32_t read_remain = (uint32_t)(h.seq_len - ii * kmer - kmer);
@@ -328,6 +329,8 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
                     ev[n].score = temp_score;
                     ev[n].cell = ((uint32_t)ii << 16) | i;
                 }
+                if (n == 0) e0 = temp_score;           // the first two improvements are handed back: most cells have no more,
+                else if (n == 1) e1 = temp_score;      // and the caller then skips the second (storing) evaluation
                 ++n;
             }
         }
@@ -382,9 +385,9 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
             for (uint32_t i0 = 0; i0 < cn[ii]; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 const bool on = i < cn[ii];
-                double sc = 0;
+                double sc = 0, e0 = 0, e1 = 0;
                 int32_t pv = -1;
-                const uint32_t mine = on ? heavy_cell(H, ii, i, (CM_G cmc::Event *)nullptr, sc, pv) : 0u;
+                const uint32_t mine = on ? heavy_cell(H, ii, i, (CM_G cmc::Event *)nullptr, sc, pv, e0, e1) : 0u;
                 uint32_t total;
                 const uint32_t off = wave_excl_scan(mine, lane, total);
                 if (n_ev + total > cap_ev && !lost) {                 // grow the log (uniform decision)
@@ -405,7 +408,17 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
                     }
                 }
                 if (on) {
-                    if (mine && !lost) heavy_cell(H, ii, i, ev + n_ev + off, sc, pv);
+                    if (mine && !lost) {
+                        CM_G cmc::Event *dst = ev + n_ev + off;
+                        if (mine <= 2) {
+                            dst[0].score = e0;
+                            dst[0].cell = ((uint32_t)ii << 16) | i;
+                            if (mine == 2) {
+                                dst[1].score = e1;
+                                dst[1].cell = ((uint32_t)ii << 16) | i;
+                            }
+                        } else heavy_cell(H, ii, i, dst, sc, pv, e0, e1);
+                    }
                     dps[base[ii] + i] = sc;
                     dpp[base[ii] + i] = pv;
                 }

@@ -27,7 +27,7 @@ print("step ms", [round(x, 1) for x in ts], {k: round(v / 3, 2) for k, v in zip(
 st1, cat1, act1 = hp.download()
 print("types", np.bincount(st1["type"], minlength=14).tolist(), flush=True)
 # parity on a slice (the oracle is single-threaded: ~70 k pairs/s)
-N0 = 20000
+N0 = int(os.environ.get("PARITY_N", "20000"))
 st0, act0 = op.default_state(P, b.n)
 cat0 = op.map_round(P, hi.views[0], hi.annots[0], b, True, st0, act0, 0, N0)
 ok = (cat0[:N0] == cat1[:N0]).all() and (act0[:N0] == act1[:N0]).all() and st0[:N0].tobytes() == st1[:N0].tobytes()

@@ -34,6 +34,8 @@ def emu(built):
     out_dir = os.path.join(ROOT, "tests", "_hostemu")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libcmemu.so")
+    if os.environ.get("CM_EMU_LIB"):           # e.g. an ASan / UBSan build of tests/hostemu.cpp (see tests/diag/asan_emu.sh)
+        so = os.environ["CM_EMU_LIB"]
     srcs = [os.path.join(ROOT, "tests", "hostemu.cpp"), os.path.join(ROOT, "circminer_amd", "csrc", "cm_core.h"),
             os.path.join(ROOT, "include", "circminer_hot.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):

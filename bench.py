@@ -126,10 +126,10 @@ def main():
         hp.reset()
         for ci in range(hi.n_contigs):
             hp.map_round(ci, ci == hi.n_contigs - 1)
-        idx, st = hp.collect_active()          # BSJ hand-off to stage 2 (small D2H; syncs the stream)
+        rec = hp.collect_records(base)         # BSJ hand-off to stage 2: records assembled on the device, one small D2H
         if world > 1:
-            return cdist.gather_bsj(cdist.pack_records(idx + base, st), device=dev)
-        return cdist.pack_records(idx + base, st)
+            return cdist.gather_bsj(rec, device=dev)
+        return rec
 
     def fence():
         hp.sync()

@@ -946,6 +946,15 @@ __global__ void __launch_bounds__(BLK) k_gather_active(const uint32_t *perm, con
     out_state[i] = state[p];
 }
 
+__global__ void __launch_bounds__(BLK) k_gather_records(const uint32_t *perm, const unsigned int *count, unsigned long long cap, const cm_mapped_read *state,
+                                                        unsigned long long index_base, cm_record *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (i >= *count || i >= cap) return;
+    const uint32_t p = perm[i];
+    out[i].pair = index_base + p;
+    out[i].state = state[p];
+}
+
 __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
@@ -1002,6 +1011,8 @@ struct cm_ctx {
     unsigned int *d_cls_ctr = nullptr, *d_blk_cnt = nullptr;
     unsigned long long *d_collect_idx = nullptr;
     cm_mapped_read *d_collect_st = nullptr;
+    cm_record *d_collect_rec = nullptr;
+    uint64_t collect_rec_cap = 0;
     uint64_t collect_cap = 0;
     int8_t *d_col_cls = nullptr;
     uint32_t *d_col_perm = nullptr;
@@ -1065,7 +1076,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
+    dfree(c->d_collect_rec); dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -1568,14 +1579,11 @@ int cm_reads_reset(cm_ctx *ctx) {
 #define TRACE_T0
 #define TRACE_PT(name)
 #endif
-int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n) {
-    if (!ctx || !out_n || (cap && (!out_idx || !out_state))) return CM_EINVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    *out_n = 0;
-    TRACE_T0;
+// stable compaction of the active pairs (block histogram -> scan -> place): ascending pair index, no atomics, no
+// host sort; leaves the permutation in d_col_perm and the count in d_col_ctr[0]
+static int compact_active(cm_ctx *ctx) {
     const uint64_t n = ctx->n_pairs;
-    if (n == 0) return CM_OK;
-    if (n > 0xfffffff0ull) return fail(ctx, CM_ELIMIT, "cm_collect_active: too many pairs");
+    if (n > 0xfffffff0ull) return fail(ctx, CM_ELIMIT, "cm_collect_*: too many pairs");
     const uint32_t nbk = (uint32_t)((n + CLS_T - 1) / CLS_T);
     if (!ctx->d_col_cls) {                        // scratch sized for the whole batch, allocated on first use
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_cls, n));
@@ -1583,6 +1591,31 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
     }
+    hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
+    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
+    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
+                       ctx->d_col_perm, (uint32_t *)nullptr);
+    return CM_OK;
+}
+// count + error flags through the pinned landing zone (one synchronisation)
+static int read_count(cm_ctx *ctx, uint64_t cap, unsigned int *cnt, const char *what) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_col_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *cnt = *(const unsigned int *)ctx->h_pin;
+    if (*(const int *)(ctx->h_pin + 1)) return check_dev_err(ctx);
+    if (*cnt > cap) return fail(ctx, CM_ELIMIT, "%s: %u active pairs > cap %llu", what, *cnt, (unsigned long long)cap);
+    return CM_OK;
+}
+
+int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n) {
+    if (!ctx || !out_n || (cap && (!out_idx || !out_state))) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    *out_n = 0;
+    if (ctx->n_pairs == 0) return CM_OK;
+    int rc = compact_active(ctx);
+    if (rc) return rc;
     if (cap > ctx->collect_cap) {                 // grow-only output staging
         dfree(ctx->d_collect_idx);
         dfree(ctx->d_collect_st);
@@ -1591,30 +1624,45 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_st, cap * sizeof(cm_mapped_read)));
         ctx->collect_cap = cap;
     }
-    // stable compaction (block histogram -> scan -> place): ascending pair index, no atomics, no host sort
-    hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
-    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
-    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
-                       ctx->d_col_perm, (uint32_t *)nullptr);
-    TRACE_PT("pre");
     if (cap)
         hipLaunchKernelGGL(k_gather_active, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
                            (unsigned long long)cap, ctx->d_state, ctx->d_collect_idx, ctx->d_collect_st);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_col_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 1, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    TRACE_PT("launch+cnt");
-    const unsigned int cnt = *(const unsigned int *)ctx->h_pin;
-    if (*(const int *)(ctx->h_pin + 1)) return check_dev_err(ctx);
+    unsigned int cnt = 0;
+    rc = read_count(ctx, cap, &cnt, "cm_collect_active");
     *out_n = cnt;
-    if (cnt > cap) return fail(ctx, CM_ELIMIT, "cm_collect_active: %u active pairs > cap %llu", cnt, (unsigned long long)cap);
+    if (rc) return rc;
     if (cnt) {
         HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->d_collect_idx, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(out_state, ctx->d_collect_st, (size_t)cnt * sizeof(cm_mapped_read), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    TRACE_PT("data");
+    return CM_OK;
+}
+
+int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *out, uint64_t *out_n) {
+    if (!ctx || !out_n || (cap && !out)) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    *out_n = 0;
+    if (ctx->n_pairs == 0) return CM_OK;
+    int rc = compact_active(ctx);
+    if (rc) return rc;
+    if (cap > ctx->collect_rec_cap) {
+        dfree(ctx->d_collect_rec);
+        ctx->collect_rec_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_rec, cap * sizeof(cm_record)));
+        ctx->collect_rec_cap = cap;
+    }
+    if (cap)
+        hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
+                           (unsigned long long)cap, ctx->d_state, (unsigned long long)index_base, ctx->d_collect_rec);
+    unsigned int cnt = 0;
+    rc = read_count(ctx, cap, &cnt, "cm_collect_records");
+    *out_n = cnt;
+    if (rc) return rc;
+    if (cnt) {
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_collect_rec, (size_t)cnt * sizeof(cm_record), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return CM_OK;
 }
 

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import lib as cl
 
-REC_DTYPE = np.dtype([("pair", "<u8"), ("state", cl.MAPPED_DTYPE)])   # 80 bytes
+REC_DTYPE = cl.RECORD_DTYPE        # cm_record: (global pair index, state), 80 bytes
 
 
 def shard_bounds(n_total: int, rank: int, world: int):

@@ -68,6 +68,7 @@ MAPPED_DTYPE = np.dtype([(n, "<u4") for n in ("spos_r1", "spos_r2", "epos_r1", "
                         [("junc_num", "<u2"), ("r1_forward", "u1"), ("r2_forward", "u1"), ("gm_compatible", "u1"),
                          ("pad", "u1", (3,))])
 assert MAPPED_DTYPE.itemsize == C.sizeof(MappedRead) == 72
+RECORD_DTYPE = np.dtype([("pair", "<u8"), ("state", MAPPED_DTYPE)])      # cm_record, 80 bytes
 
 CHAIN_DTYPE = np.dtype([("score", "<f4"), ("chain_len", "<u4"), ("rpos", "<u4", (CM_MAX_CHAIN_FRAGS,)),
                         ("qpos", "<i4", (CM_MAX_CHAIN_FRAGS,))])
@@ -149,6 +150,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_sync": (C.c_int, [vp]),
         "cm_reads_reset": (C.c_int, [vp]),
         "cm_collect_active": (C.c_int, [vp, C.c_uint64, vp, vp, pp(C.c_uint64)]),
+        "cm_collect_records": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, pp(C.c_uint64)]),
         "cm_host_alloc": (C.c_int, [vp, C.c_uint64, pp(vp)]),
         "cm_host_free": (C.c_int, [vp, vp]),
         "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
@@ -188,7 +190,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
@@ -436,6 +438,17 @@ class HotPath:
         self._chk(self.L.cm_collect_active(self.h, cap, self._col_idx.ctypes.data, self._col_st.ctypes.data, C.byref(n)), "cm_collect_active")
         return self._col_idx[:n.value], self._col_st[:n.value]     # views: valid until the next call
 
+    def collect_records(self, index_base=0, cap=None):
+        """Active pairs as (global pair index, state) records -- dist.REC_DTYPE -- assembled on the device; a view of a
+        page-locked buffer that the next call overwrites."""
+        cap = int(cap if cap is not None else max(self.n, 1))
+        if getattr(self, "_rec_cap", 0) < cap:
+            self._rec = self.host_array(cap, RECORD_DTYPE)
+            self._rec_cap = cap
+        n = C.c_uint64(0)
+        self._chk(self.L.cm_collect_records(self.h, int(index_base), cap, self._rec.ctypes.data, C.byref(n)), "cm_collect_records")
+        return self._rec[:n.value]
+
     def host_array(self, n, dtype):
         """numpy array over page-locked memory from cm_host_alloc (freed with the context)."""
         dt = np.dtype(dtype)
@@ -486,7 +499,8 @@ class HotPath:
 
     def close(self):
         if self.h:
-            self._col_idx = self._col_st = None
+            self._col_idx = self._col_st = self._rec = None
+            self._rec_cap = 0
             self._col_cap = 0
             for p in self._pinned:
                 self.L.cm_host_free(self.h, p)

@@ -201,6 +201,13 @@ int cm_reads_reset(cm_ctx *ctx);
  * after an earlier round, the pairs re-queued for the next contig.  Ascending pair index.
  * Returns CM_ELIMIT (and the needed count in *out_n) if cap is too small. */
 int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_read *out_state, uint64_t *out_n);
+/* The same pairs as self-contained records (global pair index = index_base + index in the batch, then the state):
+ * what a rank hands to the BSJ gather, assembled on the device so the host does no packing. */
+typedef struct cm_record {
+    uint64_t pair;
+    cm_mapped_read state;
+} cm_record;
+int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *out, uint64_t *out_n);
 
 /* Page-locked host memory for the buffers that cross PCIe (read batches, downloaded states, collected
  * records): the copies in cm_reads_upload / cm_reads_download / cm_collect_active are direct DMA for such

@@ -37,6 +37,8 @@ def _run_all_rounds(ds, P):
         idx, stc = hp.collect_active()                 # stable device-side compaction of the re-queued pairs
         want = np.nonzero(act1)[0]
         assert (idx == want).all() and stc.tobytes() == st1[want].tobytes()
+        rec = hp.collect_records(1000)                 # the same pairs as device-assembled records
+        assert (rec["pair"] == want + 1000).all() and rec["state"].tobytes() == st1[want].tobytes()
     hp.close()
     return st0
 

@@ -124,6 +124,45 @@ def test_dp_bodies_fuzz(emu):
             assert O.oracle_one_side(s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w) == emu.emu_one_side(C.byref(P), s3.ctypes.data, n3, t3.ctypes.data, n3 + w, w)
 
 
+def test_xdrop_long_prefixes_and_low_complexity(emu):
+    """X-drop DP on strings that share a long exact prefix, first difference anywhere (substitution, insertion, deletion,
+    N), low-complexity alphabets (ties between the diagonal and shifted alignments), every length up to 300.
+    (Written for a fast-forward over exact prefixes that was bit-exact but slower on MI355X; kept as a fuzz.)"""
+    O = op.load()
+    rng = np.random.default_rng(5)
+    P = cl.default_params()
+    for it in range(6000):
+        alpha = [b"ACGT", b"AC", b"A", b"AAC", b"ACGTACGA"][it % 5]
+        A = np.frombuffer(alpha, dtype=np.uint8)
+        m = int(rng.integers(20, 300))
+        t = A[rng.integers(0, len(A), m)].copy()
+        s = t.copy()
+        kind = it % 7
+        p = int(rng.integers(0, m))
+        if kind == 0:
+            s[p] = ord("ACGT"[int(rng.integers(0, 4))])
+        elif kind == 1:
+            s = np.delete(s, p)
+        elif kind == 2:
+            s = np.insert(s, p, ord("ACGT"[int(rng.integers(0, 4))]))
+        elif kind == 3:
+            s[p] = ord("N")
+        elif kind == 4:
+            t[p] = ord("n")
+        elif kind == 5:
+            for q in rng.integers(p, m, 3):
+                s[int(q)] = ord("ACGT"[int(rng.integers(0, 4))])
+        # kind 6: identical (the wrapper's closed form) plus the tail below
+        s = np.ascontiguousarray(np.concatenate([s, A[rng.integers(0, len(A), 5)]])[:m + 3])
+        n = len(s)
+        for left in (0, 1):
+            a = [C.c_int() for _ in range(3)]
+            b = [C.c_int() for _ in range(3)]
+            r0 = O.oracle_drop_sc(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, *[C.byref(x) for x in a])
+            r1 = emu.emu_drop_sc(C.byref(P), s.ctypes.data, n, t.ctypes.data, m, left, *[C.byref(x) for x in b])
+            assert r0 == r1 and [x.value for x in a] == [x.value for x in b], (it, kind, left, n, m, p, bytes(s), bytes(t))
+
+
 def test_skipped_leftover_extensions_are_dead_work(emu):
     """leftovers_matter() == false must imply that no outcome of the unpaired-chain extensions can change
     mr.type: leftover_type() is applied with mr_update_type (type only ever decreases), an extension can only

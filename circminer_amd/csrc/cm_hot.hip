@@ -139,6 +139,13 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_c(unsigned long long *out, cons
     if (i < n) out[i] += bsum[i / SCAN_ELEMS];
 }
 
+// bases of a problem's best chain left to extend on the left / right (work proxies of the pair-stage ordering):
+// left in the low byte, right in the high byte, each capped at 255
+__device__ inline int pack_resid(int left, int right) {
+    left = left < 0 ? 0 : (left > 255 ? 255 : left);
+    right = right < 0 ? 0 : (right > 255 ? 255 : right);
+    return left | (right << 8);
+}
 #ifndef CM_CHAIN_WAVES
 #define CM_CHAIN_WAVES 5
 #endif
@@ -179,12 +186,12 @@ __global__ void __launch_bounds__(BLK_CHAIN, CM_CHAIN_WAVES) k_chain(KCore kc, R
         n = cmc::chain_kbest(c, len, S, st, cn, w, (CM_G cm_chain *)(chains + (uint64_t)r * CM_BESTCHAINLIM));
         if (n > 0) {          // bases of the best chain left to extend (work proxy used by the pair-stage ordering)
             const cm_chain &b = chains[(uint64_t)r * CM_BESTCHAINLIM];
-            rs = b.qpos[0] + (len - (b.qpos[b.chain_len - 1] + c.P.kmer));
+            rs = pack_resid(b.qpos[0], len - (b.qpos[b.chain_len - 1] + c.P.kmer));
         }
     }
     nchain[r] = n;
     high[r] = hh;
-    resid[r] = (uint16_t)(rs < 0 ? 0 : rs);
+    resid[r] = (uint16_t)rs;
 }
 
 #ifndef CM_PAIR_WAVES
@@ -528,8 +535,8 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
         if (lane == 0) {
             nchain[r] = (int32_t)best_count;
             int rs = 0;
-            if (best_count > 0) rs = out[0].qpos[0] + (len - (out[0].qpos[out[0].chain_len - 1] + kmer));
-            resid[r] = (uint16_t)(rs < 0 ? 0 : rs);
+            if (best_count > 0) rs = pack_resid(out[0].qpos[0], len - (out[0].qpos[out[0].chain_len - 1] + kmer));
+            resid[r] = (uint16_t)rs;
         }
         __syncthreads();
     }
@@ -552,14 +559,21 @@ constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_
 // wave carry similar work; the classes are a heuristic, results do not depend on them.
 // (Measured: a "some residual is inexact" flag as a further key costs as much in k_pair_cls as it saves in k_pair.)
 __device__ inline int pair_class(const Core &c, const cm_chain *chains, const uint16_t *resid4, const int32_t *nchain,
-                                 const uint8_t *active, uint64_t pair0, uint32_t t, int heavy_cost) {
+                                 const uint8_t *active, uint64_t pair0, uint32_t t, int heavy_cost, int *sub) {
     const uint64_t p = pair0 + t;
+    if (sub) *sub = 0;
     if (!active[p]) return -2;
     const int32_t *nc = nchain + 4 * (uint64_t)t;
     const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
     if ((a * d + cc * b + a + b + cc + d) > heavy_cost) return HEAVY_CLS;
     const uint16_t *q = resid4 + 4 * (uint64_t)t;
-    const int resid = (int)q[0] + q[1] + q[2] + q[3];
+    int resid = 0;
+    for (int x = 0; x < 4; ++x) resid += (q[x] & 0xff) + (q[x] >> 8);
+    if (sub) {          // which of the four extensions of the main orientation have bases to extend (LL, LR, RL, RR of both_mates)
+        const bool main0 = a > 0 && d > 0;                 // forward R1 / backward R2 carries chains, else the other orientation
+        const uint16_t f = q[main0 ? 0 : 2], bk = q[main0 ? 3 : 1];
+        *sub = ((f & 0xff) ? 1 : 0) | ((f >> 8) ? 2 : 0) | ((bk & 0xff) ? 4 : 0) | ((bk >> 8) ? 8 : 0);
+    }
     const int bucket = resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : 6;
     bool genic = false;
     for (int x = 0; x < 4 && !genic; ++x) {
@@ -587,12 +601,15 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
     }
 }
 __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
-                                                 const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost) {
+                                                 const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost,
+                                                 int8_t *cls_sub) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
-    const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost);
+    int sub = 0;
+    const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost, &sub);
     cls[t] = (int8_t)k;
+    cls_sub[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : sub));    // secondary key (first pass of the two-pass radix sort)
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
@@ -622,10 +639,14 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
                                  : n <= 96 ? 10 : 11)
                       : w <= 4096 ? 12 : w <= 65536 ? 13 : w <= 1048576 ? 14 : 15);
 }
-__global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb) {
+// `order` (optional): visit the elements in this order (second pass of an LSD radix sort: order = the permutation of the
+// first pass, *n_order entries); the element at position i is order[i]
+__global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb, const uint32_t *order,
+                                                    const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
-    const int k = t < n ? (int)cls[t] : -2;
+    const uint32_t i = blockIdx.x * CLS_T + threadIdx.x;
+    const uint32_t lim = order ? *n_order : n;
+    const int k = i < lim ? (int)cls[order ? order[i] : i] : -2;
     unsigned int r;
     block_class_ranks(k, wcnt, r, threadIdx.x & 63, threadIdx.x >> 6);
     __syncthreads();
@@ -681,10 +702,13 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
     }
 }
 __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t n_tile, const unsigned int *blk_base, uint32_t nb,
-                                                     const unsigned int *ctr, uint32_t *perm, uint32_t *hlist) {
+                                                     const unsigned int *ctr, uint32_t *perm, uint32_t *hlist, const uint32_t *order,
+                                                     const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t t = blockIdx.x * CLS_T + threadIdx.x;
-    const int k = t < n_tile ? (int)cls[t] : -2;
+    const uint32_t i = blockIdx.x * CLS_T + threadIdx.x;
+    const uint32_t lim = order ? *n_order : n_tile;
+    const uint32_t t = i < lim ? (order ? order[i] : i) : 0u;
+    const int k = i < lim ? (int)cls[t] : -2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int r;
     block_class_ranks(k, wcnt, r, lane, wave);
@@ -1004,7 +1028,9 @@ struct cm_ctx {
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
-    int8_t *d_cls = nullptr, *d_cls4 = nullptr;
+    int8_t *d_cls = nullptr, *d_cls4 = nullptr, *d_cls_sub = nullptr;
+    uint32_t *d_perm1 = nullptr;
+    unsigned int *d_cls_ctr2 = nullptr;
     uint32_t *d_perm4 = nullptr;
     uint16_t *d_resid = nullptr;
     uint32_t *d_perm = nullptr;
@@ -1075,7 +1101,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_collect_rec); dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
@@ -1188,10 +1214,11 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
         hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high,
                            light_w, light_cells, ctx->d_nchain, ctx->d_resid);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, (const uint32_t *)nullptr,
+                           (const unsigned int *)nullptr);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
-                           (uint32_t *)nullptr);
+                           (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
         ctx->launches[5] += 4;
     }
     for (auto &rg : ranges) {
@@ -1477,6 +1504,9 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_hres, (size_t)4096 * 64 * sizeof(HRes)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_sub, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm1, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
@@ -1519,12 +1549,20 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
             static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
-                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost);
-            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk);
+                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost, ctx->d_cls_sub);
+            // two-pass LSD radix sort, 16 x 16 classes: by the set of extensions a pair needs, then (stable) by its class
+            const uint32_t *no_order = nullptr;
+            const unsigned int *no_count = nullptr;
+            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
+            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
+                               (uint32_t *)nullptr, no_order, no_count);
+            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
+                               (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
-                               ctx->d_hlist);
-            ctx->launches[5] += 4;
+                               ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
+            ctx->launches[5] += 7;
             }
             // The heavy pairs go to the second stream: one wave per pair fits into the slots the light kernel leaves
             // instead of queueing behind it.
@@ -1592,10 +1630,11 @@ static int compact_active(cm_ctx *ctx) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
     }
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
-    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk);
+    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, (const uint32_t *)nullptr,
+                       (const unsigned int *)nullptr);
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
-                       ctx->d_col_perm, (uint32_t *)nullptr);
+                       ctx->d_col_perm, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
     return CM_OK;
 }
 // count + error flags through the pinned landing zone (one synchronisation)

@@ -573,6 +573,13 @@ __device__ inline int pair_class(const Core &c, const cm_chain *chains, const ui
         const bool main0 = a > 0 && d > 0;                 // forward R1 / backward R2 carries chains, else the other orientation
         const uint16_t f = q[main0 ? 0 : 2], bk = q[main0 ? 3 : 1];
         *sub = ((f & 0xff) ? 1 : 0) | ((f >> 8) ? 2 : 0) | ((bk & 0xff) ? 4 : 0) | ((bk >> 8) ? 8 : 0);
+        int mx = f & 0xff;                                  // longest single residual of the main orientation, 16 levels
+        mx = (f >> 8) > mx ? (f >> 8) : mx;
+        mx = (bk & 0xff) > mx ? (bk & 0xff) : mx;
+        mx = (bk >> 8) > mx ? (bk >> 8) : mx;
+        const int lv = mx < 5 ? 0 : mx < 10 ? 1 : mx < 15 ? 2 : mx < 20 ? 3 : mx < 25 ? 4 : mx < 30 ? 5 : mx < 40 ? 6 : mx < 50 ? 7 : mx < 60 ? 8 : mx < 70 ? 9
+                       : mx < 80 ? 10 : mx < 90 ? 11 : mx < 100 ? 12 : mx < 115 ? 13 : mx < 130 ? 14 : 15;
+        *sub |= lv << 4;
     }
     const int bucket = resid < 25 ? 0 : resid < 50 ? 1 : resid < 100 ? 2 : resid < 150 ? 3 : resid < 200 ? 4 : resid < 300 ? 5 : 6;
     bool genic = false;
@@ -602,14 +609,15 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
 }
 __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
                                                  const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost,
-                                                 int8_t *cls_sub) {
+                                                 int8_t *cls_sub, int8_t *cls_sub2) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
     int sub = 0;
     const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost, &sub);
     cls[t] = (int8_t)k;
-    cls_sub[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : sub));    // secondary key (first pass of the two-pass radix sort)
+    cls_sub[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : (sub & 15)));    // secondary key
+    cls_sub2[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : (sub >> 4)));   // tertiary key (first pass of the radix sort)
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
@@ -1028,9 +1036,9 @@ struct cm_ctx {
     cm_chain *d_chains = nullptr;
     int32_t *d_nchain = nullptr, *d_high = nullptr;
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
-    int8_t *d_cls = nullptr, *d_cls4 = nullptr, *d_cls_sub = nullptr;
-    uint32_t *d_perm1 = nullptr;
-    unsigned int *d_cls_ctr2 = nullptr;
+    int8_t *d_cls = nullptr, *d_cls4 = nullptr, *d_cls_sub = nullptr, *d_cls_sub2 = nullptr;
+    uint32_t *d_perm1 = nullptr, *d_perm0 = nullptr;
+    unsigned int *d_cls_ctr2 = nullptr, *d_cls_ctr3 = nullptr;
     uint32_t *d_perm4 = nullptr;
     uint16_t *d_resid = nullptr;
     uint32_t *d_perm = nullptr;
@@ -1101,7 +1109,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
+    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_collect_rec); dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
@@ -1507,6 +1515,9 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_sub, (size_t)tile));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm1, (size_t)tile * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr3, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_sub2, (size_t)tile));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm0, (size_t)tile * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
@@ -1549,20 +1560,26 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
             static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
             hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
-                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost, ctx->d_cls_sub);
-            // two-pass LSD radix sort, 16 x 16 classes: by the set of extensions a pair needs, then (stable) by its class
+                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2);
+            // three-pass LSD radix sort, 16 x 16 x 16 classes: by the longest residual, by the set of extensions a pair needs,
+            // then (stable) by its class
             const uint32_t *no_order = nullptr;
             const unsigned int *no_count = nullptr;
-            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
+            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
+                               (uint32_t *)nullptr, no_order, no_count);
+            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
+                               (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
-                               (uint32_t *)nullptr, no_order, no_count);
+                               (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
             hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
                                (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
             hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
             hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
                                ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
-            ctx->launches[5] += 7;
+            ctx->launches[5] += 10;
             }
             // The heavy pairs go to the second stream: one wave per pair fits into the slots the light kernel leaves
             // instead of queueing behind it.

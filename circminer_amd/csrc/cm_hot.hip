@@ -667,34 +667,29 @@ __global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t 
 // ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
 // (highest class first); the classes in the bit mask `separate` (none: -1) go to their own lists instead
 __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used) {
-    __shared__ unsigned int part[1024];
+    // one wave per class row: 64 block counts per step, exclusive scan inside the wave, running total carried on
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
-    const uint32_t chunk = (nb + 1023u) / 1024u;
+    const int lane = (int)(t & 63u), c = (int)(t >> 6);        // 16 waves = N_CLS rows
     if (t < N_CLS) tot[t] = 0;
     __syncthreads();
-    for (int c = 0; c < n_used; ++c) {                  // classes >= n_used are not produced by this caller
+    if (c < n_used) {                                    // classes >= n_used are not produced by this caller
         unsigned int *row = blk_cnt + (size_t)c * nb;
-        const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
-        unsigned int s = 0;
-        for (uint32_t i = a; i < b; ++i) s += row[i];
-        part[t] = s;
-        __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            const unsigned int v = (t >= d) ? part[t - d] : 0u;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
+        unsigned int run = 0;
+        for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const unsigned int x = i < nb ? row[i] : 0u;
+            unsigned int incl = x;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (i < nb) row[i] = run + incl - x;
+            run += __shfl(incl, 63);
         }
-        unsigned int run = t ? part[t - 1] : 0u;
-        for (uint32_t i = a; i < b; ++i) {
-            const unsigned int x = row[i];
-            row[i] = run;
-            run += x;
-        }
-        if (t == 1023) tot[c] = part[1023];
-        __syncthreads();
+        if (lane == 0) tot[c] = run;
     }
+    __syncthreads();
     if (t == 0) {
         unsigned int off = 0;
         for (int c = N_CLS - 1; c >= 0; --c) {          // heaviest class first

@@ -565,7 +565,15 @@ __device__ inline int pair_class(const Core &c, const cm_chain *chains, const ui
     if (!active[p]) return -2;
     const int32_t *nc = nchain + 4 * (uint64_t)t;
     const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
-    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) return HEAVY_CLS;
+    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) {
+        if (sub) {          // heavy pairs: cost level as the first radix key, so that k_pair_heavy starts with the longest ones
+            const int cost = a * d + cc * b + a + b + cc + d;
+            const int lv = cost <= 12 ? 0 : cost <= 16 ? 1 : cost <= 24 ? 2 : cost <= 32 ? 3 : cost <= 48 ? 4 : cost <= 64 ? 5 : cost <= 96 ? 6 : cost <= 128 ? 7
+                           : cost <= 192 ? 8 : cost <= 256 ? 9 : cost <= 384 ? 10 : cost <= 512 ? 11 : cost <= 768 ? 12 : 13;
+            *sub = lv << 4;
+        }
+        return HEAVY_CLS;
+    }
     const uint16_t *q = resid4 + 4 * (uint64_t)t;
     int resid = 0;
     for (int x = 0; x < 4; ++x) resid += (q[x] & 0xff) + (q[x] >> 8);
@@ -617,7 +625,7 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chai
     const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost, &sub);
     cls[t] = (int8_t)k;
     cls_sub[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : (sub & 15)));    // secondary key
-    cls_sub2[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : (sub >> 4)));   // tertiary key (first pass of the radix sort)
+    cls_sub2[t] = (int8_t)(k < 0 ? -2 : (sub >> 4));                           // tertiary key (first pass of the radix sort)
     if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine

@@ -104,14 +104,16 @@ def test_map_batch_wrapper_and_errors(ds_tiny):
     hp.close()
 
 
-def test_full_size_parity_chr21_1M(tmp_path_factory):
+@pytest.mark.parametrize("n_pairs,seed,kw", [(1_000_000, 21, {}), (300_000, 77, dict(scan_level=1)), (200_000, 78, dict(scan_level=2, max_ed=6, seed_lim=1000))])
+def test_full_size_parity_chr21(tmp_path_factory, n_pairs, seed, kw):
     """BASELINE.json configs[1] at full size: chr21-like contig, 1 M pairs — every pair's state, category and
-    active flag bit-exact against the oracle (run on all host cores of the GPU box)."""
+    active flag bit-exact against the oracle (run on all host cores of the GPU box); two more genomes / read sets
+    at other scan levels."""
     import os
     import threading
     from conftest import DataSet
-    ds = DataSet(tmp_path_factory.mktemp("chr21"), "chr21", 1_000_000, 21)
-    P = cl.default_params()
+    ds = DataSet(tmp_path_factory.mktemp("chr21"), "chr21", n_pairs, seed)
+    P = cl.default_params(**kw)
     hp = cl.HotPath(P)
     hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
     hp.upload(ds.batch)

@@ -110,6 +110,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
+    if world > 1:                       # one rank compiles (if anything is stale), the others wait: no concurrent writes of the .o / .so
+        if rank == 0:
+            ge.build()
+        dist.barrier()
     ge.build()
     from circminer_amd import dist as cdist, lib as cl, synth
 

@@ -6,7 +6,8 @@
 //               plain or gzip input (gzread handles both, as in the reference);
 //   * remain  : FilterRead::write_read_category PE (src/filter.cpp:413-455): "<out>_<round>_remain_R{1,2}.fastq",
 //               header "@name gspos type chr spos epos mlen qspos qepos dir ed chr ... tlen junc gm contig";
-//   * PAM     : SAMOutput::write_pam_rec_pe (src/output.cpp:279-299).
+//   * PAM     : SAMOutput::write_pam_rec_pe (src/output.cpp:279-299);
+//   * SAM     : SAMOutput::print_header / set_flag_pe / set_output_pe / write_sam_rec_pe (src/output.cpp:118-277, 301-333).
 // Reads are delivered in the cm_reads layout (concatenated bytes + offsets), whole batches at a time, so a
 // batch goes to cm_reads_upload without another copy; with cm_host_alloc'ed staging the copy is one DMA.
 // Deliberately defined where the reference has undefined behaviour: names shorter than 2 characters are not
@@ -204,7 +205,7 @@ int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_
 struct cm_writer {
     FILE *f1 = nullptr, *f2 = nullptr;
     std::vector<std::string> chr_names;
-    std::vector<uint32_t> chr_shift;
+    std::vector<uint32_t> chr_shift, chr_len;
 };
 
 extern "C" {
@@ -281,6 +282,7 @@ int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs
     for (uint32_t i = 0; i < n_chr; ++i) {
         w->chr_names.emplace_back(chrs[i].name ? chrs[i].name : "");
         w->chr_shift.push_back(chrs[i].start_pos);
+        w->chr_len.push_back(chrs[i].len);
     }
     *out = w;
     return CM_OK;
@@ -336,6 +338,92 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
                     m.qepos_r2, m.r2_forward ? '+' : '-', m.ed_r2, m.tlen, (int)m.junc_num, (int)(m.gm_compatible != 0), m.type);
         } else {
             fprintf(w->f1, "%s\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t%d\n", nm, m.type);
+        }
+    }
+    return CM_OK;
+}
+
+// SAMOutput::print_header (src/output.cpp:301-311)
+int cm_write_sam_header(cm_writer *w) {
+    if (!w) return CM_EINVAL;
+    fprintf(w->f1, "@HD\tVN:1.4\tSO:unsorted\n");
+    for (size_t i = 0; i < w->chr_names.size(); ++i) fprintf(w->f1, "@SQ\tSN:%s\tLN:%u\n", w->chr_names[i].c_str(), w->chr_len[i]);
+    return CM_OK;
+}
+
+namespace {
+constexpr unsigned PAIRED = 1u << 0, PROPER = 1u << 1, RUNMAP = 1u << 2, MUNMAP = 1u << 3, RREVER = 1u << 4, MREVER = 1u << 5, FIPAIR = 1u << 6,
+                   SIPAIR = 1u << 7;
+unsigned sam_flag(const cm_mapped_read &m, bool first) {                 // set_flag_pe, src/output.cpp:118-149
+    unsigned flag = PAIRED;
+    if (m.type == CM_CONCRD) flag |= PROPER;
+    if (!(m.type <= CM_CHIORF || m.type == CM_CONGEN || m.type == CM_CONGNM)) flag |= RUNMAP | MUNMAP;
+    if (first) {
+        if (!(flag & RUNMAP) && !m.r1_forward) flag |= RREVER;
+        if (!(flag & MUNMAP) && !m.r2_forward) flag |= MREVER;
+        flag |= FIPAIR;
+    } else {
+        if (!(flag & MUNMAP) && !m.r1_forward) flag |= MREVER;
+        if (!(flag & RUNMAP) && !m.r2_forward) flag |= RREVER;
+        flag |= SIPAIR;
+    }
+    return flag;
+}
+// FASTQParser::set_comp / set_reverse_comp (src/fastq_parser.cpp:141-176): bytes outside ACGTN / acgtn map to NUL, which
+// ends the %s the reference prints
+char comp_of(unsigned char ch) {
+    switch (ch) {
+        case 'A': case 'a': return 'T';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        case 'T': case 't': return 'A';
+        case 'N': case 'n': return 'N';
+        default: return '\0';
+    }
+}
+}  // namespace
+
+// write_sam_rec_pe for the selected pairs (two records per pair)
+int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel) {
+    if (!w || !b || !states) return CM_EINVAL;
+    const uint64_t n = sel ? n_sel : b->reads.n_pairs;
+    std::string seq[2], qual[2];
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t i = sel ? sel[k] : k;
+        if (i >= b->reads.n_pairs) return CM_EINVAL;
+        const cm_mapped_read &m = states[i];
+        const char *qname = b->names1 + b->name_off1[i];
+        const unsigned flag[2] = {sam_flag(m, true), sam_flag(m, false)};
+        const char *cn = chr_name(w, m.chr_id);
+        int32_t tlen[2];
+        if (m.spos_r1 < m.spos_r2) { tlen[0] = m.tlen; tlen[1] = m.tlen * -1; }
+        else { tlen[0] = m.tlen * -1; tlen[1] = m.tlen; }
+        const char *rname[2], *rnext[2];
+        uint32_t pos[2], pnext[2];
+        // set_output_pe, src/output.cpp:151-222 (chr_r1 == chr_r2 always, so rnext of a mapped mate is "=")
+        if (flag[0] & RUNMAP) { rname[0] = "*"; rnext[1] = "*"; pos[0] = 0; pnext[1] = 0; tlen[0] = tlen[1] = 0; }
+        else { rname[0] = cn; rnext[1] = "="; pos[0] = m.spos_r1; pnext[1] = m.spos_r1; }
+        if (flag[1] & RUNMAP) { rname[1] = "*"; rnext[0] = "*"; pos[1] = 0; pnext[0] = 0; tlen[0] = tlen[1] = 0; }
+        else { rname[1] = cn; rnext[0] = "="; pos[1] = m.spos_r2; pnext[0] = m.spos_r2; }
+        for (int s = 0; s < 2; ++s) {
+            const uint8_t *sq = s ? b->reads.seq2 : b->reads.seq1, *ql = s ? b->qual2 : b->qual1;
+            const uint64_t *off = s ? b->reads.off2 : b->reads.off1;
+            const size_t len = (size_t)(off[i + 1] - off[i]);
+            seq[s].assign((const char *)sq + off[i], len);
+            qual[s].assign((const char *)ql + off[i], len);
+            if (flag[s] & RREVER) {
+                std::string rc(len, '\0'), rq(len, '\0');
+                for (size_t x = 0; x < len; ++x) {
+                    rc[x] = comp_of((unsigned char)seq[s][len - 1 - x]);
+                    rq[x] = qual[s][len - 1 - x];
+                }
+                seq[s] = rc.substr(0, rc.find('\0'));             // %s stops at the first NUL
+                qual[s] = rq;
+            }
+            const bool un = (flag[s] & RUNMAP) != 0;
+            const int ed = un ? 0 : (s ? m.ed_r2 : m.ed_r1), jc = un ? 0 : (int)m.junc_num, gm = un ? 0 : (int)(m.gm_compatible != 0);
+            fprintf(w->f1, "%s\t%u\t%s\t%u\t%u\t%s\t%s\t%u\t%u\t%s\t%s\tAT:i:%d\tNM:i:%d\tJC:i:%d\tTC:i:%d\n", qname, flag[s], rname[s], pos[s], 255u, "*",
+                    rnext[s], pnext[s], (unsigned)tlen[s], seq[s].c_str(), qual[s].c_str(), m.type, ed, jc, gm);
         }
     }
     return CM_OK;

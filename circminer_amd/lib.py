@@ -178,6 +178,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_write_sam_header": (C.c_int, [vp]),
+        "cm_write_sam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_writer_close": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -195,7 +197,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_writer_close"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close"]
 
 
 class HostIndex:
@@ -383,6 +385,13 @@ class RecordWriter:
 
     def write_pam(self, batch, states, sel=None):
         self._call(self.L.cm_write_pam, batch, states, sel)
+
+    def write_sam_header(self):
+        if self.L.cm_write_sam_header(self.h) != 0:
+            raise RuntimeError("cm_write_sam_header failed")
+
+    def write_sam(self, batch, states, sel=None):
+        self._call(self.L.cm_write_sam, batch, states, sel)
 
     def close(self):
         if self.h:

@@ -319,6 +319,11 @@ typedef struct cm_writer cm_writer;
 int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs, uint32_t n_chr, cm_writer **out);
 int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
 int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
+/* <out>.mapping.sam (--sam): header = SAMOutput::print_header (src/output.cpp:301-311, one @SQ per row of the chromosome
+ * table), records = write_sam_rec_pe with set_flag_pe / set_output_pe (src/output.cpp:118-277): two lines per pair,
+ * CIGAR "*", MAPQ 255, tags AT / NM / JC / TC; TLEN is printed with %u like the reference does. */
+int cm_write_sam_header(cm_writer *w);
+int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
 void cm_writer_close(cm_writer *w);
 
 #ifdef __cplusplus

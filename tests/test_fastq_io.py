@@ -1,6 +1,6 @@
 """FASTQ ingest, the 23-token carry-over header, PAM and remain-FASTQ writers
 (circminer_amd/csrc/host_fastq.cpp) against Python restatements of the reference's formats
-(src/fastq_parser.cpp:178-269, src/filter.cpp:413-455, src/output.cpp:279-299)."""
+(src/fastq_parser.cpp:178-269, src/filter.cpp:413-455, src/output.cpp:118-333)."""
 import gzip
 
 import numpy as np
@@ -147,6 +147,67 @@ def test_remain_and_pam_formats_round_trip(built, tmp_path):
         assert b2.name(k) == names[int(sel[k])] and b2.seq(k, 2).decode() == s2[int(sel[k])]
     rd.close()
     rd2.close()
+
+
+def py_sam_rows(name, m, chrs, s1, q1, s2, q2):
+    """set_flag_pe / set_output_pe / write_sam_rec_pe, src/output.cpp:118-277."""
+    comp = dict(zip("ACGTNacgtn", "TGCANTGCAN"))
+    t = int(m["type"])
+    un = not (t <= 2 or t in (5, 7))
+    rows = []
+    for first in (True, False):
+        flag = 1 | (2 if t == 0 else 0) | (12 if un else 0)
+        mine_fw, mate_fw = (m["r1_forward"], m["r2_forward"]) if first else (m["r2_forward"], m["r1_forward"])
+        if not un and not mine_fw:
+            flag |= 16
+        if not un and not mate_fw:
+            flag |= 32
+        flag |= 64 if first else 128
+        tl = int(m["tlen"]) if (m["spos_r1"] < m["spos_r2"]) == first else -int(m["tlen"])
+        seq, qual = (s1, q1) if first else (s2, q2)
+        if flag & 16:
+            seq, qual = "".join(comp[c] for c in reversed(seq)), qual[::-1]
+        if un:
+            f = [name, flag, "*", 0, 255, "*", "*", 0, 0, seq, qual, f"AT:i:{t}", "NM:i:0", "JC:i:0", "TC:i:0"]
+        else:
+            cn = chrs[int(m["chr_id"])][0]
+            pos, pnext = (m["spos_r1"], m["spos_r2"]) if first else (m["spos_r2"], m["spos_r1"])
+            ed = m["ed_r1"] if first else m["ed_r2"]
+            f = [name, flag, cn, pos, 255, "*", "=", pnext, tl & 0xFFFFFFFF, seq, qual, f"AT:i:{t}", f"NM:i:{ed}", f"JC:i:{m['junc_num']}",
+                 f"TC:i:{int(bool(m['gm_compatible']))}"]
+        rows.append("\t".join(str(x) for x in f))
+    return rows
+
+
+def test_sam_header_and_records(built, tmp_path):
+    rng = np.random.default_rng(23)
+    n = 900
+    s1, q1 = _rand_reads(rng, n)
+    s2, q2 = _rand_reads(rng, n)
+    names = [f"frag{i}" for i in range(n)]
+    p1, p2 = str(tmp_path / "in_1.fq"), str(tmp_path / "in_2.fq")
+    _fastq(p1, names, s1, q1)
+    _fastq(p2, names, s2, q2)
+    rd = cl.FastqReader(p1, p2, CHRS)
+    b = rd.next_batch(n)
+    st = _rand_states(rng, n)
+    sam = str(tmp_path / "out.mapping.sam")
+    w = cl.RecordWriter(sam, None, CHRS)
+    w.write_sam_header()
+    w.write_sam(b, st)
+    sel = np.array([5, 17, 899], dtype=np.uint64)
+    w.write_sam(b, st, sel)
+    w.close()
+    rows = open(sam).read().split("\n")
+    assert rows[-1] == ""
+    assert rows[:4] == ["@HD\tVN:1.4\tSO:unsorted"] + [f"@SQ\tSN:{c[0]}\tLN:{c[3]}" for c in CHRS]
+    want = []
+    for i in list(range(n)) + [5, 17, 899]:
+        want += py_sam_rows(names[i], st[i], CHRS, s1[i], q1[i], s2[i], q2[i])
+    assert rows[4:-1] == want
+    kinds = {int(r.split("\t")[1]) for r in rows[4:-1]}
+    assert {77, 141} <= kinds and any(k & 16 for k in kinds) and any(k & 2 for k in kinds)
+    rd.close()
 
 
 def test_malformed_fastq_is_an_error_not_a_crash(built, tmp_path):

@@ -59,29 +59,56 @@ struct ContigBuild {
     bool has_gene = false;
 };
 
-void split_tokens(const std::string &s, const char *delims, std::vector<std::string> &out, size_t cap) {
-    // GTFParser::tokenize with len == 0: consecutive delimiters collapse, no CR/LF strip.
-    out.assign(cap, std::string());
-    size_t field = 0;
-    std::string cur;
-    for (char ch : s) {
-        if (strchr(delims, ch) != nullptr && ch != '\0') {
-            if (field < cap) out[field] = cur;
-            if (!cur.empty()) ++field;
-            cur.clear();
-        } else {
-            cur += ch;
-        }
+// GTFParser::tokenize with len == 0 on the tab-separated columns: consecutive delimiters collapse (empty fields are
+// dropped), no CR/LF strip.  Fields are (pointer, length) views into the line; only the first `cap` are kept.
+struct Field {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool is(const char *lit) const { return strlen(lit) == n && memcmp(p, lit, n) == 0; }
+};
+size_t split_tabs(const char *line, Field *out, size_t cap) {
+    size_t nf = 0;
+    const char *q = line;
+    while (*q && nf < cap) {
+        while (*q == '\t') ++q;
+        if (!*q) break;
+        const char *b = q;
+        while (*q && *q != '\t') ++q;
+        out[nf].p = b;
+        out[nf].n = (size_t)(q - b);
+        ++nf;
     }
-    if (!cur.empty() && field < cap) out[field++] = cur;
+    for (size_t k = nf; k < cap; ++k) out[k] = Field();
+    return nf;
+}
+// atoi on a field view (leading blanks, optional sign, digits; stops at the first other byte)
+inline int field_atoi(const Field &f) {
+    char buf[24];
+    const size_t n = f.n < sizeof(buf) - 1 ? f.n : sizeof(buf) - 1;
+    memcpy(buf, f.p, n);
+    buf[n] = 0;
+    return atoi(buf);
 }
 
+// bits [lo, hi_incl] of a little-endian word bitset; whole words at a time (the reference's per-position loops,
+// gene_annotation.cpp:236-238,269-278, are what makes its GTF load slow on long genes)
 inline void set_bits(std::vector<uint64_t> &bs, uint64_t lo, uint64_t hi_incl, bool v) {
     const uint64_t nbits = bs.size() * 64;
-    for (uint64_t k = lo; k <= hi_incl && k < nbits; ++k) {
-        if (v) bs[k >> 6] |= (1ull << (k & 63));
-        else bs[k >> 6] &= ~(1ull << (k & 63));
+    if (lo >= nbits || hi_incl < lo) return;
+    if (hi_incl >= nbits) hi_incl = nbits - 1;
+    const uint64_t w0 = lo >> 6, w1 = hi_incl >> 6;
+    const uint64_t m0 = ~0ull << (lo & 63), m1 = ~0ull >> (63 - (hi_incl & 63));
+    auto apply = [&](uint64_t w, uint64_t m) {
+        if (v) bs[w] |= m;
+        else bs[w] &= ~m;
+    };
+    if (w0 == w1) {
+        apply(w0, m0 & m1);
+        return;
     }
+    apply(w0, m0);
+    for (uint64_t w = w0 + 1; w < w1; ++w) bs[w] = v ? ~0ull : 0ull;
+    apply(w1, m1);
 }
 
 // FlatIntervalTree::handle_overlap, reference src/interval_tree_impl.h:40-95
@@ -160,32 +187,37 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
 
     char *line = nullptr;
     size_t cap = 0;
-    std::vector<std::string> f;
+    Field f[8];
+    std::string chr_key;
+    auto it = chr2con.end();
     const uint32_t mrl = (uint32_t)max_read_len;
     while (getline(&line, &cap, fp) != -1) {
         if (line[0] == '#') continue;
-        split_tokens(line, "\t", f, 10);
-        const std::string &type = f[2];
-        if (type != "gene" && type != "transcript" && type != "exon") continue;
-        auto it = chr2con.find(f[0]);
+        split_tabs(line, f, 8);
+        const bool is_gene = f[2].is("gene"), is_trans = f[2].is("transcript"), is_exon = f[2].is("exon");
+        if (!is_gene && !is_trans && !is_exon) continue;
+        if (it == chr2con.end() || chr_key.size() != f[0].n || memcmp(chr_key.data(), f[0].p, f[0].n) != 0) {
+            chr_key.assign(f[0].p ? f[0].p : "", f[0].n);
+            it = chr2con.find(chr_key);
+        }
         if (it == chr2con.end()) continue;  // chr = "0" -> tmp_chr < 0
         int con = it->second.first;
         if (con < 0 || con >= (int)n_contigs) continue;
-        uint32_t start = (uint32_t)atoi(f[3].c_str()) + it->second.second;
-        uint32_t end = (uint32_t)atoi(f[4].c_str()) + it->second.second;
-        bool fwd = (f[6] == "+");
+        uint32_t start = (uint32_t)field_atoi(f[3]) + it->second.second;
+        uint32_t end = (uint32_t)field_atoi(f[4]) + it->second.second;
+        bool fwd = f[6].is("+");
         ContigBuild &B = cb[con];
 
-        if (type == "gene") {
+        if (is_gene) {
             ++B.n_gene;
             B.has_gene = true;
             set_bits(B.intr, start, end, true);
             B.gene_start.push_back(start);
             B.gene_end.push_back(end);
         }
-        if (type == "transcript") ++B.n_trans;
+        if (is_trans) ++B.n_trans;
 
-        if (type == "exon") {
+        if (is_exon) {
             set_bits(B.intr, start, end, false);
             // uint32 wrap quirk: no flank when the subtraction underflows
             uint32_t lo1 = start - mrl;

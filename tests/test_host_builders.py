@@ -144,3 +144,49 @@ def test_annotation_matches_python_restatement(ds_tiny2r):
             if b + 1 >= 300:
                 exp_nb[b - 299:b + 1] = 1
         assert (nb == exp_nb).all() and (it == exp_it).all()
+
+
+def _annot_bytes(av):
+    """every array of a cm_annot_view as bytes, keyed by field name"""
+    n = {"iv_spos": av.n_iv, "iv_epos": av.n_iv, "iv_max_end": av.n_iv, "iv_min_end": av.n_iv, "iv_max_next_exon": av.n_iv,
+         "iv_seg_off": av.n_iv + 1, "seg_start": av.n_seg, "seg_end": av.n_seg, "seg_next_exon_beg": av.n_seg, "seg_gene_id": av.n_seg,
+         "seg_tid_off": av.n_seg + 1, "trans_start_ind": av.n_trans, "t2s_off": av.n_trans + 1, "gene_start": av.n_gene,
+         "gene_end": av.n_gene, "near_border_bits": av.n_bits // 64, "intronic_bits": av.n_bits // 64, "chr_shift": av.n_chr,
+         "chr_id": av.n_chr, "iv_bucket": av.n_iv_bucket}
+    out = {k: np.ctypeslib.as_array(getattr(av, k), shape=(max(v, 1),))[:v].tobytes() for k, v in n.items()}
+    out["iv_seg"] = np.ctypeslib.as_array(av.iv_seg, shape=(max(int(av.iv_seg_off[av.n_iv]), 1),))[:int(av.iv_seg_off[av.n_iv])].tobytes()
+    out["seg_tid"] = np.ctypeslib.as_array(av.seg_tid, shape=(max(int(av.seg_tid_off[av.n_seg]), 1),))[:int(av.seg_tid_off[av.n_seg])].tobytes()
+    out["t2s"] = np.ctypeslib.as_array(av.t2s, shape=(max(int(av.t2s_off[av.n_trans]), 1),))[:int(av.t2s_off[av.n_trans])].tobytes()
+    out["counts"] = (av.n_iv, av.n_seg, av.n_trans, av.n_gene, av.n_bits, av.n_chr)
+    return out
+
+
+def test_gtf_line_handling(ds_tiny2r, tmp_path):
+    """Rows the reference's load_gtf ignores or reads leniently (gene_annotation.cpp:79-143,200-215): comments, other feature
+    types, unknown chromosomes, runs of tabs (tokenize drops empty fields), short rows; and a long gene crossing many
+    bitset words.  The annotation must be identical to the one built from the clean file."""
+    d = ds_tiny2r.d
+    clean = d.gtf_text.splitlines(keepends=True)
+    rng = np.random.default_rng(2)
+    messy = ["#!genome-build synthetic\n"]
+    for ln in clean:
+        f = ln.split("\t")
+        r = rng.random()
+        if r < 0.2:
+            messy.append("# a comment\n")
+        elif r < 0.4:
+            messy.append("\t".join([f[0], f[1], "CDS"] + f[3:]))
+        elif r < 0.5:
+            messy.append("\t".join(["0"] + f[1:]))               # chromosome that is not in the table
+        elif r < 0.6:
+            messy.append("chr_short\tx\n")
+        if rng.random() < 0.3:
+            ln = "\t\t".join(f[:4]) + "\t\t\t" + "\t".join(f[4:])   # empty fields collapse
+        messy.append(ln)
+    p = tmp_path / "messy.gtf"
+    p.write_text("".join(messy))
+    hi = cl.HostIndex(d.contigs, d.chr_table, str(p), kmer=20)
+    for con in range(hi.n_contigs):
+        a, b = _annot_bytes(ds_tiny2r.hi.annots[con]), _annot_bytes(hi.annots[con])
+        for k in a:
+            assert a[k] == b[k], (con, k)

@@ -99,7 +99,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    # CM_BENCH_FORCE_DIST=1: take the N>1 code path (process group, gatherv, barriers) with a single rank -- a rehearsal of
+    # the RCCL calls on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("CM_BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -110,7 +113,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
-    if world > 1:                       # one rank compiles (if anything is stale), the others wait: no concurrent writes of the .o / .so
+    if multi:                           # one rank compiles (if anything is stale), the others wait: no concurrent writes of the .o / .so
         if rank == 0:
             ge.build()
         dist.barrier()
@@ -134,20 +137,25 @@ def main():
         hp.load_contig(ci, hi.views[ci], hi.annots[ci])
     hp.upload(batch)
     base = rank * args.pairs
+    gather = cdist.BsjGather(args.pairs, dev) if multi else None
 
     def step():
         hp.reset()
         for ci in range(hi.n_contigs):
             hp.map_round(ci, ci == hi.n_contigs - 1)
-        rec = hp.collect_records(base)         # BSJ hand-off to stage 2: records assembled on the device, one small D2H
-        if world > 1:
-            return cdist.gather_bsj(rec, device=dev)
-        return rec
+        # BSJ hand-off to stage 2: records assembled on the device.  One GPU: one small D2H.  N GPUs: gatherv to rank 0 over
+        # RCCL from HBM; rank 0's D2H of the gathered records overlaps the next step's rounds and is waited for in fence().
+        if multi:
+            gather.submit(hp.collect_records_device(base, args.pairs, gather.send_ptr()))
+            return None
+        return hp.collect_records(base)
 
     def fence():
         hp.sync()
+        if multi:
+            gather.result()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,11 +176,13 @@ def main():
         marks.append(time.perf_counter() - t)
     fence()
     dt = time.perf_counter() - t
+    if multi:
+        rec = gather.result()
     if os.environ.get("CM_BENCH_TRACE"):
         print("step marks (ms):", [round(m * 1e3, 2) for m in marks], "end", round(dt * 1e3, 2), file=sys.stderr)
     ms, launches, counters = hp.prof_get()
     hp.prof(False)
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -204,7 +214,7 @@ def main():
             "config": {"workload": f"{args.workload}-like synthetic contig ({sum(len(c) for c in d.contigs)} bp, "
                                    f"{len(d.genes)} genes), k=20, {args.pairs} 2x150 bp pairs per GPU, "
                                    f"{hi.n_contigs} round(s), defaults (BASELINE.json configs[1])",
-                       "pairs_per_gpu": args.pairs, "rounds": hi.n_contigs, "bsj_records": int(len(rec)),
+                       "pairs_per_gpu": args.pairs, "rounds": hi.n_contigs, "bsj_records": int(len(rec)),         # all ranks' records, as gathered on rank 0
                        "prep_seconds": round(prep_s, 1)},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_pair_heavy+k_classify" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -219,7 +229,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     hp.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

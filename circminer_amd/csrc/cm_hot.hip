@@ -1698,31 +1698,50 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     return CM_OK;
 }
 
-int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *out, uint64_t *out_n) {
-    if (!ctx || !out_n || (cap && !out)) return CM_EINVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+// compaction + record assembly into `d_dst` (device memory, cap records); complete on return
+static int collect_records_into(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *d_dst, uint64_t *out_n, const char *what) {
     *out_n = 0;
     if (ctx->n_pairs == 0) return CM_OK;
     int rc = compact_active(ctx);
     if (rc) return rc;
+    if (cap)
+        hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
+                           (unsigned long long)cap, ctx->d_state, (unsigned long long)index_base, d_dst);
+    unsigned int cnt = 0;
+    rc = read_count(ctx, cap, &cnt, what);
+    *out_n = cnt;
+    return rc;
+}
+
+int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *out, uint64_t *out_n) {
+    if (!ctx || !out_n || (cap && !out)) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
     if (cap > ctx->collect_rec_cap) {
         dfree(ctx->d_collect_rec);
         ctx->collect_rec_cap = 0;
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_rec, cap * sizeof(cm_record)));
         ctx->collect_rec_cap = cap;
     }
-    if (cap)
-        hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((cap + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_col_perm, ctx->d_col_ctr,
-                           (unsigned long long)cap, ctx->d_state, (unsigned long long)index_base, ctx->d_collect_rec);
-    unsigned int cnt = 0;
-    rc = read_count(ctx, cap, &cnt, "cm_collect_records");
-    *out_n = cnt;
+    int rc = collect_records_into(ctx, index_base, cap, ctx->d_collect_rec, out_n, "cm_collect_records");
     if (rc) return rc;
-    if (cnt) {
-        HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_collect_rec, (size_t)cnt * sizeof(cm_record), hipMemcpyDeviceToHost, ctx->stream));
+    if (*out_n) {
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_collect_rec, (size_t)*out_n * sizeof(cm_record), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return CM_OK;
+}
+
+int cm_collect_records_device(cm_ctx *ctx, uint64_t index_base, uint64_t cap, void *d_out, uint64_t *out_n) {
+    if (!ctx || !out_n || (cap && !d_out)) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (cap) {                                     // a host pointer here would fault inside the kernel: refuse it up front
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_out) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != ctx->P.device) {
+            (void)hipGetLastError();
+            return fail(ctx, CM_EINVAL, "cm_collect_records_device: d_out is not memory of device %d", ctx->P.device);
+        }
+    }
+    return collect_records_into(ctx, index_base, cap, (cm_record *)d_out, out_n, "cm_collect_records_device");
 }
 
 int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out) {

@@ -151,6 +151,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_reads_reset": (C.c_int, [vp]),
         "cm_collect_active": (C.c_int, [vp, C.c_uint64, vp, vp, pp(C.c_uint64)]),
         "cm_collect_records": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, pp(C.c_uint64)]),
+        "cm_collect_records_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, pp(C.c_uint64)]),
         "cm_host_alloc": (C.c_int, [vp, C.c_uint64, pp(vp)]),
         "cm_host_free": (C.c_int, [vp, vp]),
         "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
@@ -192,7 +193,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
@@ -457,6 +458,14 @@ class HotPath:
         n = C.c_uint64(0)
         self._chk(self.L.cm_collect_records(self.h, int(index_base), cap, self._rec.ctypes.data, C.byref(n)), "cm_collect_records")
         return self._rec[:n.value]
+
+    def collect_records_device(self, index_base, cap, dev_ptr):
+        """Same records written to caller-owned device memory (`dev_ptr`: cap * 80 bytes on this context's GPU, e.g. a
+        torch tensor's data_ptr()); returns the record count.  Used by dist.BsjGather."""
+        n = C.c_uint64(0)
+        self._chk(self.L.cm_collect_records_device(self.h, int(index_base), int(cap), C.c_void_p(int(dev_ptr)), C.byref(n)),
+                  "cm_collect_records_device")
+        return int(n.value)
 
     def host_array(self, n, dtype):
         """numpy array over page-locked memory from cm_host_alloc (freed with the context)."""

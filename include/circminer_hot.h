@@ -208,6 +208,10 @@ typedef struct cm_record {
     cm_mapped_read state;
 } cm_record;
 int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record *out, uint64_t *out_n);
+/* Same records, left in device memory the caller owns (`d_out`: cap * sizeof(cm_record) bytes on ctx's device; complete
+ * when the call returns): the multi-GPU hand-off gathers them to rank 0 over RCCL straight from HBM
+ * (circminer_amd/dist.py) and only rank 0 copies anything to the host. */
+int cm_collect_records_device(cm_ctx *ctx, uint64_t index_base, uint64_t cap, void *d_out, uint64_t *out_n);
 
 /* Page-locked host memory for the buffers that cross PCIe (read batches, downloaded states, collected
  * records): the copies in cm_reads_upload / cm_reads_download / cm_collect_active are direct DMA for such

@@ -35,9 +35,24 @@ def _worker(rank, world, port, n_total, outdir):
     P = cl.default_params()
     st, act, _ = op.map_all_rounds(P, hi, batch)
     idx = np.nonzero(act)[0].astype(np.uint64)
-    rec = cdist.gather_bsj(cdist.pack_records(idx + a, st[idx]))
+    mine = cdist.pack_records(idx + a, st[idx])
+    rec = cdist.gather_bsj(mine)
+    assert (rec is None) == (rank != 0)
+    # the stepping form bench.py uses: same buffers reused over several batches, an empty batch in between
+    g = cdist.BsjGather(len(mine))
+    g.submit(g.fill(mine[:len(mine) // 2]))
+    half = g.result()
+    half = None if half is None else half.copy()
+    g.submit(g.fill(mine[:0]) if rank == 0 else g.fill(mine[:1]))
+    one = g.result()
+    one = None if one is None else one.copy()
+    g.submit(g.fill(mine))
+    again = g.result()
     if rank == 0:
+        assert again.tobytes() == rec.tobytes() and len(one) == 1 and one["pair"][0] >= b
+        assert (np.diff(rec["pair"].astype(np.int64)) > 0).all()
         np.save(os.path.join(outdir, "gathered.npy"), rec)
+        np.save(os.path.join(outdir, "half.npy"), half)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,12 +1,18 @@
 """GPU parity tests proper: HIP path through the C-ABI vs the CPU oracle (bit-exact)."""
 import numpy as np
 import pytest
+import torch
 
 from circminer_amd import lib as cl
 from oracle import oracle_py as op
 from conftest import first_diff
 
 pytestmark = pytest.mark.gpu
+
+# A process that uses both this library and PyTorch's device tensors (the BsjGather test below, bench.py) has to let
+# torch bring up its bundled HIP runtime first: initialised second, it reports "No HIP GPUs are available".
+if torch.cuda.is_available():
+    torch.cuda.init()
 
 
 def _chains_equal(c0, n0, c1, n1):
@@ -39,6 +45,17 @@ def _run_all_rounds(ds, P):
         assert (idx == want).all() and stc.tobytes() == st1[want].tobytes()
         rec = hp.collect_records(1000)                 # the same pairs as device-assembled records
         assert (rec["pair"] == want + 1000).all() and rec["state"].tobytes() == st1[want].tobytes()
+        rec = rec.copy()
+        # ... and left in caller-owned HBM for the gather to rank 0 (dist.BsjGather; single process here)
+        from circminer_amd import dist as cdist
+        g = cdist.BsjGather(ds.batch.n, torch.device("cuda", 0))
+        for _ in range(2):                             # buffers are reused from batch to batch
+            n = hp.collect_records_device(1000, ds.batch.n, g.send_ptr())
+            g.submit(n)
+            assert n == len(want) and g.result().tobytes() == rec.tobytes()
+        host = np.zeros(4, dtype=cl.RECORD_DTYPE)     # a host pointer is refused, not dereferenced by a kernel
+        with pytest.raises(RuntimeError):
+            hp.collect_records_device(0, 4, host.ctypes.data)
     hp.close()
     return st0
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -1050,6 +1051,7 @@ struct cm_ctx {
     cm_mapped_read *d_collect_st = nullptr;
     cm_record *d_collect_rec = nullptr;
     uint64_t collect_rec_cap = 0;
+    std::unordered_map<const void *, size_t> caps;   // bytes behind each grow-only per-batch buffer, keyed by the pointer field (ensure())
     uint64_t collect_cap = 0;
     int8_t *d_col_cls = nullptr;
     uint32_t *d_col_perm = nullptr;
@@ -1107,13 +1109,26 @@ void dfree(T *&p) {
     p = nullptr;
 }
 
+// Grow-only per-batch buffers: a batch re-uses the previous batch's allocation when it is large enough.  hipFree + hipMalloc
+// of the multi-GB workspaces cost ~0.85 s per 1 M-pair batch on MI355X, 85x the mapping itself (tests/diag/upload_rate.py).
+template <class T>
+hipError_t ensure(cm_ctx *c, T *&p, size_t bytes) {
+    size_t &cap = c->caps[(const void *)&p];
+    if (p && cap >= bytes) return hipSuccess;
+    dfree(p);
+    cap = 0;
+    const hipError_t e = hipMalloc((void **)&p, bytes ? bytes : 1);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+}
+
 void free_reads(cm_ctx *c) {
     dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_collect_rec); dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
+    dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -1335,6 +1350,7 @@ void cm_destroy(cm_ctx *ctx) {
     }
     dfree(ctx->d_collect_idx);
     dfree(ctx->d_collect_st);
+    dfree(ctx->d_collect_rec);        // grow-only output staging outlives a batch (collect_cap / collect_rec_cap go with it)
     dfree(ctx->d_pool_cursor);
     dfree(ctx->d_err);
     dfree(ctx->d_counters);
@@ -1437,9 +1453,13 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     if (!ctx || !rd) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    free_reads(ctx);
     const uint64_t n = rd->n_pairs;
-    if (n == 0) return CM_OK;
+    ctx->n_pairs = 0;
+    ctx->tile = 0;
+    if (n == 0) {                                  // an empty batch releases the per-batch buffers
+        free_reads(ctx);
+        return CM_OK;
+    }
     if (n > 0x3fffffffull) return fail(ctx, CM_ELIMIT, "more than 2^30 pairs in one batch");
     if (!rd->seq1 || !rd->seq2 || !rd->off1 || !rd->off2) return fail(ctx, CM_EINVAL, "null read arrays");
     int max_len = 0;
@@ -1456,17 +1476,17 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     if (ctx->n_seeds > cmc::MAX_SEEDS) return fail(ctx, CM_ELIMIT, "%d seeds per read > %d supported", ctx->n_seeds, cmc::MAX_SEEDS);
     const size_t b1 = (size_t)rd->off1[n], b2 = (size_t)rd->off2[n];
     const size_t pad = cmc::CM_STAGE_PAD;                  // readable slack around the reads (see cmc::stage)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq1_base, b1 + 2 * pad));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq2_base, b2 + 2 * pad));
+    HIPCHK(ctx, ensure(ctx, ctx->d_seq1_base, b1 + 2 * pad));
+    HIPCHK(ctx, ensure(ctx, ctx->d_seq2_base, b2 + 2 * pad));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_seq1_base, 0, b1 + 2 * pad, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_seq2_base, 0, b2 + 2 * pad, ctx->stream));
     ctx->d_seq1 = ctx->d_seq1_base + pad;
     ctx->d_seq2 = ctx->d_seq2_base + pad;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_off1, (n + 1) * sizeof(uint64_t)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_off2, (n + 1) * sizeof(uint64_t)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_state, n * sizeof(cm_mapped_read)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_active, n));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cat, n * sizeof(int32_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_off1, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_off2, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_state, n * sizeof(cm_mapped_read)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_active, n));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cat, n * sizeof(int32_t)));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq1, rd->seq1, b1, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq2, rd->seq2, b2, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_off1, rd->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1489,12 +1509,12 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     const uint32_t tile = (uint32_t)(n < tile_cap ? n : tile_cap);
     ctx->tile = tile;
     const size_t nprob = (size_t)tile * 4, nprobe = nprob * (size_t)(ctx->n_seeds ? ctx->n_seeds : 1);
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sstart, nprobe * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scnt, nprobe * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sraw, nprobe * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cells, nprob * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_celloff, (nprob + 1) * 8));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsum, (nprob / SCAN_ELEMS + 2) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_sstart, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_scnt, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_sraw, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cells, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_celloff, (nprob + 1) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_bsum, (nprob / SCAN_ELEMS + 2) * 8));
     // DP cells: room for 64 cells per problem on average, at least 8M (one worst-case problem is
     // n_seeds * seed_lim cells); larger tiles are split into ranges by run_chain_tile.
     unsigned long long cap = (unsigned long long)nprob * 64ull;
@@ -1502,40 +1522,40 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     if (cap < (8ull << 20)) cap = 8ull << 20;
     if (cap < worst) cap = worst;
     ctx->cells_cap = cap;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_dpscore, cap * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_dpprev, cap * sizeof(int32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_nchain, nprob * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_high, nprob * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls, (size_t)tile));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls4, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm4, (size_t)tile * 4 * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_hres, (size_t)4096 * 64 * sizeof(HRes)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_sub, (size_t)tile));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm1, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_ctr3, CTR_WORDS * sizeof(unsigned int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_cls_sub2, (size_t)tile));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_perm0, (size_t)tile * 4));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_dpscore, cap * sizeof(double)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_dpprev, cap * sizeof(int32_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_nchain, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_high, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls, (size_t)tile));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls4, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm4, (size_t)tile * 4 * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)4096 * 64 * sizeof(HRes)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_sub, (size_t)tile));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm1, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr3, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_sub2, (size_t)tile));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm0, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_blk_cnt, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     if (getenv("CM_LANE_CLK")) {
 #if defined(CM_DIAG)
         const size_t clk_words = 16 * 2 + 1;  // per-pair rows + wave-level rows of k_pair and k_pair_heavy (diag)
 #else
         const size_t clk_words = 1;
 #endif
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_lane_clk, n * 8 * clk_words));
+        HIPCHK(ctx, ensure(ctx, ctx->d_lane_clk, n * 8 * clk_words));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lane_clk, 0, n * 8 * clk_words, ctx->stream));
     }
     unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
     if (pool < (256ull << 20)) pool = 256ull << 20;
     if (pool > (8ull << 30)) pool = 8ull << 30;
     ctx->pool_bytes = pool;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pool, pool));
+    HIPCHK(ctx, ensure(ctx, ctx->d_pool, pool));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CM_OK;
 }
@@ -1643,12 +1663,11 @@ static int compact_active(cm_ctx *ctx) {
     const uint64_t n = ctx->n_pairs;
     if (n > 0xfffffff0ull) return fail(ctx, CM_ELIMIT, "cm_collect_*: too many pairs");
     const uint32_t nbk = (uint32_t)((n + CLS_T - 1) / CLS_T);
-    if (!ctx->d_col_cls) {                        // scratch sized for the whole batch, allocated on first use
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_cls, n));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_perm, n * 4));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
-    }
+    // scratch sized for the whole batch, made on first use
+    HIPCHK(ctx, ensure(ctx, ctx->d_col_cls, n));
+    HIPCHK(ctx, ensure(ctx, ctx->d_col_perm, n * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, (const uint32_t *)nullptr,
                        (const unsigned int *)nullptr);

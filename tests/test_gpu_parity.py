@@ -282,3 +282,34 @@ def test_empty_batch_is_a_no_op(ds_tiny):
     idx, stc = hp.collect_active()
     assert len(st) == len(cat) == len(act) == len(idx) == 0
     hp.close()
+
+
+def test_one_context_many_batches(ds_tiny):
+    """A streaming caller re-uses one context for batch after batch (different sizes, an empty one in between): every
+    per-batch buffer is re-made, the grow-only output staging survives, and each batch's results equal a fresh
+    context's.  (Regression: the record staging buffer was freed with the batch while its capacity was kept.)"""
+    d = ds_tiny.d
+    P = cl.default_params()
+    hp = cl.HotPath(P)
+    hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
+    n = ds_tiny.batch.n
+    want = {}
+    for lo, hi_ in ((0, n // 2), (n // 2, n), (0, 0), (3, n // 4), (0, n)):
+        b = cl.ReadBatch(d.seq1[lo:hi_], d.seq2[lo:hi_]) if hi_ > lo else \
+            cl.ReadBatch(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int64))
+        hp.upload(b)
+        hp.map_round(0, True)
+        st, cat, act = hp.download()
+        rec = hp.collect_records(lo).copy()
+        idx, stc = hp.collect_active()
+        sel = np.nonzero(act)[0]
+        assert (rec["pair"] == sel + lo).all() and rec["state"].tobytes() == st[sel].tobytes()
+        assert (idx == sel).all() and stc.tobytes() == st[sel].tobytes()
+        want[(lo, hi_)] = (st.copy(), cat.copy())
+    hp.close()
+    st_all, cat_all = want[(0, n)]
+    for (lo, hi_), (st, cat) in want.items():       # process_read is a pure function of the pair: slices agree with the whole
+        assert st.tobytes() == st_all[lo:hi_].tobytes() and (cat == cat_all[lo:hi_]).all()
+    st0, act0 = op.default_state(P, n)
+    op.map_round(P, ds_tiny.hi.views[0], ds_tiny.hi.annots[0], ds_tiny.batch, True, st0, act0)
+    assert st0.tobytes() == st_all.tobytes()

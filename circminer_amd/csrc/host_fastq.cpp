@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -232,17 +233,44 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     f->b.clear();
     f->prior.clear();
     f->any_prior = false;
-    uint64_t n = 0;
+    // The two files are independent streams until the records are paired up: R2 is parsed (and, for .gz input, inflated)
+    // on a second thread while this one does R1 and its carried state.  The reference does both inside one lock-protected
+    // serial section (src/circminer.cpp:373-379), which is its ingest ceiling.
+    uint64_t n = 0, n2 = 0;
+    int bad2 = 0;
+    std::thread side_b([&]() {
+        while (n2 < max_pairs) {
+            const int r2 = parse_record(f, f->s2, f->b, false, nullptr, nullptr);
+            if (r2 == 0) break;
+            if (r2 < 0) {
+                bad2 = 1;
+                break;
+            }
+            ++n2;
+        }
+    });
+    int bad1 = 0;
     while (n < max_pairs) {
         cm_mapped_read st;
         bool carried = false;
         const int r1 = parse_record(f, f->s1, f->a, true, &st, &carried);
         if (r1 == 0) break;
-        const int r2 = r1 == 1 ? parse_record(f, f->s2, f->b, false, nullptr, nullptr) : -1;
-        if (r1 < 0 || r2 != 1) return CM_EINVAL;
+        if (r1 < 0) {
+            bad1 = 1;
+            break;
+        }
         f->prior.push_back(st);
         f->any_prior = f->any_prior || carried;
         ++n;
+    }
+    side_b.join();
+    if (bad1 || bad2 || n2 < n) return CM_EINVAL;                   // malformed record, or R2 ends before R1
+    if (n2 > n) {        // R1 ended first: like the reference, which stops at R1's end, the surplus R2 records are not paired
+        f->b.off.resize(n + 1);
+        f->b.seq.resize(f->b.off[n]);
+        f->b.qual.resize(f->b.off[n]);
+        f->b.name_off.resize(n + 1);
+        f->b.names.resize(f->b.name_off[n]);
     }
     memset(out, 0, sizeof *out);
     out->reads.n_pairs = n;

@@ -220,3 +220,16 @@ def test_malformed_fastq_is_an_error_not_a_crash(built, tmp_path):
     rd.close()
     with pytest.raises(RuntimeError):
         cl.FastqReader(str(tmp_path / "missing_1.fq"), p2)
+    # R2 shorter than R1 is an error; R2 longer is read up to R1's end (the reference stops when R1 runs out)
+    rec = lambda names: "".join(f"@{x}\nACGTA\n+\nIIIII\n" for x in names)
+    open(p1, "w").write(rec("abc"))
+    open(p2, "w").write(rec("ab"))
+    rd = cl.FastqReader(p1, p2)
+    with pytest.raises(RuntimeError):
+        rd.next_batch(10)
+    rd.close()
+    open(p2, "w").write(rec("abcde"))
+    rd = cl.FastqReader(p1, p2)
+    b = rd.next_batch(10)
+    assert b.n == 3 and [b.name(i, 2) for i in range(3)] == list("abc") and b.seq(2, 2) == b"ACGTA" and b.qual(2, 2) == b"IIIII"
+    rd.close()

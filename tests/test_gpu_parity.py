@@ -313,3 +313,20 @@ def test_one_context_many_batches(ds_tiny):
     st0, act0 = op.default_state(P, n)
     op.map_round(P, ds_tiny.hi.views[0], ds_tiny.hi.annots[0], ds_tiny.batch, True, st0, act0)
     assert st0.tobytes() == st_all.tobytes()
+
+
+def test_contigs_streamed_through_one_slot(ds_tiny2r):
+    """The reference keeps one packed contig resident at a time (loadHashTable per round, src/circminer.cpp:258-268).
+    Re-loading slot 0 for every round must give what the all-resident layout gives; the batch goes through twice so the
+    second pass starts from buffers the first one left behind."""
+    ds, P = ds_tiny2r, cl.default_params()
+    want, _, _ = op.map_all_rounds(P, ds.hi, ds.batch)
+    hp = cl.HotPath(P)
+    for _ in range(2):
+        hp.upload(ds.batch)
+        for ci in range(ds.hi.n_contigs):
+            hp.load_contig(0, ds.hi.views[ci], ds.hi.annots[ci])
+            hp.map_round(0, ci == ds.hi.n_contigs - 1)
+        st, _, _ = hp.download()
+        assert st.tobytes() == want.tobytes(), first_diff(want, st)
+    hp.close()

@@ -18,6 +18,8 @@ int cm_map_round(cm_ctx *, int, int) { return CM_ENODEV; }
 int cm_sync(cm_ctx *) { return CM_ENODEV; }
 int cm_reads_reset(cm_ctx *) { return CM_ENODEV; }
 int cm_collect_active(cm_ctx *, uint64_t, uint64_t *, cm_mapped_read *, uint64_t *) { return CM_ENODEV; }
+int cm_collect_records(cm_ctx *, uint64_t, uint64_t, cm_record *, uint64_t *) { return CM_ENODEV; }
+int cm_collect_records_device(cm_ctx *, uint64_t, uint64_t, void *, uint64_t *) { return CM_ENODEV; }
 int cm_host_alloc(cm_ctx *, uint64_t, void **) { return CM_ENODEV; }
 int cm_host_free(cm_ctx *, void *) { return CM_ENODEV; }
 int cm_reads_download(cm_ctx *, cm_mapped_read *, int32_t *, uint8_t *) { return CM_ENODEV; }

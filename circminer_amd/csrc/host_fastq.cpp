@@ -107,8 +107,13 @@ struct Side {
 
 struct cm_fastq {
     Stream s1, s2;
-    Side a, b;
-    std::vector<cm_mapped_read> prior;
+    // two generations of batch storage, used alternately: the batch a call returns stays valid while the NEXT call fills
+    // the other one, so a caller can parse batch k+1 while the GPU maps batch k and still write batch k's records after
+    struct Gen {
+        Side a, b;
+        std::vector<cm_mapped_read> prior;
+    } gen[2];
+    int cur = 1;
     std::vector<std::string> chr_names;
     int max_ed = 4;
     bool any_prior = false;
@@ -229,9 +234,11 @@ int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *c
 
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     if (!f || !out) return CM_EINVAL;
-    f->a.clear();
-    f->b.clear();
-    f->prior.clear();
+    f->cur ^= 1;
+    cm_fastq::Gen &G = f->gen[f->cur];
+    G.a.clear();
+    G.b.clear();
+    G.prior.clear();
     f->any_prior = false;
     // The two files are independent streams until the records are paired up: R2 is parsed (and, for .gz input, inflated)
     // on a second thread while this one does R1 and its carried state.  The reference does both inside one lock-protected
@@ -240,7 +247,7 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     int bad2 = 0;
     std::thread side_b([&]() {
         while (n2 < max_pairs) {
-            const int r2 = parse_record(f, f->s2, f->b, false, nullptr, nullptr);
+            const int r2 = parse_record(f, f->s2, G.b, false, nullptr, nullptr);
             if (r2 == 0) break;
             if (r2 < 0) {
                 bad2 = 1;
@@ -253,38 +260,38 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     while (n < max_pairs) {
         cm_mapped_read st;
         bool carried = false;
-        const int r1 = parse_record(f, f->s1, f->a, true, &st, &carried);
+        const int r1 = parse_record(f, f->s1, G.a, true, &st, &carried);
         if (r1 == 0) break;
         if (r1 < 0) {
             bad1 = 1;
             break;
         }
-        f->prior.push_back(st);
+        G.prior.push_back(st);
         f->any_prior = f->any_prior || carried;
         ++n;
     }
     side_b.join();
     if (bad1 || bad2 || n2 < n) return CM_EINVAL;                   // malformed record, or R2 ends before R1
     if (n2 > n) {        // R1 ended first: like the reference, which stops at R1's end, the surplus R2 records are not paired
-        f->b.off.resize(n + 1);
-        f->b.seq.resize(f->b.off[n]);
-        f->b.qual.resize(f->b.off[n]);
-        f->b.name_off.resize(n + 1);
-        f->b.names.resize(f->b.name_off[n]);
+        G.b.off.resize(n + 1);
+        G.b.seq.resize(G.b.off[n]);
+        G.b.qual.resize(G.b.off[n]);
+        G.b.name_off.resize(n + 1);
+        G.b.names.resize(G.b.name_off[n]);
     }
     memset(out, 0, sizeof *out);
     out->reads.n_pairs = n;
-    out->reads.seq1 = f->a.seq.data();
-    out->reads.off1 = f->a.off.data();
-    out->reads.seq2 = f->b.seq.data();
-    out->reads.off2 = f->b.off.data();
-    out->qual1 = f->a.qual.data();
-    out->qual2 = f->b.qual.data();
-    out->names1 = f->a.names.data();
-    out->name_off1 = f->a.name_off.data();
-    out->names2 = f->b.names.data();
-    out->name_off2 = f->b.name_off.data();
-    out->prior = f->any_prior ? f->prior.data() : nullptr;
+    out->reads.seq1 = G.a.seq.data();
+    out->reads.off1 = G.a.off.data();
+    out->reads.seq2 = G.b.seq.data();
+    out->reads.off2 = G.b.off.data();
+    out->qual1 = G.a.qual.data();
+    out->qual2 = G.b.qual.data();
+    out->names1 = G.a.names.data();
+    out->name_off1 = G.a.name_off.data();
+    out->names2 = G.b.names.data();
+    out->name_off2 = G.b.name_off.data();
+    out->prior = f->any_prior ? G.prior.data() : nullptr;
     return CM_OK;
 }
 

@@ -1,0 +1,190 @@
+// Stage 1 of CircMiner end to end, on top of the C ABI (the caller of the hot path).
+//
+// Mirrors mapping() + map_reads() of the reference (src/circminer.cpp:98-352, :354-400): index info -> GTF ->
+// one ROUND per packed contig -> per pair the skip / print / write rules of :386-397.  What changes is the order of
+// the loops.  The reference streams ALL reads through one contig, writes the survivors to <out>_<r>_remain_R?.fastq,
+// loads the next contig and streams those files again.  Here every packed contig is resident in HBM (hg38: ~40 GB of
+// 288 GB) and each batch of pairs goes through all rounds back to back on the device, so the only files written are
+// the ones a user of the reference keeps:
+//   <out>.mapping.pam | .sam            one row (two SAM lines) per pair, with the state it had when it was retired
+//                                       (skip) or after the last round -- the same rows the reference prints, in
+//                                       another order (the reference's order depends on its thread schedule);
+//   <out>_<R>_remain_R{1,2}.fastq       R = number of packed contigs: the CHIBSJ / CHI2BSJ pairs of the last round with
+//                                       their 23-token headers, stage 2's input (it sorts them itself).
+// A pair retired in round r is left untouched by later rounds (cm_map_round), so its final state is the one the
+// reference printed in round r.
+//
+// While the GPU maps batch k the host parses batch k+1 (cm_fastq_next keeps two generations of storage).
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "circminer_hot.h"
+
+namespace {
+
+struct Fail {
+    char *buf;
+    size_t cap;
+    int operator()(int code, const char *fmt, ...) const {
+        if (buf && cap) {
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, cap, fmt, ap);
+            va_end(ap);
+        }
+        return code;
+    }
+};
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats, char *err, uint64_t err_cap) {
+    Fail fail{err, (size_t)err_cap};
+    if (err && err_cap) err[0] = 0;
+    if (!a || !a->index_path || !a->index_info_path || !a->gtf_path || !a->fastq1 || !a->fastq2 || !a->out_prefix)
+        return fail(CM_EINVAL, "cm_mapping_run: null argument");
+    if (a->report < 0 || a->report > 2) return fail(CM_EINVAL, "report must be 0 (none), 1 (PAM) or 2 (SAM)");
+    cm_mapping_stats st;
+    memset(&st, 0, sizeof st);
+    const double t0 = now();
+    const int n_threads = a->n_threads > 0 ? a->n_threads : 1;
+    const uint64_t batch_pairs = a->batch_pairs ? a->batch_pairs : (1ull << 20);
+
+    cm_chr_info *chrs = nullptr;
+    uint32_t n_chr = 0;
+    cm_index_file *idx = nullptr;
+    cm_ctx *cm = nullptr;
+    cm_fastq *fq = nullptr;
+    cm_writer *w_map = nullptr, *w_rem = nullptr;
+    std::vector<cm_index_view> views;
+    std::vector<cm_annot_view> annots;
+    std::vector<cm_mapped_read> state;
+    std::vector<uint8_t> active;
+    std::vector<uint64_t> sel;
+    int rc = CM_OK;
+    auto cleanup = [&]() {
+        if (w_map) cm_writer_close(w_map);
+        if (w_rem) cm_writer_close(w_rem);
+        if (fq) cm_fastq_close(fq);
+        if (cm) cm_destroy(cm);
+        if (!annots.empty()) cm_host_free_annotation(annots.data(), (uint32_t)annots.size());
+        for (auto &v : views) cm_host_free_loaded_contig(&v);
+        if (idx) cm_host_close_index(idx);
+        if (chrs) cm_host_free_index_info(chrs, n_chr);
+    };
+#define MAP_TRY(call, what)                                                                                  \
+    do {                                                                                                     \
+        rc = (call);                                                                                         \
+        if (rc != CM_OK) {                                                                                   \
+            rc = fail(rc, "%s failed (%d)%s%s", what, rc, cm ? ": " : "", cm ? cm_last_error(cm) : "");       \
+            cleanup();                                                                                       \
+            return rc;                                                                                       \
+        }                                                                                                    \
+    } while (0)
+
+    // ---- index info, index file, context (genome_packer.load_index_info, checkHashTable, initLoadingHashTableMeta) ----
+    MAP_TRY(cm_host_read_index_info(a->index_info_path, &chrs, &n_chr), "cm_host_read_index_info");
+    int32_t kmer = 0, full = 0;
+    uint32_t n_rec = 0;
+    MAP_TRY(cm_host_open_index(a->index_path, &idx, &kmer, &full, &n_rec), "cm_host_open_index");
+    cm_params P = a->params;
+    if (P.kmer == 0) P.kmer = kmer;
+    if (P.kmer != kmer) {
+        rc = fail(CM_EINVAL, "index was built for k = %d, params ask for k = %d", kmer, P.kmer);
+        cleanup();
+        return rc;
+    }
+    MAP_TRY(cm_create(&P, &cm), "cm_create");
+
+    // ---- every packed contig into its own slot (loadHashTable + pac2char_whole_contig per round in the reference) ----
+    for (;;) {
+        cm_index_view iv;
+        int loaded = 0;
+        MAP_TRY(cm_host_next_contig(idx, n_threads, &iv, &loaded), "cm_host_next_contig");
+        if (!loaded) break;
+        views.push_back(iv);
+        if (iv.contig_num != (int32_t)views.size() - 1) {
+            rc = fail(CM_EINVAL, "packed contigs out of order: record %zu is contig %d", views.size(), iv.contig_num + 1);
+            cleanup();
+            return rc;
+        }
+        MAP_TRY(cm_load_contig(cm, (int)views.size() - 1, &iv), "cm_load_contig");
+    }
+    const uint32_t n_con = (uint32_t)views.size();
+    if (n_con == 0) {
+        rc = fail(CM_EINVAL, "index file holds no contig");
+        cleanup();
+        return rc;
+    }
+    // ---- GTF (gtf_parser.init / load_gtf) ----
+    {
+        std::vector<uint32_t> clen(n_con);
+        for (uint32_t c = 0; c < n_con; ++c) clen[c] = views[c].ref_len;
+        annots.resize(n_con);
+        rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen.data(), n_con, P.max_read_len, annots.data());
+        if (rc != CM_OK) {
+            annots.clear();
+            rc = fail(rc, "cm_host_build_annotation failed (%d)", rc);
+            cleanup();
+            return rc;
+        }
+        for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_load_annotation(cm, (int)c, &annots[c]), "cm_load_annotation");
+        for (auto &v : views) cm_host_free_loaded_contig(&v);      // host copies are no longer needed: everything is in HBM
+        views.clear();
+    }
+    st.rounds = (int32_t)n_con;
+    st.seconds_load = now() - t0;
+
+    // ---- outputs (FilterRead::init, src/filter.cpp:34-84; SAMOutput::init) ----
+    const std::string out = a->out_prefix;
+    if (a->report) {
+        const std::string path = out + (a->report == 2 ? ".mapping.sam" : ".mapping.pam");
+        MAP_TRY(cm_writer_open(path.c_str(), nullptr, chrs, n_chr, &w_map), "cm_writer_open (mapping)");
+        if (a->report == 2) MAP_TRY(cm_write_sam_header(w_map), "cm_write_sam_header");
+    }
+    {
+        const std::string r1 = out + "_" + std::to_string(n_con) + "_remain_R1.fastq", r2 = out + "_" + std::to_string(n_con) + "_remain_R2.fastq";
+        MAP_TRY(cm_writer_open(r1.c_str(), r2.c_str(), chrs, n_chr, &w_rem), "cm_writer_open (remain)");
+    }
+    MAP_TRY(cm_fastq_open(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, &fq), "cm_fastq_open");
+
+    // ---- batches: parse k+1 while the device runs all rounds of k ----
+    const double t1 = now();
+    cm_fastq_batch cur, nxt;
+    MAP_TRY(cm_fastq_next(fq, batch_pairs, &cur), "cm_fastq_next");
+    while (cur.reads.n_pairs) {
+        const uint64_t n = cur.reads.n_pairs;
+        MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
+        for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_map_round(cm, (int)c, c + 1 == n_con), "cm_map_round");   // asynchronous
+        MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");
+        state.resize(n);
+        active.resize(n);
+        MAP_TRY(cm_reads_download(cm, state.data(), nullptr, active.data()), "cm_reads_download");
+        // map_reads, src/circminer.cpp:386-397: printed if (skip || last round) = every pair by now;
+        // written to the remain files if still active after the last round = CHIBSJ / CHI2BSJ
+        if (a->report == 1) MAP_TRY(cm_write_pam(w_map, &cur, state.data(), nullptr, 0), "cm_write_pam");
+        if (a->report == 2) MAP_TRY(cm_write_sam(w_map, &cur, state.data(), nullptr, 0), "cm_write_sam");
+        sel.clear();
+        for (uint64_t i = 0; i < n; ++i)
+            if (active[i]) sel.push_back(i);
+        if (!sel.empty()) MAP_TRY(cm_write_remain(w_rem, &cur, state.data(), sel.data(), sel.size()), "cm_write_remain");
+        st.pairs += n;
+        st.bsj_pairs += sel.size();
+        for (uint64_t i = 0; i < n; ++i) {
+            const int t = state[i].type;
+            if (t >= 0 && t < 14) ++st.by_type[t];
+        }
+        cur = nxt;
+    }
+    st.seconds_map = now() - t1;
+    cleanup();
+    if (stats) *stats = st;
+    return CM_OK;
+#undef MAP_TRY
+}

@@ -29,6 +29,17 @@ class Params(C.Structure):
                                          "max_tlen", "max_intron", "max_chain_len", "device", "reserved")]
 
 
+class MappingArgs(C.Structure):
+    _fields_ = [("index_path", C.c_char_p), ("index_info_path", C.c_char_p), ("gtf_path", C.c_char_p), ("fastq1", C.c_char_p),
+                ("fastq2", C.c_char_p), ("out_prefix", C.c_char_p), ("params", Params), ("report", C.c_int32), ("n_threads", C.c_int32),
+                ("batch_pairs", C.c_uint64)]
+
+
+class MappingStats(C.Structure):
+    _fields_ = [("pairs", C.c_uint64), ("bsj_pairs", C.c_uint64), ("by_type", C.c_uint64 * 14), ("rounds", C.c_int32),
+                ("reserved", C.c_int32), ("seconds_load", C.c_double), ("seconds_map", C.c_double)]
+
+
 def default_params(**kw) -> Params:
     """Defaults of reference src/commandline_parser.cpp:7-33 / src/common.h:39-53."""
     d = dict(kmer=20, seed_lim=500, max_read_len=300, scan_level=0, max_ed=4, max_sc=7, band=3, max_tlen=500,
@@ -179,6 +190,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_mapping_run": (C.c_int, [pp(MappingArgs), pp(MappingStats), C.c_char_p, C.c_uint64]),
         "cm_write_sam_header": (C.c_int, [vp]),
         "cm_write_sam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_writer_close": (None, [vp]),
@@ -198,7 +210,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run"]
 
 
 class HostIndex:
@@ -334,6 +346,19 @@ class ParsedBatch:
     def qual(self, i: int, mate: int = 1) -> bytes:
         q, o = (self.fb.qual1, self.c.off1) if mate == 1 else (self.fb.qual2, self.c.off2)
         return bytes(np.ctypeslib.as_array(q, (int(o[self.n]),))[int(o[i]):int(o[i + 1])])
+
+
+def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report=1, n_threads=4, batch_pairs=0, index_info=None):
+    """cm_mapping_run: stage 1 from files to files (the reference's mapping(), src/circminer.cpp:98-352)."""
+    L = load()
+    a = MappingArgs(index_path.encode(), (index_info or index_path + ".info").encode(), gtf.encode(), fastq1.encode(), fastq2.encode(),
+                    out_prefix.encode(), params if params is not None else default_params(), report, n_threads, batch_pairs)
+    st = MappingStats()
+    err = C.create_string_buffer(1024)
+    rc = L.cm_mapping_run(C.byref(a), C.byref(st), err, len(err))
+    if rc != 0:
+        raise RuntimeError(f"cm_mapping_run failed ({rc}): {err.value.decode()}")
+    return st
 
 
 class FastqReader:

@@ -295,7 +295,8 @@ void cm_host_close_index(cm_index_file *f);
 
 /* ---------------- FASTQ ingest, carry-over header, PAM / remain writers ---------- */
 /* One batch of parsed pairs in the layout cm_reads_upload takes.  All pointers belong to the parser and stay
- * valid until the next cm_fastq_next / cm_fastq_close.  names*: NUL-terminated read names (first header token,
+ * valid until the SECOND next cm_fastq_next (two generations of storage alternate, so batch k+1 can be parsed while
+ * batch k is on the GPU and batch k's records written afterwards) or cm_fastq_close.  names*: NUL-terminated read names (first header token,
  * trailing "/x" cut: FASTQParser::extract_map_info, src/fastq_parser.cpp:178-198), name i at names + name_off[i].
  * prior: the MatchedRead each pair carried in its 23-token header (fill_map_info, :200-269) or NULL when no
  * pair of the batch carried one (fresh reads: cm_reads_upload's default state). */
@@ -329,6 +330,33 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
 int cm_write_sam_header(cm_writer *w);
 int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
 void cm_writer_close(cm_writer *w);
+
+/* ---------------- stage 1 end to end: the caller of the hot path ---------------- */
+/* mapping() + map_reads() of the reference (src/circminer.cpp:98-352, :354-400) over the entry points above: reads
+ * <ref>.packed.fa.index(.info) and the GTF, keeps every packed contig resident, takes the paired FASTQ through all
+ * rounds batch by batch, and writes what the reference leaves behind for the user and for stage 2:
+ *   <out>.mapping.pam (report 1) or <out>.mapping.sam (report 2): the rows map_reads prints (skip || last round);
+ *   <out>_<R>_remain_R1.fastq / _R2.fastq, R = number of packed contigs: the CHIBSJ / CHI2BSJ pairs (:395-397).
+ * The per-round remain files of the reference (its way of carrying pairs from one contig to the next) are not
+ * written: the carried state stays in HBM.  params.kmer == 0 takes the index file's k. */
+typedef struct cm_mapping_args {
+    const char *index_path;        /* <ref>.packed.fa.index        */
+    const char *index_info_path;   /* <ref>.packed.fa.index.info   */
+    const char *gtf_path;
+    const char *fastq1, *fastq2;   /* plain or gzip                */
+    const char *out_prefix;        /* outputFilename               */
+    cm_params params;
+    int32_t report;                /* reportMapping: 0 none, 1 PAM, 2 SAM */
+    int32_t n_threads;             /* host threads for the index loader   */
+    uint64_t batch_pairs;          /* pairs per resident batch, 0 = 2^20  */
+} cm_mapping_args;
+typedef struct cm_mapping_stats {
+    uint64_t pairs, bsj_pairs;
+    uint64_t by_type[14];          /* final MatchedRead::type histogram (CM_CONCRD ... ) */
+    int32_t rounds, reserved;
+    double seconds_load, seconds_map;
+} cm_mapping_stats;
+int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *err, uint64_t err_cap);
 
 #ifdef __cplusplus
 }

@@ -330,3 +330,73 @@ def test_contigs_streamed_through_one_slot(ds_tiny2r):
         st, _, _ = hp.download()
         assert st.tobytes() == want.tobytes(), first_diff(want, st)
     hp.close()
+
+
+@pytest.mark.parametrize("preset,contig_size,report", [("tiny2r", 150_000, 1), ("tiny", 1_100_000_000, 2)])
+def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
+    """cm_mapping_run = the reference's mapping() (src/circminer.cpp:98-352) on stock file formats: FASTA -> packed genome +
+    index file, GTF, gzip FASTQ in; <out>.mapping.pam / .sam and the last round's remain FASTQ out.  Expected rows come
+    from the CPU oracle's final states through the Python restatements of the writers (tests/test_fastq_io.py)."""
+    import gzip
+    from circminer_amd import synth
+    from test_fastq_io import py_pam_row, py_remain_header, py_sam_rows
+    n = 3000
+    d = synth.generate(preset, n_pairs=n, seed=33)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as f:
+        for name, con, start, ln in d.chr_table:
+            seq = d.contigs[con - 1][start:start + ln].tobytes().decode()
+            f.write(f">{name} some description\n")
+            f.writelines(seq[i:i + 70] + "\n" for i in range(0, ln, 70))
+    packed, info = cl.pack_genome(fa, contig_size)
+    idx = cl.write_index(packed, kmer=20, n_threads=4)
+    gtf = str(tmp_path / "ref.gtf")
+    open(gtf, "w").write(d.gtf_text)
+    names = [f"frag.{i}" for i in range(n)]
+    quals = ["".join(chr(33 + (i * 7 + k) % 40) for k in range(d.seq1.shape[1])) for i in range(16)]
+    fq = []
+    for mate, arr in ((1, d.seq1), (2, d.seq2)):
+        p = str(tmp_path / f"reads_{mate}.fq.gz")
+        with gzip.open(p, "wt", compresslevel=1) as f:
+            for i in range(n):
+                f.write(f"@{names[i]}/{mate} extra\n{arr[i].tobytes().decode()}\n+\n{quals[i % 16]}\n")
+        fq.append(p)
+    out = str(tmp_path / "run")
+    P = cl.default_params(kmer=0)                                       # k comes from the index file
+    st = cl.run_mapping(idx, gtf, fq[0], fq[1], out, P, report=report, n_threads=4, batch_pairs=1024)   # 3 batches
+
+    # expectation: the oracle on the in-memory builder's views of the same genome
+    gtf2 = str(tmp_path / "ref2.gtf")
+    open(gtf2, "w").write(d.gtf_text)
+    hi = cl.HostIndex(d.contigs, d.chr_table, gtf2, kmer=20)
+    P20 = cl.default_params()
+    want, act, _ = op.map_all_rounds(P20, hi, cl.ReadBatch(d.seq1, d.seq2))
+    chrs = d.chr_table
+    assert st.pairs == n and st.rounds == hi.n_contigs and st.bsj_pairs == int(act.sum()) > 0
+    assert list(st.by_type) == [int((want["type"] == t).sum()) for t in range(14)]
+    s1 = [d.seq1[i].tobytes().decode() for i in range(n)]
+    s2 = [d.seq2[i].tobytes().decode() for i in range(n)]
+    if report == 1:
+        rows = open(out + ".mapping.pam").read().split("\n")
+        assert rows[-1] == "" and rows[:-1] == [py_pam_row(names[i], want[i], chrs) for i in range(n)]
+    else:
+        rows = open(out + ".mapping.sam").read().split("\n")
+        hdr = 1 + len(chrs)
+        assert rows[0].startswith("@HD") and [r.split("\t")[1] for r in rows[1:hdr]] == [f"SN:{c[0]}" for c in chrs]
+        exp = []
+        for i in range(n):
+            exp += py_sam_rows(names[i], want[i], chrs, s1[i], quals[i % 16], s2[i], quals[i % 16])
+        assert rows[hdr:-1] == exp
+    keep = np.nonzero(act)[0]
+    assert set(want["type"][keep]) <= {3, 4}
+    for mate, seqs in ((1, s1), (2, s2)):
+        lines = open(f"{out}_{hi.n_contigs}_remain_R{mate}.fastq").read().split("\n")
+        assert lines[-1] == "" and len(lines) == 4 * len(keep) + 1
+        for k, i in enumerate(keep):
+            assert lines[4 * k] == py_remain_header(names[i], want[i], chrs)
+            assert lines[4 * k + 1:4 * k + 4] == [seqs[i], "+", quals[i % 16]]
+    # bad input is an error message, not a crash
+    with pytest.raises(RuntimeError, match="k = 20"):
+        cl.run_mapping(idx, gtf, fq[0], fq[1], out, cl.default_params(kmer=18))
+    with pytest.raises(RuntimeError):
+        cl.run_mapping(idx + ".nope", gtf, fq[0], fq[1], out, P)

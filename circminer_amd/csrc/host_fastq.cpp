@@ -107,13 +107,13 @@ struct Side {
 
 struct cm_fastq {
     Stream s1, s2;
-    // two generations of batch storage, used alternately: the batch a call returns stays valid while the NEXT call fills
-    // the other one, so a caller can parse batch k+1 while the GPU maps batch k and still write batch k's records after
+    // three generations of batch storage, used in turn: the batch a call returns stays valid over the next two calls, so a
+    // caller can have batch k-1 with its writer thread, batch k on the GPU and batch k+1 in the parser at the same time
     struct Gen {
         Side a, b;
         std::vector<cm_mapped_read> prior;
-    } gen[2];
-    int cur = 1;
+    } gen[3];
+    int cur = 2;
     std::vector<std::string> chr_names;
     int max_ed = 4;
     bool any_prior = false;
@@ -208,8 +208,60 @@ int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_
 
 }  // namespace
 
+// Append-only text buffer in front of a FILE: the writers format integers themselves (a PAM row is 20 of them), which is
+// several times faster than one fprintf per record.
+struct Out {
+    FILE *f = nullptr;
+    std::vector<char> buf;
+    size_t n = 0;
+    void open(FILE *fp) {
+        f = fp;
+        buf.resize(4u << 20);
+        n = 0;
+    }
+    void flush() {
+        if (f && n) fwrite(buf.data(), 1, n, f);
+        n = 0;
+    }
+    void room(size_t k) {
+        if (n + k > buf.size()) {
+            flush();
+            if (k > buf.size()) buf.resize(k);
+        }
+    }
+    void raw(const void *p, size_t k) {
+        room(k);
+        memcpy(buf.data() + n, p, k);
+        n += k;
+    }
+    void str(const char *z) { raw(z, strlen(z)); }
+    void ch(char c) {
+        room(1);
+        buf[n++] = c;
+    }
+    void u64(uint64_t v) {
+        char t[24];
+        int k = 0;
+        do {
+            t[k++] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        room((size_t)k);
+        while (k) buf[n++] = t[--k];
+    }
+    void i64(int64_t v) {
+        if (v < 0) {
+            ch('-');
+            u64(0 - (uint64_t)v);
+        } else {
+            u64((uint64_t)v);
+        }
+    }
+};
+
 struct cm_writer {
     FILE *f1 = nullptr, *f2 = nullptr;
+    Out o1, o2;
     std::vector<std::string> chr_names;
     std::vector<uint32_t> chr_shift, chr_len;
 };
@@ -234,7 +286,7 @@ int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *c
 
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     if (!f || !out) return CM_EINVAL;
-    f->cur ^= 1;
+    f->cur = (f->cur + 1) % 3;
     cm_fastq::Gen &G = f->gen[f->cur];
     G.a.clear();
     G.b.clear();
@@ -314,6 +366,8 @@ int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs
         delete w;
         return CM_EINVAL;
     }
+    w->o1.open(w->f1);
+    if (w->f2) w->o2.open(w->f2);
     for (uint32_t i = 0; i < n_chr; ++i) {
         w->chr_names.emplace_back(chrs[i].name ? chrs[i].name : "");
         w->chr_shift.push_back(chrs[i].start_pos);
@@ -333,25 +387,51 @@ int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read 
         const uint64_t i = sel ? sel[k] : k;
         if (i >= b->reads.n_pairs) return CM_EINVAL;
         const cm_mapped_read &m = states[i];
-        FILE *fs[2] = {w->f1, w->f2};
+        Out *os[2] = {&w->o1, &w->o2};
         for (int s = 0; s < 2; ++s) {
-            FILE *f = fs[s];
-            fprintf(f, "@%s", (s ? b->names2 : b->names1) + (s ? b->name_off2 : b->name_off1)[i]);
+            Out &o = *os[s];
+            o.ch('@');
+            o.str((s ? b->names2 : b->names1) + (s ? b->name_off2 : b->name_off1)[i]);
             if (mapped_type(m.type)) {
                 const char *cn = chr_name(w, m.chr_id);
                 const uint32_t shift = (m.chr_id >= 0 && (size_t)m.chr_id < w->chr_shift.size()) ? w->chr_shift[(size_t)m.chr_id] : 0u;
                 const uint64_t gspos = (uint64_t)(int64_t)m.contig_num * CM_CONTIG_SIZE + (uint32_t)(m.spos_r1 + shift);   // chrloc2conloc
-                fprintf(f, " %" PRId64 " %d %s %u %u %d %u %u %c %d %s %u %u %d %u %u %c %d %d %d %d %d", (int64_t)gspos, m.type, cn, m.spos_r1,
-                        m.epos_r1, (int)m.mlen_r1, m.qspos_r1, m.qepos_r1, m.r1_forward ? '+' : '-', m.ed_r1, cn, m.spos_r2, m.epos_r2,
-                        (int)m.mlen_r2, m.qspos_r2, m.qepos_r2, m.r2_forward ? '+' : '-', m.ed_r2, m.tlen, (int)m.junc_num,
-                        (int)(m.gm_compatible != 0), m.contig_num);
+                // " %PRId64 %d %s %u %u %d %u %u %c %d %s %u %u %d %u %u %c %d %d %d %d %d"
+                o.ch(' '); o.i64((int64_t)gspos);
+                o.ch(' '); o.i64(m.type);
+                o.ch(' '); o.str(cn);
+                o.ch(' '); o.u64(m.spos_r1);
+                o.ch(' '); o.u64(m.epos_r1);
+                o.ch(' '); o.i64((int)m.mlen_r1);
+                o.ch(' '); o.u64(m.qspos_r1);
+                o.ch(' '); o.u64(m.qepos_r1);
+                o.ch(' '); o.ch(m.r1_forward ? '+' : '-');
+                o.ch(' '); o.i64(m.ed_r1);
+                o.ch(' '); o.str(cn);
+                o.ch(' '); o.u64(m.spos_r2);
+                o.ch(' '); o.u64(m.epos_r2);
+                o.ch(' '); o.i64((int)m.mlen_r2);
+                o.ch(' '); o.u64(m.qspos_r2);
+                o.ch(' '); o.u64(m.qepos_r2);
+                o.ch(' '); o.ch(m.r2_forward ? '+' : '-');
+                o.ch(' '); o.i64(m.ed_r2);
+                o.ch(' '); o.i64(m.tlen);
+                o.ch(' '); o.i64((int)m.junc_num);
+                o.ch(' '); o.i64((int)(m.gm_compatible != 0));
+                o.ch(' '); o.i64(m.contig_num);
             } else {
-                fprintf(f, " * %d * * * * * * * * * * * * * * * * * * * *", m.type);
+                o.str(" * ");
+                o.i64(m.type);
+                o.str(" * * * * * * * * * * * * * * * * * * * *");
             }
             const uint8_t *seq = s ? b->reads.seq2 : b->reads.seq1, *q = s ? b->qual2 : b->qual1;
             const uint64_t *off = s ? b->reads.off2 : b->reads.off1;
-            const int len = (int)(off[i + 1] - off[i]);
-            fprintf(f, "\n%.*s\n+\n%.*s\n", len, (const char *)seq + off[i], len, (const char *)q + off[i]);
+            const size_t len = (size_t)(off[i + 1] - off[i]);
+            o.ch('\n');
+            o.raw(seq + off[i], len);
+            o.str("\n+\n");
+            o.raw(q + off[i], len);
+            o.ch('\n');
         }
     }
     return CM_OK;
@@ -366,13 +446,36 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
         if (i >= b->reads.n_pairs) return CM_EINVAL;
         const cm_mapped_read &m = states[i];
         const char *nm = b->names1 + b->name_off1[i];
+        Out &o = w->o1;
+        o.str(nm);
         if (mapped_type(m.type)) {
             const char *cn = chr_name(w, m.chr_id);
-            fprintf(w->f1, "%s\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%d\t%d\t%d\t%d\n", nm, cn, m.spos_r1, m.epos_r1,
-                    (int)m.mlen_r1, m.qspos_r1, m.qepos_r1, m.r1_forward ? '+' : '-', m.ed_r1, cn, m.spos_r2, m.epos_r2, (int)m.mlen_r2, m.qspos_r2,
-                    m.qepos_r2, m.r2_forward ? '+' : '-', m.ed_r2, m.tlen, (int)m.junc_num, (int)(m.gm_compatible != 0), m.type);
+            // "%s\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%d\t%d\t%d\t%d\n"
+            o.ch('\t'); o.str(cn);
+            o.ch('\t'); o.u64(m.spos_r1);
+            o.ch('\t'); o.u64(m.epos_r1);
+            o.ch('\t'); o.i64((int)m.mlen_r1);
+            o.ch('\t'); o.u64(m.qspos_r1);
+            o.ch('\t'); o.u64(m.qepos_r1);
+            o.ch('\t'); o.ch(m.r1_forward ? '+' : '-');
+            o.ch('\t'); o.i64(m.ed_r1);
+            o.ch('\t'); o.str(cn);
+            o.ch('\t'); o.u64(m.spos_r2);
+            o.ch('\t'); o.u64(m.epos_r2);
+            o.ch('\t'); o.i64((int)m.mlen_r2);
+            o.ch('\t'); o.u64(m.qspos_r2);
+            o.ch('\t'); o.u64(m.qepos_r2);
+            o.ch('\t'); o.ch(m.r2_forward ? '+' : '-');
+            o.ch('\t'); o.i64(m.ed_r2);
+            o.ch('\t'); o.i64(m.tlen);
+            o.ch('\t'); o.i64((int)m.junc_num);
+            o.ch('\t'); o.i64((int)(m.gm_compatible != 0));
+            o.ch('\t'); o.i64(m.type);
+            o.ch('\n');
         } else {
-            fprintf(w->f1, "%s\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t%d\n", nm, m.type);
+            o.str("\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t");
+            o.i64(m.type);
+            o.ch('\n');
         }
     }
     return CM_OK;
@@ -381,8 +484,15 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
 // SAMOutput::print_header (src/output.cpp:301-311)
 int cm_write_sam_header(cm_writer *w) {
     if (!w) return CM_EINVAL;
-    fprintf(w->f1, "@HD\tVN:1.4\tSO:unsorted\n");
-    for (size_t i = 0; i < w->chr_names.size(); ++i) fprintf(w->f1, "@SQ\tSN:%s\tLN:%u\n", w->chr_names[i].c_str(), w->chr_len[i]);
+    Out &o = w->o1;
+    o.str("@HD\tVN:1.4\tSO:unsorted\n");
+    for (size_t i = 0; i < w->chr_names.size(); ++i) {
+        o.str("@SQ\tSN:");
+        o.str(w->chr_names[i].c_str());
+        o.str("\tLN:");
+        o.u64(w->chr_len[i]);
+        o.ch('\n');
+    }
     return CM_OK;
 }
 
@@ -406,15 +516,17 @@ unsigned sam_flag(const cm_mapped_read &m, bool first) {                 // set_
 }
 // FASTQParser::set_comp / set_reverse_comp (src/fastq_parser.cpp:141-176): bytes outside ACGTN / acgtn map to NUL, which
 // ends the %s the reference prints
-char comp_of(unsigned char ch) {
-    switch (ch) {
-        case 'A': case 'a': return 'T';
-        case 'C': case 'c': return 'G';
-        case 'G': case 'g': return 'C';
-        case 'T': case 't': return 'A';
-        case 'N': case 'n': return 'N';
-        default: return '\0';
+struct CompTable {
+    char t[256];
+    CompTable() {
+        memset(t, 0, sizeof t);
+        const char *from = "ACGTNacgtn", *to = "TGCANTGCAN";
+        for (int i = 0; from[i]; ++i) t[(unsigned char)from[i]] = to[i];
     }
+};
+inline char comp_of(unsigned char ch) {
+    static const CompTable c;
+    return c.t[ch];
 }
 }  // namespace
 
@@ -422,7 +534,8 @@ char comp_of(unsigned char ch) {
 int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel) {
     if (!w || !b || !states) return CM_EINVAL;
     const uint64_t n = sel ? n_sel : b->reads.n_pairs;
-    std::string seq[2], qual[2];
+    std::vector<char> rc, rq;
+    Out &o = w->o1;
     for (uint64_t k = 0; k < n; ++k) {
         const uint64_t i = sel ? sel[k] : k;
         if (i >= b->reads.n_pairs) return CM_EINVAL;
@@ -441,24 +554,44 @@ int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
         if (flag[1] & RUNMAP) { rname[1] = "*"; rnext[0] = "*"; pos[1] = 0; pnext[0] = 0; tlen[0] = tlen[1] = 0; }
         else { rname[1] = cn; rnext[0] = "="; pos[1] = m.spos_r2; pnext[0] = m.spos_r2; }
         for (int s = 0; s < 2; ++s) {
-            const uint8_t *sq = s ? b->reads.seq2 : b->reads.seq1, *ql = s ? b->qual2 : b->qual1;
+            const uint8_t *sq = (s ? b->reads.seq2 : b->reads.seq1), *ql = (s ? b->qual2 : b->qual1);
             const uint64_t *off = s ? b->reads.off2 : b->reads.off1;
             const size_t len = (size_t)(off[i + 1] - off[i]);
-            seq[s].assign((const char *)sq + off[i], len);
-            qual[s].assign((const char *)ql + off[i], len);
+            sq += off[i];
+            ql += off[i];
+            // "%s\t%u\t%s\t%u\t%u\t%s\t%s\t%u\t%u\t%s\t%s" + "\tAT:i:%d\tNM:i:%d\tJC:i:%d\tTC:i:%d" + "\n"
+            o.str(qname);
+            o.ch('\t'); o.u64(flag[s]);
+            o.ch('\t'); o.str(rname[s]);
+            o.ch('\t'); o.u64(pos[s]);
+            o.str("\t255\t*\t");
+            o.str(rnext[s]);
+            o.ch('\t'); o.u64(pnext[s]);
+            o.ch('\t'); o.u64((uint32_t)tlen[s]);                   // the reference prints the int32 through %u
+            o.ch('\t');
             if (flag[s] & RREVER) {
-                std::string rc(len, '\0'), rq(len, '\0');
+                rc.resize(len);
+                rq.resize(len);
+                size_t rc_len = len;                                // %s stops at the first NUL of rcseq
                 for (size_t x = 0; x < len; ++x) {
-                    rc[x] = comp_of((unsigned char)seq[s][len - 1 - x]);
-                    rq[x] = qual[s][len - 1 - x];
+                    rc[x] = comp_of(sq[len - 1 - x]);
+                    rq[x] = (char)ql[len - 1 - x];
+                    if (rc[x] == '\0' && rc_len == len) rc_len = x;
                 }
-                seq[s] = rc.substr(0, rc.find('\0'));             // %s stops at the first NUL
-                qual[s] = rq;
+                o.raw(rc.data(), rc_len);
+                o.ch('\t');
+                o.raw(rq.data(), len);
+            } else {
+                o.raw(sq, len);
+                o.ch('\t');
+                o.raw(ql, len);
             }
             const bool un = (flag[s] & RUNMAP) != 0;
-            const int ed = un ? 0 : (s ? m.ed_r2 : m.ed_r1), jc = un ? 0 : (int)m.junc_num, gm = un ? 0 : (int)(m.gm_compatible != 0);
-            fprintf(w->f1, "%s\t%u\t%s\t%u\t%u\t%s\t%s\t%u\t%u\t%s\t%s\tAT:i:%d\tNM:i:%d\tJC:i:%d\tTC:i:%d\n", qname, flag[s], rname[s], pos[s], 255u, "*",
-                    rnext[s], pnext[s], (unsigned)tlen[s], seq[s].c_str(), qual[s].c_str(), m.type, ed, jc, gm);
+            o.str("\tAT:i:"); o.i64(m.type);
+            o.str("\tNM:i:"); o.i64(un ? 0 : (s ? m.ed_r2 : m.ed_r1));
+            o.str("\tJC:i:"); o.i64(un ? 0 : (int)m.junc_num);
+            o.str("\tTC:i:"); o.i64(un ? 0 : (int)(m.gm_compatible != 0));
+            o.ch('\n');
         }
     }
     return CM_OK;
@@ -466,6 +599,8 @@ int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
 
 void cm_writer_close(cm_writer *w) {
     if (!w) return;
+    w->o1.flush();
+    w->o2.flush();
     if (w->f1) fclose(w->f1);
     if (w->f2) fclose(w->f2);
     delete w;

@@ -14,12 +14,14 @@
 // A pair retired in round r is left untouched by later rounds (cm_map_round), so its final state is the one the
 // reference printed in round r.
 //
-// While the GPU maps batch k the host parses batch k+1 (cm_fastq_next keeps two generations of storage).
+// Three batches are in flight: batch k-1's rows are being written by a worker thread, batch k is on the GPU, batch k+1
+// is being parsed (cm_fastq_next keeps three generations of storage).
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -54,7 +56,7 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     memset(&st, 0, sizeof st);
     const double t0 = now();
     const int n_threads = a->n_threads > 0 ? a->n_threads : 1;
-    const uint64_t batch_pairs = a->batch_pairs ? a->batch_pairs : (1ull << 20);
+    const uint64_t batch_pairs = a->batch_pairs ? a->batch_pairs : (1ull << 18);
 
     cm_chr_info *chrs = nullptr;
     uint32_t n_chr = 0;
@@ -64,11 +66,18 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     cm_writer *w_map = nullptr, *w_rem = nullptr;
     std::vector<cm_index_view> views;
     std::vector<cm_annot_view> annots;
-    std::vector<cm_mapped_read> state;
-    std::vector<uint8_t> active;
-    std::vector<uint64_t> sel;
+    // results of batch k live in set k & 1: the writer thread of batch k reads them while batch k+1 is downloaded
+    struct Result {
+        std::vector<cm_mapped_read> state;
+        std::vector<uint8_t> active;
+        std::vector<uint64_t> sel;
+        cm_fastq_batch batch;
+    } res[2];
+    std::thread writer;
+    int writer_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
+        if (writer.joinable()) writer.join();
         if (w_map) cm_writer_close(w_map);
         if (w_rem) cm_writer_close(w_rem);
         if (fq) cm_fastq_close(fq);
@@ -154,34 +163,43 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     }
     MAP_TRY(cm_fastq_open(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, &fq), "cm_fastq_open");
 
-    // ---- batches: parse k+1 while the device runs all rounds of k ----
+    // ---- batches: write k-1 (worker thread) | all rounds of k (device) | parse k+1 (this thread) ----
     const double t1 = now();
     cm_fastq_batch cur, nxt;
     MAP_TRY(cm_fastq_next(fq, batch_pairs, &cur), "cm_fastq_next");
-    while (cur.reads.n_pairs) {
+    for (uint64_t k = 0; cur.reads.n_pairs; ++k) {
         const uint64_t n = cur.reads.n_pairs;
+        Result &R = res[k & 1];
         MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_map_round(cm, (int)c, c + 1 == n_con), "cm_map_round");   // asynchronous
         MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");
-        state.resize(n);
-        active.resize(n);
-        MAP_TRY(cm_reads_download(cm, state.data(), nullptr, active.data()), "cm_reads_download");
-        // map_reads, src/circminer.cpp:386-397: printed if (skip || last round) = every pair by now;
-        // written to the remain files if still active after the last round = CHIBSJ / CHI2BSJ
-        if (a->report == 1) MAP_TRY(cm_write_pam(w_map, &cur, state.data(), nullptr, 0), "cm_write_pam");
-        if (a->report == 2) MAP_TRY(cm_write_sam(w_map, &cur, state.data(), nullptr, 0), "cm_write_sam");
-        sel.clear();
-        for (uint64_t i = 0; i < n; ++i)
-            if (active[i]) sel.push_back(i);
-        if (!sel.empty()) MAP_TRY(cm_write_remain(w_rem, &cur, state.data(), sel.data(), sel.size()), "cm_write_remain");
-        st.pairs += n;
-        st.bsj_pairs += sel.size();
+        R.state.resize(n);
+        R.active.resize(n);
+        MAP_TRY(cm_reads_download(cm, R.state.data(), nullptr, R.active.data()), "cm_reads_download");
+        R.sel.clear();
         for (uint64_t i = 0; i < n; ++i) {
-            const int t = state[i].type;
+            if (R.active[i]) R.sel.push_back(i);
+            const int t = R.state[i].type;
             if (t >= 0 && t < 14) ++st.by_type[t];
         }
+        st.pairs += n;
+        st.bsj_pairs += R.sel.size();
+        R.batch = cur;
+        if (writer.joinable()) writer.join();                    // rows of batch k-1 are out: file order = batch order
+        MAP_TRY(writer_rc, "writer");
+        // map_reads, src/circminer.cpp:386-397: printed if (skip || last round) = every pair by now;
+        // written to the remain files if still active after the last round = CHIBSJ / CHI2BSJ
+        writer = std::thread([&R, &writer_rc, w_map, w_rem, report = a->report]() {
+            int r = CM_OK;
+            if (report == 1) r = cm_write_pam(w_map, &R.batch, R.state.data(), nullptr, 0);
+            if (report == 2) r = cm_write_sam(w_map, &R.batch, R.state.data(), nullptr, 0);
+            if (r == CM_OK && !R.sel.empty()) r = cm_write_remain(w_rem, &R.batch, R.state.data(), R.sel.data(), R.sel.size());
+            writer_rc = r;
+        });
         cur = nxt;
     }
+    if (writer.joinable()) writer.join();
+    MAP_TRY(writer_rc, "writer");
     st.seconds_map = now() - t1;
     cleanup();
     if (stats) *stats = st;

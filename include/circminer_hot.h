@@ -295,8 +295,8 @@ void cm_host_close_index(cm_index_file *f);
 
 /* ---------------- FASTQ ingest, carry-over header, PAM / remain writers ---------- */
 /* One batch of parsed pairs in the layout cm_reads_upload takes.  All pointers belong to the parser and stay
- * valid until the SECOND next cm_fastq_next (two generations of storage alternate, so batch k+1 can be parsed while
- * batch k is on the GPU and batch k's records written afterwards) or cm_fastq_close.  names*: NUL-terminated read names (first header token,
+ * valid over the next TWO cm_fastq_next calls (three generations of storage take turns: batch k-1 can be with a writer
+ * thread and batch k on the GPU while batch k+1 is parsed) or until cm_fastq_close.  names*: NUL-terminated read names (first header token,
  * trailing "/x" cut: FASTQParser::extract_map_info, src/fastq_parser.cpp:178-198), name i at names + name_off[i].
  * prior: the MatchedRead each pair carried in its 23-token header (fill_map_info, :200-269) or NULL when no
  * pair of the batch carried one (fresh reads: cm_reads_upload's default state). */
@@ -348,7 +348,7 @@ typedef struct cm_mapping_args {
     cm_params params;
     int32_t report;                /* reportMapping: 0 none, 1 PAM, 2 SAM */
     int32_t n_threads;             /* host threads for the index loader   */
-    uint64_t batch_pairs;          /* pairs per resident batch, 0 = 2^20  */
+    uint64_t batch_pairs;          /* pairs per resident batch, 0 = 2^18  */
 } cm_mapping_args;
 typedef struct cm_mapping_stats {
     uint64_t pairs, bsj_pairs;

@@ -297,6 +297,11 @@ PRESETS = {
     "small": ([2_000_000, 1_500_000, 1_000_000], 25.0, 1_100_000_000, 120),
     "chr21": ([46_700_000], 5.5, 1_100_000_000, 2000),         # BASELINE.json configs[1]
     # one full-size packed contig (hg38 chr1-5 lengths, 1.06 Gbp): the scale of one round of configs[2..4]
+    # hg38 primary chromosome lengths (1-22, X, Y; 3.09 Gbp) -> three packed contigs of <= 1.1 Gbp = three rounds: the layout of
+    # BASELINE.json configs[2..4].  ~25 GB of index + genome in HBM, ~40 GB of host memory while one contig's index is built.
+    "hg38like": ([248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+                  135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+                  50818468, 156040895, 57227415], 5.5, 1_100_000_000, 100000),
     "contig1g": ([248_000_000, 242_000_000, 198_000_000, 190_000_000, 181_000_000], 5.5, 1_100_000_000, 40000),
 }
 

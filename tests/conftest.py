@@ -30,6 +30,10 @@ def built():
 
 @pytest.fixture(scope="session")
 def emu(built):
+    return load_emu()
+
+
+def load_emu():
     """Host emulation of the kernel bodies (tests/hostemu.cpp) — test infrastructure only."""
     out_dir = os.path.join(ROOT, "tests", "_hostemu")
     os.makedirs(out_dir, exist_ok=True)

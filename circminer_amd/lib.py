@@ -29,6 +29,12 @@ class Params(C.Structure):
                                          "max_tlen", "max_intron", "max_chain_len", "device", "reserved")]
 
 
+class CircRes(C.Structure):
+    _fields_ = [("chr", C.c_char_p), ("rname", C.c_char_p), ("spos", C.c_uint32), ("epos", C.c_uint32), ("type", C.c_int32),
+                ("reserved", C.c_int32), ("start_signal", C.c_char_p), ("end_signal", C.c_char_p), ("start_bp_ref", C.c_char_p),
+                ("end_bp_ref", C.c_char_p)]
+
+
 class MappingArgs(C.Structure):
     _fields_ = [("index_path", C.c_char_p), ("index_info_path", C.c_char_p), ("gtf_path", C.c_char_p), ("fastq1", C.c_char_p),
                 ("fastq2", C.c_char_p), ("out_prefix", C.c_char_p), ("params", Params), ("report", C.c_int32), ("n_threads", C.c_int32),
@@ -190,6 +196,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_sort_remain": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "cm_circ_report": (C.c_int, [pp(CircRes), C.c_uint64, C.c_char_p]),
         "cm_mapping_run": (C.c_int, [pp(MappingArgs), pp(MappingStats), C.c_char_p, C.c_uint64]),
         "cm_write_sam_header": (C.c_int, [vp]),
         "cm_write_sam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
@@ -210,7 +218,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report"]
 
 
 class HostIndex:
@@ -346,6 +354,27 @@ class ParsedBatch:
     def qual(self, i: int, mate: int = 1) -> bytes:
         q, o = (self.fb.qual1, self.c.off1) if mate == 1 else (self.fb.qual2, self.c.off2)
         return bytes(np.ctypeslib.as_array(q, (int(o[self.n]),))[int(o[i]):int(o[i + 1])])
+
+
+def sort_remain(path: str, out: str = None) -> str:
+    """<remain>.fastq -> <remain>.fastq.srt, ordered as ProcessCirc::sort_fq's GNU sort pipeline orders it (C locale)."""
+    out = out or path + ".srt"
+    rc = load().cm_sort_remain(path.encode(), out.encode())
+    if rc != 0:
+        raise RuntimeError(f"cm_sort_remain failed ({rc})")
+    return out
+
+
+def circ_report(calls, path: str):
+    """calls: iterable of (chr, rname, spos, epos, type, start_signal, end_signal, start_bp_ref, end_bp_ref) -> .circ_report"""
+    calls = list(calls)
+    keep = [[x.encode() if isinstance(x, str) else x for x in c] for c in calls]
+    arr = (CircRes * max(len(keep), 1))()
+    for i, c in enumerate(keep):
+        arr[i] = CircRes(c[0], c[1], c[2], c[3], c[4], 0, c[5], c[6], c[7], c[8])
+    rc = load().cm_circ_report(arr, len(keep), path.encode())
+    if rc != 0:
+        raise RuntimeError(f"cm_circ_report failed ({rc})")
 
 
 def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report=1, n_threads=4, batch_pairs=0, index_info=None):

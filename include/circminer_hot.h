@@ -358,6 +358,21 @@ typedef struct cm_mapping_stats {
 } cm_mapping_stats;
 int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *err, uint64_t err_cap);
 
+/* ---------------- stage 2, first and last step (SURVEY.md §8(f) N3 -- the BSJ calling in between is not built) -------- */
+/* ProcessCirc::sort_fq (src/process_circ.cpp:179-193): the remain FASTQ of the last round ordered like
+ * `paste - - - - | sort -k2,2n | tr "\t" "\n"` does in the C locale (key = genome_spos, ties by the whole pasted line). */
+int cm_sort_remain(const char *in_path, const char *out_path);
+/* ProcessCirc::report_events (src/process_circ.cpp:1570-1631): the BSJ calls of stage 2 (CircRes, src/common.h:406-423;
+ * type 20 = CR, 21 = NCR, 22 = MCR, src/process_circ.h:16-18) -> <out>.circ_report rows
+ * chr, start, end, read count, "STC", consensus start-end signal, reference start-end signal, Pass|Fail, read names. */
+typedef struct cm_circ_res {
+    const char *chr, *rname;
+    uint32_t spos, epos;
+    int32_t type, reserved;
+    const char *start_signal, *end_signal, *start_bp_ref, *end_bp_ref;
+} cm_circ_res;
+int cm_circ_report(const cm_circ_res *res, uint64_t n, const char *report_path);
+
 #ifdef __cplusplus
 }
 #endif

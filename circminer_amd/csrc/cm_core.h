@@ -137,10 +137,10 @@ constexpr int DPTINF = 10000000;           // src/align.cpp:12
 constexpr int SC_MAT = 1, SC_MIS = -3, SC_IND = -3, SC_XD = 8;   // score_mat.init(1,-3,-3,8), src/circminer.cpp:74
 constexpr int MAX_SEEDS = CM_MAX_CHAIN_FRAGS;   // seeds per read the device path supports
 constexpr int MAX_BAND = 8;                 // bandWidth supported by the private DP rows
-constexpr int MAX_TID = 64;                 // |common_tid| supported per mate pair
+constexpr int MAX_TID = 64;                 // |common_tid| kept in registers / scratch per mate pair (larger sets: TidList)
 constexpr int MEMO_N = 8;                   // memoised exon alignments per extend call
 
-enum { ERR_POOL = 1, ERR_TID = 2, ERR_SEEDS = 4, ERR_BAND = 8 };
+enum { ERR_POOL = 1, ERR_SEEDS = 4, ERR_BAND = 8 };
 
 struct KCore {          // what the host passes as a kernel argument (plain pointers to device memory)
     cm_params P;
@@ -1381,9 +1381,11 @@ CM_HD inline bool share_gene(const Core &c, int a, int b) {
             if (A.seg[iv_segid(A, a, i)].gene_id == A.seg[iv_segid(A, b, j)].gene_id) return true;
     return false;
 }
-// same_transcript + intersect_trans, utils.cpp:322-354; returns count (order of the first list)
-CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, g_err err) {
-    if (s < 0 || r < 0) return 0;
+// same_transcript + intersect_trans, utils.cpp:322-354: the transcripts of interval s's segments (in that order) that also
+// occur in interval r.  f(tid) is called for the elements with index >= skip; returns false as soon as f does.
+template <class F>
+CM_HD inline bool common_tids_from(const Core &c, int s, int r, int skip, F &&f) {
+    if (s < 0 || r < 0) return true;
     const AnnotV &A = c.A;
     int n = 0;
     const uint32_t ns = iv_nseg(A, s), nr = iv_nseg(A, r);
@@ -1397,13 +1399,33 @@ CM_HD inline int common_tids(const Core &c, int s, int r, uint32_t *out, g_err e
                 for (uint32_t l = A.seg[h].tid_off; l < A.seg[h].tid_off + A.seg[h].ntid; ++l)
                     if (A.seg_tid[l] == t1) { found = true; break; }
             }
-            if (found) {
-                if (n < MAX_TID) out[n++] = t1;
-                else flag_err(err, ERR_TID);
-            }
+            if (found && n++ >= skip && !f(t1)) return false;
         }
     }
-    return n;
+    return true;
+}
+CM_HD inline bool any_common_tid(const Core &c, int s, int r) {
+    return !common_tids_from(c, s, r, 0, [](uint32_t) { return false; });
+}
+// The common transcripts of one mate pair as the extension consumes them: the first MAX_TID are kept in `t`; when the
+// intersection is larger (`more`), the rest is derived again from the two intervals, in the same order, each time it is
+// walked -- genes with hundreds of isoforms cost time, not an error.
+struct TidList {
+    const uint32_t *t;
+    int n, s, r;
+    bool more;
+};
+CM_HD inline TidList common_tids(const Core &c, int s, int r, uint32_t *out) {
+    TidList tl{out, 0, s, r, false};
+    common_tids_from(c, s, r, 0, [&](uint32_t t1) {
+        if (tl.n < MAX_TID) {
+            out[tl.n++] = t1;
+            return true;
+        }
+        tl.more = true;
+        return false;
+    });
+    return tl;
 }
 
 CM_HD inline bool concordant_explanation(const Core &c, const MM &sm, const MM &lm, cm_mapped_read &mr, int row, bool r1_sm, int pair_type) {
@@ -1715,7 +1737,7 @@ struct Ext {
     }
 
     // extend_right / extend_left, src/extend.cpp:285-432; q = the residual (len chars)
-    CM_HD bool extend_side(const uint32_t *tids, int n_tid, const SV &q, uint32_t &pos, int len, int ed_th, uint32_t bound, AlignRes &best,
+    CM_HD bool extend_side(const TidList &tl, const SV &q, uint32_t &pos, int len, int ed_th, uint32_t bound, AlignRes &best,
                            bool right) const {
         CM_STAT(3, 1);
         const int seq_len = len, ref_len = len + c.P.band;
@@ -1726,12 +1748,15 @@ struct Ext {
         memo.n = 0;
         int it_ind = -1, it_seg = -1;
         CM_TICK(sm, 22);
-        if (n_tid > 0) it_seg = overlap_ind(c, pos, it_ind);
+        if (tl.n > 0) it_seg = overlap_ind(c, pos, it_ind);
         CM_TICK(sm, 23);
-        for (int i = 0; i < n_tid; ++i) {
-            if (right) right_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
-            else left_trans(tids[i], pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
-        }
+        auto along = [&](uint32_t tid) {
+            if (right) right_trans(tid, pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+            else left_trans(tid, pos, it_seg, it_ind, ref_len, q, seq_len, ed_th, bound, best, consecutive, memo);
+            return true;
+        };
+        for (int i = 0; i < tl.n; ++i) along(tl.t[i]);
+        if (tl.more) common_tids_from(c, tl.s, tl.r, MAX_TID, along);
         int min_ed = best.ed, sclen_best = best.sclen;
         CM_TICK(sm, 11);
         if (min_ed <= ed_th) {
@@ -1766,12 +1791,12 @@ struct Ext {
         return (best.qcovlen >= seq_len && best.ed <= ed_th);
     }
 
-    CM_HD bool chain_right(const uint32_t *tids, int n_tid, const CH &ch, const SV &seq, int seq_len, uint32_t ub, MM &mr, int &err) const {
+    CM_HD bool chain_right(const TidList &tl, const CH &ch, const SV &seq, int seq_len, uint32_t ub, MM &mr, int &err) const {
         uint32_t rm_pos = ch.rend_excl() - 1;
         int remain_end = seq_len - ch.qend_excl();
         bool right_ok = (remain_end <= 0);
         AlignRes best = ar_init(ub);
-        if (remain_end > 0) right_ok = extend_side(tids, n_tid, seq.sub(seq_len - remain_end), rm_pos, remain_end, c.P.max_ed - err, ub, best, true);
+        if (remain_end > 0) right_ok = extend_side(tl, seq.sub(seq_len - remain_end), rm_pos, remain_end, c.P.max_ed - err, ub, best, true);
         const int sclen_right = best.sclen, err_right = best.ed;
         remain_end -= best.qcovlen;
         mr.epos = rm_pos;
@@ -1782,12 +1807,12 @@ struct Ext {
         err += err_right;
         return right_ok;
     }
-    CM_HD bool chain_left(const uint32_t *tids, int n_tid, const CH &ch, const SV &seq, int32_t qspos, uint32_t lb, MM &mr, int &err) const {
+    CM_HD bool chain_left(const TidList &tl, const CH &ch, const SV &seq, int32_t qspos, uint32_t lb, MM &mr, int &err) const {
         uint32_t lm_pos = ch.rpos(0);
         int remain_beg = ch.qpos(0) - qspos;
         bool left_ok = (remain_beg <= 0);
         AlignRes best = ar_init(lb);
-        if (remain_beg > 0) left_ok = extend_side(tids, n_tid, seq, lm_pos, remain_beg, c.P.max_ed - err, lb, best, false);
+        if (remain_beg > 0) left_ok = extend_side(tl, seq, lm_pos, remain_beg, c.P.max_ed - err, lb, best, false);
         const int sclen_left = best.sclen, err_left = best.ed;
         remain_beg -= best.qcovlen;
         mr.spos = lm_pos;
@@ -1821,7 +1846,7 @@ struct Ext {
         }
         return mid;
     }
-    CM_HD bool both_mates(const CH &lch, const CH &rch, const uint32_t *tids, int n_tid, const Read &lr, const Read &rr, MM &lmm, MM &rmm) const {
+    CM_HD bool both_mates(const CH &lch, const CH &rch, const TidList &tl, const Read &lr, const Read &rr, MM &lmm, MM &rmm) const {
         const int maxEd = c.P.max_ed;
         const SV lseq = lr.view(), rseq = rr.view();
         CM_TICK(sm, 3);
@@ -1839,19 +1864,19 @@ struct Ext {
         lmm.matched_len = (uint32_t)lr.len;
         lmm.qspos = 1;
         lmm.qepos = (uint32_t)lr.len;
-        const bool llok = chain_left(tids, n_tid, lch, lseq, 0, MINLB, lmm, lerr);
+        const bool llok = chain_left(tl, lch, lseq, 0, MINLB, lmm, lerr);
         CM_DBG_STOP(3, false);
         CM_TICK(sm, 5);
         rmm.matched_len = (uint32_t)rr.len;
         rmm.qspos = 1;
         rmm.qepos = (uint32_t)rr.len;
-        const bool rlok = chain_left(tids, n_tid, rch, rseq, 0, lmm.spos, rmm, rerr);
+        const bool rlok = chain_left(tl, rch, rseq, 0, lmm.spos, rmm, rerr);
         CM_DBG_STOP(4, false);
         CM_TICK(sm, 6);
-        const bool rrok = chain_right(tids, n_tid, rch, rseq, rr.len, MAXUB, rmm, rerr);
+        const bool rrok = chain_right(tl, rch, rseq, rr.len, MAXUB, rmm, rerr);
         CM_DBG_STOP(5, false);
         CM_TICK(sm, 7);
-        const bool lrok = chain_right(tids, n_tid, lch, lseq, lr.len, rmm.epos, lmm, lerr);
+        const bool lrok = chain_right(tl, lch, lseq, lr.len, rmm.epos, lmm, lerr);
         CM_DBG_STOP(6, false);
         CM_TICK(sm, 8);
         update_match_mate_info(c, llok, lrok, lerr, lmm);
@@ -1873,14 +1898,14 @@ struct Ext {
         int remain_beg = ch.qpos(0);
         bool left_ok = (remain_beg <= 0);
         AlignRes bl = ar_init(MINLB);
-        if (remain_beg > 0) left_ok = extend_side(nullptr, 0, seq, lm_pos, remain_beg, maxEd - mr.middle_ed, MINLB, bl, false);
+        if (remain_beg > 0) left_ok = extend_side(TidList{nullptr, 0, -1, -1, false}, seq, lm_pos, remain_beg, maxEd - mr.middle_ed, MINLB, bl, false);
         const int err_left = bl.ed, sclen_left = bl.sclen;
         remain_beg -= bl.qcovlen;
         uint32_t rm_pos = ch.rend_excl() - 1;
         int remain_end = seq_len - ch.qend_excl();
         bool right_ok = (remain_end <= 0);
         AlignRes br = ar_init(MAXUB);
-        if (remain_end > 0) right_ok = extend_side(nullptr, 0, seq.sub(seq_len - remain_end), rm_pos, remain_end, maxEd - mr.middle_ed - err_left, MAXUB, br, true);
+        if (remain_end > 0) right_ok = extend_side(TidList{nullptr, 0, -1, -1, false}, seq.sub(seq_len - remain_end), rm_pos, remain_end, maxEd - mr.middle_ed - err_left, MAXUB, br, true);
         const int err_right = br.ed, sclen_right = br.sclen;
         remain_end -= br.qcovlen;
         mr.spos = lm_pos;
@@ -1915,7 +1940,7 @@ struct ChainSet {          // chains of one (mate, orientation)
 //   extend_task : decide the left mate, extend both mates, look up the exon intervals of the ends;
 //   fold_task   : apply the outcome to the pair's MatchedRead — must be applied in (i, j) order;
 //                 returns true where the reference returns CONCRD from inside the loop.
-CM_HD inline void extend_task(const Core &c, const Ext &ext, const CH &F, const CH &R, const uint32_t *tids, int n_tid, const Read &frd,
+CM_HD inline void extend_task(const Core &c, const Ext &ext, const CH &F, const CH &R, const TidList &tl, const Read &frd,
                               const Read &brd, MM &r1, MM &r2, bool &is_left, bool &ok, int &row) {
     r1 = mm_init(c);
     r2 = mm_init(c);
@@ -1924,7 +1949,7 @@ CM_HD inline void extend_task(const Core &c, const Ext &ext, const CH &F, const 
     row = 0;
     is_left = is_left_chain(F, R, frd.len);
     // one call site (see process_read): left mate first, whichever read it is
-    ok = ext.both_mates(is_left ? F : R, is_left ? R : F, tids, n_tid, is_left ? frd : brd, is_left ? brd : frd, is_left ? r1 : r2, is_left ? r2 : r1);
+    ok = ext.both_mates(is_left ? F : R, is_left ? R : F, tl, is_left ? frd : brd, is_left ? brd : frd, is_left ? r1 : r2, is_left ? r2 : r1);
     if (ok) {
         row = chr_row(c, is_left ? r1.spos : r2.spos);
         overlap_to_epos(c, r1); overlap_to_spos(c, r1);
@@ -1950,11 +1975,11 @@ CM_HD inline bool fold_task(const Core &c, const MM &r1, const MM &r2, bool is_l
     return false;
 }
 // the pairing predicate of pair_chains for one (i, j): 0 = not paired, else pair type + 1
-CM_HD inline uint32_t pair_code(const Core &c, const CHEnds &F, const CHEnds &R, int fe_i, int re_j, int saved_type, uint32_t *tids, g_err err) {
+CM_HD inline uint32_t pair_code(const Core &c, const CHEnds &F, const CHEnds &R, int fe_i, int re_j, int saved_type) {
     const uint32_t fs = F.r0, rs = R.r0, fe_ = F.rend, re_ = R.rend;
     const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
     bool same_tr = false, same_gen = false;
-    if (fe_i >= 0 && re_j >= 0) same_tr = common_tids(c, fe_i, re_j, tids, err) > 0;
+    if (fe_i >= 0 && re_j >= 0) same_tr = any_common_tid(c, fe_i, re_j);
     if (!same_tr && fe_i >= 0 && ((c.P.scan_level == 0 && saved_type > CM_CONGEN) || (c.P.scan_level > 0 && saved_type >= CM_CONGEN)))
         same_gen = same_gene_span(c, fe_i, rs, re_);
     if (!same_gen && re_j >= 0 && saved_type >= CM_CONGEN) same_gen = same_gene_span(c, re_j, fs, fe_);
@@ -2002,7 +2027,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     for (int i = 0; i < fwd.n; ++i)
         for (int j = 0; j < bwd.n; ++j) {
             const CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-            const uint32_t code = pair_code(c, F, R, fe[i], re[j], saved_type, tids, err);
+            const uint32_t code = pair_code(c, F, R, fe[i], re[j], saved_type);
             if (code) {
                 const int idx = i * CM_BESTCHAINLIM + j;
                 ptype[idx >> 4] |= code << ((idx & 15) * 2);
@@ -2020,7 +2045,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             const uint32_t code = (ptype[idx >> 4] >> ((idx & 15) * 2)) & 3u;
             if (code == 0) continue;
             const int pair_type = (int)code - 1;
-            const int n_tid = (code == 1) ? common_tids(c, fe[i], re[j], tids, err) : 0;
+            const TidList tl = (code == 1) ? common_tids(c, fe[i], re[j], tids) : TidList{tids, 0, -1, -1, false};
             // (when same_tr is false the reference's common_tid is empty: same_transcript clears it)
             CM_STAT(0, 1);
             MM r1, r2;
@@ -2028,7 +2053,7 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
             int row;
             const CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
             CM_TICK(sm, 2);
-            extend_task(c, ext, F, R, tids, n_tid, frd, brd, r1, r2, is_left, ok, row);
+            extend_task(c, ext, F, R, tl, frd, brd, r1, r2, is_left, ok, row);
             CM_TICK(sm, 9);
             if (fold_task(c, r1, r2, is_left, ok, row, pair_type, r1_forward, mr)) return CM_CONCRD;
             CM_TICK(sm, 10);

@@ -772,7 +772,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     for (int idx = lane; idx < T; idx += 64) {
         const int i = idx / bwd.n, j = idx - i * bwd.n;
         const cmc::CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-        const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type, tids, err);
+        const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type);
         H.codes[idx] = (uint8_t)code;
         if (code) {
             fp |= 1u << i;
@@ -801,12 +801,12 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
             const int idx = H.list[x];
             const int i = idx / bwd.n, j = idx - i * bwd.n;
             const uint32_t code = H.codes[idx];
-            const int n_tid = (code == 1) ? cmc::common_tids(c, H.fe[i], H.re[j], tids, err) : 0;
+            const cmc::TidList tl = (code == 1) ? cmc::common_tids(c, H.fe[i], H.re[j], tids) : cmc::TidList{tids, 0, -1, -1, false};
             const cmc::CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
             cmc::MM r1, r2;
             bool il, ok;
             int row;
-            cmc::extend_task(c, ext, F, R, tids, n_tid, frd, brd, r1, r2, il, ok, row);
+            cmc::extend_task(c, ext, F, R, tl, frd, brd, r1, r2, il, ok, row);
             H.res[lane].r1 = r1;
             H.res[lane].r2 = r2;
             H.res[lane].row = row;
@@ -1283,8 +1283,8 @@ int check_dev_err(cm_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int e = *(const int *)ctx->h_pin;
     if (e) {
-        return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
-                    (e & cmc::ERR_TID) ? " more than 64 common transcripts for one mate pair;" : "", (e & ~3) ? " DP string longer than the staging buffer" : "");
+        return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
+                    (e & ~3) ? " DP string longer than the staging buffer" : "");
     }
     return CM_OK;
 }

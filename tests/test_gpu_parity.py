@@ -400,3 +400,10 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
         cl.run_mapping(idx, gtf, fq[0], fq[1], out, cl.default_params(kmer=18))
     with pytest.raises(RuntimeError):
         cl.run_mapping(idx + ".nope", gtf, fq[0], fq[1], out, P)
+
+
+def test_genes_with_more_than_64_isoforms(ds_tiny, tmp_path):
+    """|common_tid| > 64 (cmc::TidList's overflow walk) on the device, light and heavy pair kernels alike."""
+    from test_hostemu_parity import _many_isoforms
+    sh = _many_isoforms(ds_tiny, tmp_path, 45)
+    _run_all_rounds(sh, cl.default_params())

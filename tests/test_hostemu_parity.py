@@ -182,3 +182,45 @@ def test_skipped_leftover_extensions_are_dead_work(emu):
         for a, b, g1, g2 in itertools.product(f1, f2, (0, 1), (0, 1)):
             assert emu.emu_leftover_type(a, b, g1, g2) >= T, (T, m1, m2, can1, can2, a, b, g1, g2)
     assert skipped > 100
+
+
+def _many_isoforms(ds, tmp_path, copies):
+    """the data set's annotation with every transcript repeated `copies` times (new transcript ids, same exons)"""
+    from conftest import _Shim
+    out, block = [], []
+
+    def flush():
+        if block:
+            for c in range(copies):
+                out.extend(ln.replace('transcript_id "T', f'transcript_id "c{c}T') for ln in block)
+            block.clear()
+
+    for ln in ds.d.gtf_text.splitlines(keepends=True):
+        kind = ln.split("\t")[2]
+        if kind == "exon":
+            block.append(ln)
+            continue
+        flush()
+        if kind == "transcript":
+            block.append(ln)
+        else:
+            out.append(ln)
+    flush()
+    gtf = str(tmp_path / "iso.gtf")
+    open(gtf, "w").write("".join(out))
+    hi = cl.HostIndex(ds.d.contigs, ds.d.chr_table, gtf, kmer=ds.kmer)
+    sh = _Shim(ds, ds.batch)
+    sh.hi = hi
+    return sh
+
+
+def test_more_than_64_common_transcripts(emu, ds_tiny, tmp_path):
+    """Genes with hundreds of isoforms (Ensembl has them): |common_tid| of a mate pair exceeds the 64 entries the device
+    code keeps per lane; the rest is re-derived from the two intervals in the same order, so results equal the oracle's
+    unbounded vector (reference src/utils.cpp:322-354)."""
+    sh = _many_isoforms(ds_tiny, tmp_path, 45)
+    av = sh.hi.annots[0]
+    ntid = np.diff(np.ctypeslib.as_array(av.seg_tid_off, shape=(av.n_seg + 1,)).astype(np.int64))
+    assert ntid.max() > 2 * 64 and av.n_trans == 45 * ds_tiny.hi.annots[0].n_trans
+    _emu_rounds(emu, sh, cl.default_params())
+    _emu_rounds(emu, sh, cl.default_params(scan_level=2, max_ed=6))

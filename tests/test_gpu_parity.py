@@ -1,4 +1,6 @@
 """GPU parity tests proper: HIP path through the C-ABI vs the CPU oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -395,6 +397,18 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
         for k, i in enumerate(keep):
             assert lines[4 * k] == py_remain_header(names[i], want[i], chrs)
             assert lines[4 * k + 1:4 * k + 4] == [seqs[i], "+", quals[i % 16]]
+    # the same run from plain C++ (examples/cm_map.cpp: no Python, no torch in the process): identical files
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cm_map")
+    libdir = os.path.join(root, "circminer_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "cm_map.cpp"), "-L", libdir,
+                           "-lcmhot", f"-Wl,-rpath,{libdir}", "-o", exe])
+    out2 = str(tmp_path / "run_cpp")
+    msg = subprocess.check_output([exe, idx, gtf, fq[0], fq[1], out2, "pam" if report == 1 else "sam"], text=True)
+    assert msg.startswith(f"{n} pairs, {hi.n_contigs} round(s), {int(act.sum())} BSJ")
+    for suffix in ([".mapping.pam"] if report == 1 else [".mapping.sam"]) + [f"_{hi.n_contigs}_remain_R{m}.fastq" for m in (1, 2)]:
+        assert open(out + suffix, "rb").read() == open(out2 + suffix, "rb").read(), suffix
     # bad input is an error message, not a crash
     with pytest.raises(RuntimeError, match="k = 20"):
         cl.run_mapping(idx, gtf, fq[0], fq[1], out, cl.default_params(kmer=18))

@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 cp $OUT/stats/st_kernel_stats.csv $OUT/${R}_kernel_stats.csv
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
@@ -20,5 +20,5 @@ echo "write done"
 cd $ROOT
 python3 profiles/make_traffic.py $OUT/fetch/pmc_counter_collection.csv $OUT/write/pmc_counter_collection.csv $OUT/traffic.json $OUT/${R}_pmc_fetch_size.csv $OUT/${R}_pmc_write_size.csv
 cp $OUT/traffic.json profiles/traffic.json
-python3 bench.py --steps 5 --warmup 1 > $OUT/${R}_bench_1gpu.json 2> $OUT/bench.err
+python3 bench.py > $OUT/${R}_bench_1gpu.json 2> $OUT/bench.err
 cat $OUT/${R}_bench_1gpu.json

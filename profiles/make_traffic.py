@@ -35,9 +35,7 @@ def main():
                   "launches": f.get(k, (0, 0))[1]} for k in sorted(set(f) | set(w)) if k.startswith("k_")}
     tot = lambda k: detail.get(k, {}).get("fetch_bytes_per_launch", 0) + detail.get(k, {}).get("write_bytes_per_launch", 0)
     js = {"workload": "chr21", "pairs": 1000000,
-          "note": "FETCH_SIZE/WRITE_SIZE (KB) x 1024 from two separate rocprofv3 --pmc passes, per launch (1M pairs, 1 round). "
-                  "MI355X_MICROARCH.md: FETCH_SIZE under-counts wide coalesced streams by 2x; this path is 4-16 B random gathers "
-                  "and scratch traffic, uncalibrated, reported as counted.  Stage entries sum the kernels of a stage.",
+          "note": "FETCH_SIZE/WRITE_SIZE (KB) x 1024 from two separate rocprofv3 --pmc passes, per launch (1M pairs, 1 round). MI355X_MICROARCH.md: FETCH_SIZE under-counts wide coalesced streams by 2x (128-B requests tallied at 64 B) and other access widths are uncalibrated.  Calibration for this path's pattern (4-16 B random gathers + scratch rows): TCC_MISS_sum x 64 B of a separate pass (profiles/r01_pmc_l2_summary.txt; k_seed 53.4 M misses = 3.4 GB vs 3.24 GB fetched + 0.34 GB written) agrees with the counters at face value, i.e. these are 64-B requests and no doubling applies.  Stage entries sum the kernels of a stage.",
           "bytes_per_launch": {"k_seed": tot("k_seed"), "k_chain": tot("k_chain") + tot("k_chain_heavy"),
                                "k_pair": tot("k_pair") + tot("k_pair_heavy")},
           "detail": detail}

@@ -30,7 +30,7 @@ td = tempfile.mkdtemp()
 for k in range(n_sets):
     seed = s0 + k
     rng = np.random.default_rng(seed)
-    preset = ["tiny", "tiny2r"][k % 2]
+    preset = os.environ.get("CM_FUZZ_PRESET") or ["tiny", "tiny2r"][k % 2]
     mix = [(0.70, 0.25, 0.05), (0.3, 0.2, 0.5), (0.1, 0.8, 0.1), (0.5, 0.0, 0.5)][int(rng.integers(0, 4))]
     kw = [dict(), dict(scan_level=1), dict(scan_level=2, max_ed=6), dict(band=2), dict(band=5, max_ed=6), dict(max_sc=3, max_tlen=300),
           dict(max_chain_len=5), dict(seed_lim=50), dict(max_intron=20000)][int(rng.integers(0, 9))]
@@ -38,6 +38,28 @@ for k in range(n_sets):
     t = time.time()
     ds = conftest.DataSet(td, preset, pairs, seed, mix=mix, read_len=read_len, fam_copies=int(rng.choice([6, 40, 400])))
     P = cl.default_params(**kw)
+    dirty = int(rng.integers(0, 3)) == 0
+    if dirty:            # ragged lengths, N runs, lower-case stretches, reads longer than the generator's (cf. conftest.ds_dirty)
+        s1, s2 = [], []
+        for arr, dst in ((ds.d.seq1, s1), (ds.d.seq2, s2)):
+            for i in range(arr.shape[0]):
+                r = arr[i].copy()
+                k = int(rng.integers(0, 14))
+                if k == 0:
+                    r = r[:int(rng.integers(0, 45))]
+                elif k == 1:
+                    r = r[:int(rng.integers(45, len(r) + 1))]
+                elif k == 2:
+                    a = int(rng.integers(0, len(r))); r[a:a + int(rng.integers(1, 25))] = ord("N")
+                elif k == 3:
+                    a = int(rng.integers(0, len(r))); r[a:a + 40] = np.frombuffer(bytes(r[a:a + 40]).lower(), np.uint8)
+                elif k == 4:
+                    r = np.concatenate([r, r[:int(rng.integers(1, 300 - len(r) + 1))]]) if len(r) < 300 else r
+                elif k == 5:
+                    r[int(rng.integers(0, len(r)))] = ord("acgtn"[int(rng.integers(0, 5))])
+                dst.append(r)
+        l1, l2 = np.array([len(x) for x in s1]), np.array([len(x) for x in s2])
+        ds.batch = cl.ReadBatch(np.concatenate(s1), np.concatenate(s2), l1, l2)
     st0, act0 = op.default_state(P, ds.batch.n)
     st1, act1 = st0.copy(), act0.copy()
     hp = None
@@ -60,7 +82,7 @@ for k in range(n_sets):
         if not ((cat0 == cat1).all() and (act0 == act1).all() and st0.tobytes() == st1.tobytes()):
             print("MISMATCH", seed, preset, mix, kw, read_len, "round", ci, conftest.first_diff(st0, st1), flush=True)
             sys.exit(1)
-    print(f"seed {seed} {preset} mix {mix} {kw} len {read_len}: ok, types {np.bincount(st0['type'], minlength=14).tolist()} ({time.time() - t:.0f}s)", flush=True)
+    print(f"seed {seed} {preset}{' dirty' if dirty else ''} mix {mix} {kw} len {read_len}: ok, types {np.bincount(st0['type'], minlength=14).tolist()} ({time.time() - t:.0f}s)", flush=True)
     if hp is not None:
         hp.close()
     ds.hi.close()

@@ -166,16 +166,27 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     // ---- batches: write k-1 (worker thread) | all rounds of k (device) | parse k+1 (this thread) ----
     const double t1 = now();
     cm_fastq_batch cur, nxt;
-    MAP_TRY(cm_fastq_next(fq, batch_pairs, &cur), "cm_fastq_next");
+    double write_s = 0.0;                                       // written by the writer thread, read after its join
+    {
+        const double tp = now();
+        MAP_TRY(cm_fastq_next(fq, batch_pairs, &cur), "cm_fastq_next");
+        st.seconds_parse += now() - tp;
+    }
     for (uint64_t k = 0; cur.reads.n_pairs; ++k) {
         const uint64_t n = cur.reads.n_pairs;
         Result &R = res[k & 1];
+        double td = now();
         MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_map_round(cm, (int)c, c + 1 == n_con), "cm_map_round");   // asynchronous
+        st.seconds_device += now() - td;
+        const double tp = now();
         MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");
+        st.seconds_parse += now() - tp;
         R.state.resize(n);
         R.active.resize(n);
+        td = now();
         MAP_TRY(cm_reads_download(cm, R.state.data(), nullptr, R.active.data()), "cm_reads_download");
+        st.seconds_device += now() - td;
         R.sel.clear();
         for (uint64_t i = 0; i < n; ++i) {
             if (R.active[i]) R.sel.push_back(i);
@@ -189,18 +200,21 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         MAP_TRY(writer_rc, "writer");
         // map_reads, src/circminer.cpp:386-397: printed if (skip || last round) = every pair by now;
         // written to the remain files if still active after the last round = CHIBSJ / CHI2BSJ
-        writer = std::thread([&R, &writer_rc, w_map, w_rem, report = a->report]() {
+        writer = std::thread([&R, &writer_rc, &write_s, w_map, w_rem, report = a->report]() {
+            const double tw = now();
             int r = CM_OK;
             if (report == 1) r = cm_write_pam(w_map, &R.batch, R.state.data(), nullptr, 0);
             if (report == 2) r = cm_write_sam(w_map, &R.batch, R.state.data(), nullptr, 0);
             if (r == CM_OK && !R.sel.empty()) r = cm_write_remain(w_rem, &R.batch, R.state.data(), R.sel.data(), R.sel.size());
             writer_rc = r;
+            write_s += now() - tw;
         });
         cur = nxt;
     }
     if (writer.joinable()) writer.join();
     MAP_TRY(writer_rc, "writer");
     st.seconds_map = now() - t1;
+    st.seconds_write = write_s;
     cleanup();
     if (stats) *stats = st;
     return CM_OK;

@@ -43,7 +43,8 @@ class MappingArgs(C.Structure):
 
 class MappingStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("bsj_pairs", C.c_uint64), ("by_type", C.c_uint64 * 14), ("rounds", C.c_int32),
-                ("reserved", C.c_int32), ("seconds_load", C.c_double), ("seconds_map", C.c_double)]
+                ("reserved", C.c_int32), ("seconds_load", C.c_double), ("seconds_map", C.c_double), ("seconds_parse", C.c_double),
+                ("seconds_device", C.c_double), ("seconds_write", C.c_double)]
 
 
 def default_params(**kw) -> Params:

@@ -44,7 +44,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "cm_mapping_run: %s\n", err);
         return 1;
     }
-    printf("%llu pairs, %d round(s), %llu BSJ candidate pairs; load %.2fs, map %.2fs (%.2f M pairs/s)\n", (unsigned long long)st.pairs, st.rounds,
-           (unsigned long long)st.bsj_pairs, st.seconds_load, st.seconds_map, st.seconds_map > 0 ? st.pairs / st.seconds_map / 1e6 : 0.0);
+    printf("%llu pairs, %d round(s), %llu BSJ candidate pairs; load %.2fs, map %.2fs (%.2f M pairs/s; parse %.2fs, device %.2fs, write %.2fs)\n",
+           (unsigned long long)st.pairs, st.rounds, (unsigned long long)st.bsj_pairs, st.seconds_load, st.seconds_map,
+           st.seconds_map > 0 ? st.pairs / st.seconds_map / 1e6 : 0.0, st.seconds_parse, st.seconds_device, st.seconds_write);
     return 0;
 }

@@ -355,6 +355,9 @@ typedef struct cm_mapping_stats {
     uint64_t by_type[14];          /* final MatchedRead::type histogram (CM_CONCRD ... ) */
     int32_t rounds, reserved;
     double seconds_load, seconds_map;
+    /* where seconds_map went, summed over the batches (the three overlap, so they add up to more than seconds_map):
+     * parsing FASTQ on the calling thread, waiting for the device (upload + rounds + download), writing rows */
+    double seconds_parse, seconds_device, seconds_write;
 } cm_mapping_stats;
 int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *err, uint64_t err_cap);
 

@@ -43,4 +43,5 @@ with tempfile.TemporaryDirectory() as td:
         wall = time.time() - t
         print(f"run {it}: wall {wall:.2f}s = load {st.seconds_load:.2f}s (index file + GTF -> HBM) + map {st.seconds_map:.2f}s "
               f"({st.pairs / st.seconds_map / 1e6:.2f} M pairs/s from FASTQ text to {'none PAM SAM'.split()[report]} rows); "
+              f"parse {st.seconds_parse:.2f}s, device {st.seconds_device:.2f}s, write {st.seconds_write:.2f}s (overlapped); "
               f"{st.bsj_pairs} BSJ pairs, types {list(st.by_type)}", flush=True)

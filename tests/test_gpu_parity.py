@@ -296,7 +296,7 @@ def test_one_context_many_batches(ds_tiny):
     hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
     n = ds_tiny.batch.n
     want = {}
-    for lo, hi_ in ((0, n // 2), (n // 2, n), (0, 0), (3, n // 4), (0, n)):
+    for lo, hi_ in ((0, n // 2), (n // 2, n), (0, 0), (3, n // 4), (5, 6), (0, 63), (1, 65), (100, 165), (0, n)):   # 1 pair; around a wave
         b = cl.ReadBatch(d.seq1[lo:hi_], d.seq2[lo:hi_]) if hi_ > lo else \
             cl.ReadBatch(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int64))
         hp.upload(b)

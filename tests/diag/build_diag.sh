@@ -5,7 +5,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="$ROOT/tests/_hostemu"; mkdir -p "$OUT"
-for f in cm_hot.hip host_index.cpp host_annot.cpp host_index_io.cpp host_fastq.cpp; do
+for f in cm_hot.hip host_index.cpp host_annot.cpp host_index_io.cpp host_fastq.cpp host_mapping.cpp host_circ.cpp; do
   /opt/rocm/bin/hipcc -c -O3 -std=c++17 -fPIC -ffp-contract=off ${DIAG_FLAGS--DCM_DIAG} --offload-arch=gfx950 -I"$ROOT/include" -I"$ROOT/circminer_amd/csrc" \
       "$ROOT/circminer_amd/csrc/$f" -o "$OUT/${DIAG_NAME-diag}_${f%.*}.o"
 done

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -55,6 +56,7 @@ struct ContigBuild {
     uint32_t n_gene = 0, n_trans = 0;
     std::vector<uint32_t> gene_start, gene_end;
     std::map<Seg, std::vector<uint32_t>> merged;  // merged_exons[con]: seg -> trans ids
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> merged_genes;   // (start, end) -> gene id of the first gene with that span
     std::vector<uint64_t> near, intr;
     bool has_gene = false;
 };
@@ -112,7 +114,10 @@ inline void set_bits(std::vector<uint64_t> &bs, uint64_t lo, uint64_t hi_incl, b
 }
 
 // FlatIntervalTree::handle_overlap, reference src/interval_tree_impl.h:40-95
-bool handle_overlap(std::vector<Interval> &iv, int &cur, uint32_t fresh_idx, const Seg &fresh) {
+struct Span {
+    uint32_t start, end;
+};
+bool handle_overlap(std::vector<Interval> &iv, int &cur, uint32_t fresh_idx, const Span &fresh) {
     if (iv[cur].spos < fresh.start) {
         uint32_t pre_epos = iv[cur].epos;
         iv[cur].epos = fresh.start - 1;
@@ -151,6 +156,28 @@ bool handle_overlap(std::vector<Interval> &iv, int &cur, uint32_t fresh_idx, con
     iv[cur].spos = fresh.end + 1;
     iv.insert(iv.begin() + cur, ov);
     return false;
+}
+
+// FlatIntervalTree::build, interval_tree_impl.h:98-127: spans in the order of the reference's std::map
+std::vector<Interval> build_intervals(const std::vector<Span> &spans) {
+    std::vector<Interval> iv;
+    size_t j = 0;
+    for (uint32_t si = 0; si < spans.size(); ++si) {
+        const Span &s = spans[si];
+        while (j < iv.size() && s.start > iv[j].epos) ++j;
+        if (j == iv.size()) {
+            iv.push_back(Interval{s.start, s.end, {si}});
+        } else {
+            int curi = (int)j;
+            bool rem = false;
+            while (curi < (int)iv.size()) {
+                rem = handle_overlap(iv, curi, si, s);
+                if (!rem) break;
+            }
+            if (curi == (int)iv.size() && rem) iv.push_back(Interval{iv[curi - 1].epos + 1, s.end, {si}});
+        }
+    }
+    return iv;
 }
 
 template <class T>
@@ -214,6 +241,9 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
             set_bits(B.intr, start, end, true);
             B.gene_start.push_back(start);
             B.gene_end.push_back(end);
+            // merged_genes, gene_annotation.cpp:243-256: GeneInfo orders by (start, end) only, so a second gene with the same
+            // span is folded into the first one's key (its id is not kept)
+            B.merged_genes.emplace(std::make_pair(start, end), B.n_gene - 1);
         }
         if (is_trans) ++B.n_trans;
 
@@ -272,24 +302,9 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
             segs.push_back(kv.first);
             seg_tids.push_back(kv.second);
         }
-        // FlatIntervalTree::build, interval_tree_impl.h:98-127
-        std::vector<Interval> iv;
-        size_t j = 0;
-        for (uint32_t si = 0; si < segs.size(); ++si) {
-            const Seg &s = segs[si];
-            while (j < iv.size() && s.start > iv[j].epos) ++j;
-            if (j == iv.size()) {
-                iv.push_back(Interval{s.start, s.end, {si}});
-            } else {
-                int curi = (int)j;
-                bool rem = false;
-                while (curi < (int)iv.size()) {
-                    rem = handle_overlap(iv, curi, si, s);
-                    if (!rem) break;
-                }
-                if (curi == (int)iv.size() && rem) iv.push_back(Interval{iv[curi - 1].epos + 1, s.end, {si}});
-            }
-        }
+        std::vector<Span> spans;
+        for (const Seg &g : segs) spans.push_back(Span{g.start, g.end});
+        std::vector<Interval> iv = build_intervals(spans);
         // build_trans2seg_table, interval_tree_impl.h:186-242
         const uint32_t nt = B.n_trans;
         std::vector<int32_t> starts(nt, 1000000000), ends(nt, 0);
@@ -349,8 +364,36 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
                 cshift.push_back(chrs[i].start_pos);
                 cid.push_back((int32_t)i);
             }
+        // genes_int_map (stage 2: get_gene_overlap): the same interval construction over the gene spans
+        std::vector<uint32_t> giv_spos, giv_epos, giv_off{0}, giv_gene;
+        {
+            std::vector<Span> gspans;
+            std::vector<uint32_t> gid;
+            for (auto &kv : B.merged_genes) {
+                gspans.push_back(Span{kv.first.first, kv.first.second});
+                gid.push_back(kv.second);
+            }
+            std::vector<Interval> giv = build_intervals(gspans);
+            for (auto &x : giv) {
+                giv_spos.push_back(x.spos);
+                giv_epos.push_back(x.epos);
+                for (uint32_t k : x.segs) giv_gene.push_back(gid[k]);
+                giv_off.push_back((uint32_t)giv_gene.size());
+            }
+            if (giv.empty()) {                     // add_dummy_interval(temp_gene), gene_annotation.cpp:371-378: {MAXUB, MAXUB, gene 0}
+                giv_spos.push_back(0xffffffffu);
+                giv_epos.push_back(0xffffffffu);
+                giv_gene.push_back(0);
+                giv_off.push_back(1);
+            }
+        }
         cm_annot_view &A = out[c];
         memset(&A, 0, sizeof(A));
+        A.n_giv = (uint32_t)giv_spos.size();
+        A.giv_spos = dup(giv_spos);
+        A.giv_epos = dup(giv_epos);
+        A.giv_gene_off = dup(giv_off);
+        A.giv_gene = dup(giv_gene);
         A.n_iv = (uint32_t)iv.size();
         A.iv_spos = dup(iv_spos);
         A.iv_epos = dup(iv_epos);
@@ -397,6 +440,24 @@ extern "C" int cm_host_build_annotation(const char *gtf_path, const cm_chr_info 
     return CM_OK;
 }
 
+// GTFParser::get_gene_overlap(loc, false) + FlatIntervalTree::find, gene_annotation.cpp:572-585, interval_tree_impl.h:136-162
+extern "C" int cm_host_gene_overlap(const cm_annot_view *av, uint32_t pos, const uint32_t **genes, uint32_t *n_genes) {
+    if (!av || !genes || !n_genes) return CM_EINVAL;
+    *genes = nullptr;
+    *n_genes = 0;
+    if (av->n_giv == 0 || pos < av->giv_spos[0]) return CM_OK;
+    uint32_t lo = 0, hi = av->n_giv;                 // number of intervals with spos <= pos
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (av->giv_spos[mid] <= pos) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0 || av->giv_epos[lo - 1] < pos) return CM_OK;
+    *genes = av->giv_gene + av->giv_gene_off[lo - 1];
+    *n_genes = av->giv_gene_off[lo] - av->giv_gene_off[lo - 1];
+    return CM_OK;
+}
+
 extern "C" void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs) {
     if (!av) return;
     for (uint32_t c = 0; c < n_contigs; ++c) {
@@ -404,7 +465,8 @@ extern "C" void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs) {
         const void *ptrs[] = {A.iv_spos, A.iv_epos, A.iv_max_end, A.iv_min_end, A.iv_max_next_exon, A.iv_seg_off,
                               A.iv_seg, A.seg_start, A.seg_end, A.seg_next_exon_beg, A.seg_gene_id, A.seg_tid_off,
                               A.seg_tid, A.trans_start_ind, A.t2s_off, A.t2s, A.gene_start, A.gene_end,
-                              A.near_border_bits, A.intronic_bits, A.chr_shift, A.chr_id, A.iv_bucket};
+                              A.near_border_bits, A.intronic_bits, A.chr_shift, A.chr_id, A.iv_bucket, A.giv_spos, A.giv_epos,
+                              A.giv_gene_off, A.giv_gene};
         for (const void *p : ptrs) free((void *)p);
         memset(&A, 0, sizeof(A));
     }

@@ -69,7 +69,8 @@ class AnnotView(C.Structure):
                 ("n_gene", C.c_uint32), ("gene_start", u32p), ("gene_end", u32p),
                 ("n_bits", C.c_uint64), ("near_border_bits", u64p), ("intronic_bits", u64p),
                 ("n_chr", C.c_uint32), ("chr_shift", u32p), ("chr_id", i32p),
-                ("iv_bucket", u32p), ("iv_bucket_shift", C.c_uint32), ("n_iv_bucket", C.c_uint32)]
+                ("iv_bucket", u32p), ("iv_bucket_shift", C.c_uint32), ("n_iv_bucket", C.c_uint32),
+                ("n_giv", C.c_uint32), ("giv_spos", u32p), ("giv_epos", u32p), ("giv_gene_off", u32p), ("giv_gene", u32p)]
 
 
 class MappedRead(C.Structure):
@@ -197,6 +198,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_host_gene_overlap": (C.c_int, [pp(AnnotView), C.c_uint32, pp(u32p), pp(C.c_uint32)]),
         "cm_sort_remain": (C.c_int, [C.c_char_p, C.c_char_p]),
         "cm_circ_report": (C.c_int, [pp(CircRes), C.c_uint64, C.c_char_p]),
         "cm_mapping_run": (C.c_int, [pp(MappingArgs), pp(MappingStats), C.c_char_p, C.c_uint64]),
@@ -219,7 +221,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_host_gene_overlap"]
 
 
 class HostIndex:

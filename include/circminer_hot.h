@@ -119,6 +119,12 @@ typedef struct cm_annot_view {
      * extra bucket).  NULL = plain binary search.  Results are identical either way. */
     const uint32_t *iv_bucket;
     uint32_t iv_bucket_shift, n_iv_bucket;
+    /* genes_int_map (stage 2 only, never uploaded: GTFParser::get_gene_overlap, src/gene_annotation.cpp:572-585): disjoint
+     * intervals over the gene spans; interval i is covered by the genes giv_gene[giv_gene_off[i] .. giv_gene_off[i+1]) in the
+     * reference's seg_list order (indices into gene_start / gene_end; genes with identical spans are represented by the
+     * first of them, as in the reference's map keyed by (start, end)) */
+    uint32_t n_giv;
+    const uint32_t *giv_spos, *giv_epos, *giv_gene_off, *giv_gene;
 } cm_annot_view;
 
 /* ---- POD mirror of MatchedRead (src/common.h:311-352); carried between rounds through the
@@ -267,6 +273,8 @@ int cm_host_build_annotation(const char *gtf_path, const cm_chr_info *chrs, uint
                              const uint32_t *contig_len, uint32_t n_contigs, int32_t max_read_len,
                              cm_annot_view *out);
 void cm_host_free_annotation(cm_annot_view *av, uint32_t n_contigs);
+/* get_gene_overlap(pos, use_mask = false): the genes whose span covers contig position pos (n_genes = 0: none) */
+int cm_host_gene_overlap(const cm_annot_view *av, uint32_t pos, const uint32_t **genes, uint32_t *n_genes);
 
 /* ---------------- on-disk genome / index formats of stock CircMiner ------ */
 /* FASTA -> <ref>.packed.fa + <ref>.packed.fa.index.info (GenomePacker::pack_genome,

@@ -190,3 +190,57 @@ def test_gtf_line_handling(ds_tiny2r, tmp_path):
         a, b = _annot_bytes(ds_tiny2r.hi.annots[con]), _annot_bytes(hi.annots[con])
         for k in a:
             assert a[k] == b[k], (con, k)
+
+
+def test_gene_interval_table_and_overlap_query(ds_tiny2r, tmp_path):
+    """genes_int_map of stage 2 (GTFParser::get_gene_overlap, src/gene_annotation.cpp:243-256,362-365,572-585): the interval
+    construction over the gene spans, genes with identical spans folded into the first, and the point query.  The synthetic
+    genes rarely overlap, so a second annotation with nested, overlapping, duplicated and abutting genes is built as well."""
+    L = cl.load()
+
+    def check(av, genes):                     # genes: [(start, end)] in file order, contig coordinates
+        first = {}
+        for gid, (a, b) in enumerate(genes):
+            first.setdefault((a, b), gid)
+        keys = sorted(first)
+        iv = _ref_intervals([(a, b) for a, b in keys])
+        assert av.n_giv == len(iv)
+        assert (_np(av.giv_spos, av.n_giv, np.int64) == [x[0] for x in iv]).all()
+        assert (_np(av.giv_epos, av.n_giv, np.int64) == [x[1] for x in iv]).all()
+        off = _np(av.giv_gene_off, av.n_giv + 1, np.int64)
+        flat = _np(av.giv_gene, off[-1], np.int64)
+        assert list(flat) == [first[keys[s]] for x in iv for s in x[2]]
+        # point query against brute force over the kept genes
+        rng = np.random.default_rng(1)
+        pts = set(int(p) for p in rng.integers(0, max(b for _a, b in genes) + 50, 400))
+        for a, b in genes:
+            pts.update((a - 1, a, b, b + 1))
+        for p in sorted(x for x in pts if x >= 0):
+            g, n = cl.u32p(), C.c_uint32(0)
+            assert L.cm_host_gene_overlap(C.byref(av), p, C.byref(g), C.byref(n)) == 0
+            got = sorted(g[i] for i in range(n.value))
+            want = sorted(first[k] for k in keys if k[0] <= p <= k[1])
+            assert got == want, (p, got, want)
+
+    d = ds_tiny2r.d
+    shift = {name: (cid - 1, st) for name, cid, st, _ in d.chr_table}
+    for con in range(ds_tiny2r.hi.n_contigs):
+        genes = [(g.start + shift[d.chr_names[g.chrom]][1], g.end + shift[d.chr_names[g.chrom]][1]) for g in d.genes
+                 if shift[d.chr_names[g.chrom]][0] == con]
+        check(ds_tiny2r.hi.annots[con], genes)
+    spans = [(100, 900), (100, 900), (300, 500), (450, 1200), (901, 950), (1200, 1300), (2000, 2100), (2050, 2060), (2050, 2060), (3000, 3000)]
+    gtf = tmp_path / "genes.gtf"
+    with open(gtf, "w") as f:
+        for i, (a, b) in enumerate(spans):
+            f.write(f'chrA\tx\tgene\t{a}\t{b}\t.\t+\t.\tgene_id "g{i}";\n')
+            f.write(f'chrA\tx\ttranscript\t{a}\t{b}\t.\t+\t.\tgene_id "g{i}"; transcript_id "t{i}";\n')
+            f.write(f'chrA\tx\texon\t{a}\t{b}\t.\t+\t.\tgene_id "g{i}"; transcript_id "t{i}";\n')
+    chrs = cl.chr_array([("chrA", 1, 0, 5000), ("chrB", 2, 0, 4000)])
+    lens = (C.c_uint32 * 2)(5000, 4000)
+    out = (cl.AnnotView * 2)()
+    assert L.cm_host_build_annotation(str(gtf).encode(), chrs, 2, lens, 2, 300, out) == 0
+    check(out[0], spans)
+    assert out[1].n_giv == 1 and out[1].giv_spos[0] == 0xFFFFFFFF        # dummy interval of an annotation-less contig
+    g, n = cl.u32p(), C.c_uint32(7)
+    assert L.cm_host_gene_overlap(C.byref(out[1]), 123, C.byref(g), C.byref(n)) == 0 and n.value == 0
+    L.cm_host_free_annotation(out, 2)

@@ -15,6 +15,7 @@
 //                       (unstable) std::sort leaves for the input order given, exactly as in the reference.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -120,6 +121,69 @@ void report_group(FILE *f, const std::vector<const Call *> &g) {
 }
 
 }  // namespace
+
+// RegionalHashTable::create_table / hash_val / add_loc (src/hash_table.cpp:58-112): every window_size-mer of the gene region
+// seq[0..len), location = start + offset; stage 2 uses ws = 8 (src/circminer.cpp:348) and probes it every 3 bases of the
+// unmapped part of a read.  Flattened: bucket hv owns loc[off[hv] .. off[hv + 1]) in ascending location.  A bucket that
+// would hold more than MAXHIT = 1000 locations is emptied, a window with a byte outside ACGTacgt has no hash value.
+extern "C" int cm_regional_table_build(const uint8_t *seq, uint32_t start, int32_t len, int32_t window_size, uint32_t **off_out, uint32_t **loc_out) {
+    if (!off_out || !loc_out || window_size < 1 || window_size > 12 || (len > 0 && !seq)) return CM_EINVAL;
+    constexpr uint32_t MAXHIT = 1000;
+    const size_t size = (size_t)1 << (2 * window_size);
+    std::vector<uint32_t> cnt(size + 1, 0);
+    std::vector<int32_t> hv_at;
+    const int n_win = len >= window_size ? len - window_size + 1 : 0;
+    hv_at.resize((size_t)n_win);
+    auto code = [](uint8_t ch) -> int {
+        switch (ch) {
+            case 'A': case 'a': return 0;
+            case 'C': case 'c': return 1;
+            case 'G': case 'g': return 2;
+            case 'T': case 't': return 3;
+            default: return -1;
+        }
+    };
+    for (int i = 0; i < n_win; ++i) {
+        int32_t hv = 0;
+        for (int k = 0; k < window_size; ++k) {
+            const int c = code(seq[i + k]);
+            if (c < 0) {
+                hv = -1;
+                break;
+            }
+            hv = (hv << 2) | c;
+        }
+        hv_at[(size_t)i] = hv;
+        if (hv >= 0) ++cnt[(size_t)hv];
+    }
+    uint32_t *off = (uint32_t *)malloc((size + 1) * sizeof(uint32_t));
+    if (!off) return CM_ENOMEM;
+    uint32_t total = 0;
+    for (size_t h = 0; h < size; ++h) {
+        off[h] = total;
+        if (cnt[h] <= MAXHIT) total += cnt[h];
+        else cnt[h] = 0;                                   // frag_count > MAXHIT -> frag_count = 0
+    }
+    off[size] = total;
+    uint32_t *loc = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
+    if (!loc) {
+        free(off);
+        return CM_ENOMEM;
+    }
+    std::vector<uint32_t> fill(size, 0);
+    for (int i = 0; i < n_win; ++i) {
+        const int32_t hv = hv_at[(size_t)i];
+        if (hv < 0 || cnt[(size_t)hv] == 0) continue;
+        loc[off[hv] + fill[(size_t)hv]++] = start + (uint32_t)i;
+    }
+    *off_out = off;
+    *loc_out = loc;
+    return CM_OK;
+}
+extern "C" void cm_regional_table_free(uint32_t *off, uint32_t *loc) {
+    free(off);
+    free(loc);
+}
 
 extern "C" int cm_sort_remain(const char *in_path, const char *out_path) {
     if (!in_path || !out_path) return CM_EINVAL;

@@ -200,6 +200,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_host_gene_overlap": (C.c_int, [pp(AnnotView), C.c_uint32, pp(u32p), pp(C.c_uint32)]),
         "cm_sort_remain": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "cm_regional_table_build": (C.c_int, [vp, C.c_uint32, C.c_int32, C.c_int32, pp(u32p), pp(u32p)]),
+        "cm_regional_table_free": (None, [u32p, u32p]),
         "cm_circ_report": (C.c_int, [pp(CircRes), C.c_uint64, C.c_char_p]),
         "cm_mapping_run": (C.c_int, [pp(MappingArgs), pp(MappingStats), C.c_char_p, C.c_uint64]),
         "cm_write_sam_header": (C.c_int, [vp]),
@@ -221,7 +223,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_host_gene_overlap"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
 
 class HostIndex:

@@ -373,6 +373,10 @@ int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *e
 /* ProcessCirc::sort_fq (src/process_circ.cpp:179-193): the remain FASTQ of the last round ordered like
  * `paste - - - - | sort -k2,2n | tr "\t" "\n"` does in the C locale (key = genome_spos, ties by the whole pasted line). */
 int cm_sort_remain(const char *in_path, const char *out_path);
+/* RegionalHashTable::create_table (src/hash_table.cpp:58-78) flattened: the window_size-mers of a gene region, bucket hv =
+ * loc[off[hv] .. off[hv+1]) ascending, location = start + offset in seq; buckets above MAXHIT = 1000 are emptied. */
+int cm_regional_table_build(const uint8_t *seq, uint32_t start, int32_t len, int32_t window_size, uint32_t **off, uint32_t **loc);
+void cm_regional_table_free(uint32_t *off, uint32_t *loc);
 /* ProcessCirc::report_events (src/process_circ.cpp:1570-1631): the BSJ calls of stage 2 (CircRes, src/common.h:406-423;
  * type 20 = CR, 21 = NCR, 22 = MCR, src/process_circ.h:16-18) -> <out>.circ_report rows
  * chr, start, end, read count, "STC", consensus start-end signal, reference start-end signal, Pass|Fail, read names. */

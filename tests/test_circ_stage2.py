@@ -89,3 +89,41 @@ def test_circ_report_rows(built, tmp_path):
     assert {r[7] for r in rows} == {"Pass", "Fail"}
     cl.circ_report([], path)
     assert open(path).read() == ""
+
+
+def test_regional_hash_table(built):
+    """RegionalHashTable::create_table (src/hash_table.cpp:58-112) flattened to CSR: every 8-mer of a gene region with its
+    location, lower case accepted, windows with N skipped, buckets above MAXHIT = 1000 emptied."""
+    import ctypes as C
+    L = cl.load()
+    rng = np.random.default_rng(6)
+    ws = 8
+    seq = "".join(rng.choice(list("ACGT"), 30000)) + "ACGTACGT" * 300 + "acgtnNacGT" * 50 + "A" * 1500 + "".join(rng.choice(list("ACGTacgt"), 2000))
+    b = np.frombuffer(seq.encode(), np.uint8)
+    off, loc = cl.u32p(), cl.u32p()
+    start = 123456
+    assert L.cm_regional_table_build(b.ctypes.data, start, len(b), ws, C.byref(off), C.byref(loc)) == 0
+    offs = np.ctypeslib.as_array(off, shape=(4 ** ws + 1,)).copy()
+    locs = np.ctypeslib.as_array(loc, shape=(max(int(offs[-1]), 1),))[:int(offs[-1])].copy()
+    L.cm_regional_table_free(off, loc)
+    want = {}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    up = seq.upper()
+    for i in range(len(seq) - ws + 1):
+        w = up[i:i + ws]
+        if any(c not in code for c in w):
+            continue
+        hv = 0
+        for c in w:
+            hv = hv * 4 + code[c]
+        want.setdefault(hv, []).append(start + i)
+    dropped = [hv for hv, v in want.items() if len(v) > 1000]
+    assert dropped and 0 in dropped                                 # the poly-A run; ACGTACGT x 300 stays (<= 1000 each)
+    for hv in range(4 ** ws):
+        got = list(locs[offs[hv]:offs[hv + 1]])
+        exp = want.get(hv, [])
+        assert got == ([] if len(exp) > 1000 else exp), hv
+    # shorter than a window / empty
+    assert L.cm_regional_table_build(b.ctypes.data, 0, ws - 1, ws, C.byref(off), C.byref(loc)) == 0
+    assert np.ctypeslib.as_array(off, shape=(4 ** ws + 1,))[-1] == 0
+    L.cm_regional_table_free(off, loc)

@@ -34,8 +34,9 @@ int cm_prof_counters(cm_ctx *, uint64_t *) { return CM_ENODEV; }
 CPP
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -I "$ROOT/include" -I "$ROOT/circminer_amd/csrc" \
     "$OUT/asan_stubs.cpp" "$ROOT/circminer_amd/csrc/host_index.cpp" "$ROOT/circminer_amd/csrc/host_annot.cpp" \
-    "$ROOT/circminer_amd/csrc/host_index_io.cpp" "$ROOT/circminer_amd/csrc/host_fastq.cpp" -o "$OUT/libcmhost_asan.so" -lpthread -lz
+    "$ROOT/circminer_amd/csrc/host_index_io.cpp" "$ROOT/circminer_amd/csrc/host_fastq.cpp" "$ROOT/circminer_amd/csrc/host_mapping.cpp" \
+    "$ROOT/circminer_amd/csrc/host_circ.cpp" -o "$OUT/libcmhost_asan.so" -lpthread -lz
 cd "$ROOT"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 CM_LIB="$OUT/libcmhost_asan.so" \
-    python -m pytest tests/test_index_files.py tests/test_fastq_io.py tests/test_host_builders.py -x -q "$@"
+    python -m pytest tests/test_index_files.py tests/test_fastq_io.py tests/test_host_builders.py tests/test_circ_stage2.py -x -q "$@"

@@ -94,6 +94,12 @@ def main():
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if collected")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever native libraries print there while we run (RCCL's version
+    # banner at communicator creation, for one) is sent to stderr; fd 1 is restored just before the line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,7 +233,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P, hi, batch)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     hp.close()
     if multi:
         dist.barrier()

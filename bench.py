@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X mapping hot path (BASELINE.json metric: paired reads/s).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts N rank processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full pass of the hot path — every mapping round (one per packed contig) — over one
-resident batch of synthetic read pairs, plus (N > 1) the RCCL gather of the back-splice-junction
-records to rank 0.  The index, genome, annotation and the reads are staged into HBM before the
-timed region; each step starts from the first-round state (cm_reads_reset, no host traffic).
-Default workload = BASELINE.json configs[1]: chr21-like 46.7 Mbp contig, k=20, 1 M 2x150 bp pairs.
+Default workload = the configuration the metric is quoted on (BASELINE.json configs[2], scaled to one step): an hg38-sized
+synthetic genome (24 chromosomes with hg38's lengths, 3.09 Gbp -> three packed contigs, all resident in HBM, three mapping
+rounds), k = 20, batches of 1 M 2x150 bp pairs.
 
-Weak scaling: every rank maps its own shard of `--pairs` pairs against its own replica of the
-index; value = (pairs of all ranks x steps) / max-over-ranks time.
+A "step" is one batch through the whole hot path:
+  * its reads come from (page-locked) host memory: cm_reads_stage copies batch k+1 over PCIe on a copy stream while batch
+    k is mapped -- the H2D copy is inside the timed region, one per step;
+  * every mapping round (one per packed contig) of the resident batch;
+  * the back-splice-junction hand-off (cm_collect_records; N > 1: device records gathered to rank 0 over RCCL).
+The index, genome and annotation are staged into HBM once, before the timed region (they are the reference's loaded
+hash table).
+
+Weak scaling: every rank maps its own stream of `--pairs`-pair batches against its own replica of the index;
+value = (pairs of all ranks x steps) / max-over-ranks time.  The host-side index is built once (rank 0) and shared with
+the other ranks through memory-mapped files.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import threading
@@ -29,11 +39,16 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNELS = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_chain_heavy"]
+METRIC = "paired reads/sec (whole node), hg38 k=20, 2x150 bp; circ_report bit-exact"
+WORKLOAD_NOTE = {
+    "hg38like": "BASELINE.json configs[2] layout: hg38-sized synthetic genome",
+    "chr21": "BASELINE.json configs[1]: chr21-like synthetic contig",
+}
 
 
 def algorithmic_bytes(counters):
-    """SURVEY.md §8(d) per-pair-round figure, split by the kernel that moves the bytes
-    (DESIGN.md §6): probes pay 16 B (bucket offset + count header) + 8 B per binary-search touch
+    """SURVEY.md 8(d) per-pair-round figure, split by the kernel that moves the bytes
+    (DESIGN.md 6): probes pay 16 B (bucket offset + count header) + 8 B per binary-search touch
     and the two reads come in once (300 B); chaining consumes 8 B per retained hit; pairing /
     extension is charged the survey's upper bound of four 170-byte reference windows (1360 B)
     plus the 96-byte result record."""
@@ -77,8 +92,52 @@ def cpu_baseline(P, hi, batch, target_s=12.0):
     reps = max(1, min(40, int(round((target_s - dt1) / max(dt1, 1e-3)))))
     dt = run(reps)
     return {"value": n * reps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} pairs of the same workload x {reps} passes, all rounds, oracle/cm_oracle.cpp on {cores} threads, {dt:.1f}s",
-            "single_thread_value": rate1}
+            "sample": f"first {n} pairs of one batch of the same workload x {reps} passes, all {hi.n_contigs} rounds, "
+                      f"oracle/cm_oracle.cpp on {cores} threads, {dt:.1f}s",
+            "single_thread_value": rate1,
+            "note": "kind 'port': the reference itself cannot be built in this image (its lib/ submodules are absent), so there is "
+                    "no reference --thread N run and no reference/port bridge ratio"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never touches the GPU),
+    pass rank 0's JSON line through."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        raise SystemExit(f"bench.py: rank 0 did not report n_gpus == {n}")
+
+
+def share_dir(tag, need_bytes):
+    """Directory for the index arrays shared between the ranks of one node: /dev/shm when it has the room, else TMPDIR."""
+    for base in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if shutil.disk_usage(base).free > need_bytes * 1.1:
+                return os.path.join(base, tag)
+        except OSError:
+            pass
+    return os.path.join(tempfile.gettempdir(), tag)
 
 
 def main():
@@ -86,13 +145,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chr21")
-    ap.add_argument("--pairs", type=int, default=1_000_000)
-    ap.add_argument("--seed", type=int, default=21)
+    ap.add_argument("--workload", default="hg38like", choices=sorted(WORKLOAD_NOTE))
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per batch (= per step and GPU)")
+    ap.add_argument("--seed", type=int, default=38)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: CPU rehearsal of the launch, tests only)")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if collected")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
 
     # stdout carries the one JSON line and nothing else: whatever native libraries print there while we run (RCCL's version
     # banner at communicator creation, for one) is sent to stderr; fd 1 is restored just before the line is printed
@@ -103,18 +167,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     dist = None
     # CM_BENCH_FORCE_DIST=1: take the N>1 code path (process group, gatherv, barriers) with a single rank -- a rehearsal of
     # the RCCL calls on a one-GPU box
     multi = world > 1 or bool(os.environ.get("CM_BENCH_FORCE_DIST"))
     if multi:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
     if not torch.cuda.is_available():
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
 
@@ -126,35 +202,60 @@ def main():
     ge.build()
     from circminer_amd import dist as cdist, lib as cl, synth
 
-    # ---- synthetic workload (same genome + annotation on every rank, own shard of reads) ----
+    # ---- synthetic workload (same genome + annotation on every rank, own stream of reads) ----
     t0 = time.time()
-    d = synth.generate(args.workload, n_pairs=args.pairs, seed=args.seed, read_seed=rank)
+    n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
+    # two different batches take turns, so that consecutive steps really move different reads over PCIe
+    d = synth.generate(args.workload, n_pairs=2 * args.pairs, seed=args.seed, read_seed=rank)
+    gen_s = time.time() - t0
+    tag = f"cm_bench_{args.workload}_{args.seed}_{os.environ.get('MASTER_PORT', '0')}"
+    sdir = share_dir(tag, 8 * sum(len(c) for c in d.contigs)) if world > 1 else None
     with tempfile.TemporaryDirectory() as td:
         gtf = os.path.join(td, "ref.gtf")
         with open(gtf, "w") as f:
             f.write(d.gtf_text)
-        hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, n_threads=max(1, (os.cpu_count() or 8) // max(world, 1)))
+        if world == 1:
+            hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, n_threads=n_threads)
+        else:
+            # the k-mer index is built once per node: rank 0 -> memory-mapped files -> the other ranks
+            if rank == 0:
+                shutil.rmtree(sdir, ignore_errors=True)
+                hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, n_threads=os.cpu_count() or 8)
+                hi.save_index(sdir)
+            dist.barrier()
+            if rank != 0:
+                hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, index_dir=sdir)
     P = cl.default_params(device=local_rank)
-    batch = cl.ReadBatch(d.seq1, d.seq2)
     prep_s = time.time() - t0
 
     hp = cl.HotPath(P)
     for ci in range(hi.n_contigs):
         hp.load_contig(ci, hi.views[ci], hi.annots[ci])
-    hp.upload(batch)
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(sdir, ignore_errors=True)          # mappings of the other ranks stay valid until they drop them
+    batches = [hp.pinned_batch(d.seq1[i * args.pairs:(i + 1) * args.pairs], d.seq2[i * args.pairs:(i + 1) * args.pairs]) for i in range(2)]
+    load_s = time.time() - t0 - prep_s
     base = rank * args.pairs
     gather = cdist.BsjGather(args.pairs, dev) if multi else None
+    turn = [0]
 
     def step():
-        hp.reset()
+        # H2D of the next batch on the copy stream, concurrent with the rounds of the resident one
+        turn[0] ^= 1
+        hp.stage(batches[turn[0]])
         for ci in range(hi.n_contigs):
             hp.map_round(ci, ci == hi.n_contigs - 1)
         # BSJ hand-off to stage 2: records assembled on the device.  One GPU: one small D2H.  N GPUs: gatherv to rank 0 over
         # RCCL from HBM; rank 0's D2H of the gathered records overlaps the next step's rounds and is waited for in fence().
         if multi:
             gather.submit(hp.collect_records_device(base, args.pairs, gather.send_ptr()))
-            return None
-        return hp.collect_records(base)
+            rec = None
+        else:
+            rec = hp.collect_records(base)
+        hp.swap()
+        return rec
 
     def fence():
         hp.sync()
@@ -165,6 +266,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    hp.stage(batches[0])
+    hp.swap()
     hp.prof(True)                      # timers on during warm-up too: their HIP events are created once and recycled
     # Setup, not warm-up: the first launches allocate the kernels' private segments and lazily created runtime
     # objects, and the device shows one ~7 ms stall within its first ~100 ms of work (tests/diag/step_times.py);
@@ -204,33 +307,42 @@ def main():
         dom = int(np.argmax(stage_ms))
         avg_ms = stage_ms[dom] / max(launches[dom], 1)
         achieved = (ab[dom] / max(launches[dom], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             with open(args.traffic) as f:
                 tj = json.load(f)
             if tj.get("workload") == args.workload and tj.get("pairs") == args.pairs:
                 traffic = tj.get("bytes_per_launch", {}).get(KERNELS[dom])
+                traffic_src = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/traffic.json), not this run"
         except Exception:
             traffic = None
+        read_bytes = int(batches[0].seq1.size + batches[0].seq2.size + 16 * (args.pairs + 1))
         out = {
-            "metric": "paired reads/sec (whole node), hg38 k=20, 2x150 bp; circ_report bit-exact",
+            "metric": METRIC,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32/u8 (chain scores f64)", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-like synthetic contig ({sum(len(c) for c in d.contigs)} bp, "
-                                   f"{len(d.genes)} genes), k=20, {args.pairs} 2x150 bp pairs per GPU, "
-                                   f"{hi.n_contigs} round(s), defaults (BASELINE.json configs[1])",
-                       "pairs_per_gpu": args.pairs, "rounds": hi.n_contigs, "bsj_records": int(len(rec)),         # all ranks' records, as gathered on rank 0
-                       "prep_seconds": round(prep_s, 1)},
+            "config": {"workload": f"{WORKLOAD_NOTE[args.workload]} ({sum(len(c) for c in d.contigs)} bp in {hi.n_contigs} packed contig(s), "
+                                   f"{len(d.genes)} genes), k=20, {hi.n_contigs} mapping round(s) per batch, batches of {args.pairs} 2x150 bp pairs "
+                                   f"streamed from host memory (H2D inside the timed region, overlapped with the rounds), defaults; "
+                                   f"{total_pairs} pairs in the timed region",
+                       "scope": "stage 1 hot path (process_read over all rounds + BSJ hand-off); reads start in host memory, "
+                                "FASTQ parsing and stage-2 circ_report are outside the timed region; parity is against the "
+                                "CPU oracle (parity unpinned: the reference cannot be built here)",
+                       "pairs_per_gpu_per_step": args.pairs, "total_pairs": total_pairs, "rounds": hi.n_contigs,
+                       "h2d_bytes_per_step": read_bytes,
+                       "bsj_records_last_step": int(len(rec)),         # all ranks' records, as gathered on rank 0
+                       "world_size": world,
+                       "prep_seconds": {"generate": round(gen_s, 1), "index+annotation": round(prep_s - gen_s, 1), "load_to_hbm": round(load_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_pair_heavy+k_classify" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": launches[dom],
                          "algorithmic_bytes_per_launch": ab[dom] / max(launches[dom], 1)},
             "kernels": {KERNELS[i]: {"ms_total": ms[i], "launches": launches[i], "algorithmic_bytes": ab[i]} for i in range(7)},
             "counters": {"probes": counters[0], "search_touches": counters[1], "hits_consumed": counters[2], "pair_rounds": counters[3]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, hi, batch)
+            out["cpu_baseline"] = cpu_baseline(P, hi, batches[0])
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 OUT = os.path.join(CSRC, "libcmhot.so")
 SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp", "host_mapping.cpp", "host_circ.cpp"]
-DEPS = SOURCES + ["cm_core.h", os.path.join("..", "..", "include", "circminer_hot.h")]
+DEPS = SOURCES + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "circminer_hot.h")]
 
 
 def needs_build() -> bool:

@@ -1030,6 +1030,16 @@ struct cm_ctx {
     uint8_t *d_active = nullptr;
     int32_t *d_cat = nullptr;
     int n_seeds = 0, max_len = 0;
+    // staged batch (cm_reads_stage): a second set of read buffers filled on the copy stream while the resident batch is mapped
+    hipStream_t stream_copy = nullptr;
+    hipEvent_t ev_staged = nullptr, ev_retired = nullptr;
+    bool staged = false;
+    uint64_t st_n_pairs = 0;
+    uint8_t *st_seq1_base = nullptr, *st_seq2_base = nullptr;
+    uint64_t *st_off1 = nullptr, *st_off2 = nullptr;
+    cm_mapped_read *st_prior = nullptr;
+    bool st_has_prior = false;
+    int st_max_len = 0;
     // workspace
     uint32_t tile = 0;
     uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
@@ -1129,6 +1139,10 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
+    if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
+    dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
+    c->staged = false;
+    c->st_n_pairs = 0;
     c->n_pairs = 0;
     c->tile = 0;
 }
@@ -1310,6 +1324,9 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     cm_ctx *ctx = new cm_ctx();
     ctx->P = *p;
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_retired, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
@@ -1357,6 +1374,9 @@ void cm_destroy(cm_ctx *ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
+    if (ctx->ev_retired) (void)hipEventDestroy(ctx->ev_retired);
+    if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1449,57 +1469,38 @@ int cm_unload_contig(cm_ctx *ctx, int slot) {
     return CM_OK;
 }
 
-int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior) {
-    if (!ctx || !rd) return CM_EINVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+// Validation shared by cm_reads_upload / cm_reads_stage; returns the longest read through *max_len_out.
+static int check_reads(cm_ctx *ctx, const cm_reads *rd, int *max_len_out) {
     const uint64_t n = rd->n_pairs;
-    ctx->n_pairs = 0;
-    ctx->tile = 0;
-    if (n == 0) {                                  // an empty batch releases the per-batch buffers
-        free_reads(ctx);
-        return CM_OK;
-    }
     if (n > 0x3fffffffull) return fail(ctx, CM_ELIMIT, "more than 2^30 pairs in one batch");
     if (!rd->seq1 || !rd->seq2 || !rd->off1 || !rd->off2) return fail(ctx, CM_EINVAL, "null read arrays");
     int max_len = 0;
+    const uint64_t lim = (uint64_t)ctx->P.max_read_len;
+    uint64_t bad = 0, longest = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        if (rd->off1[i + 1] < rd->off1[i] || rd->off2[i + 1] < rd->off2[i]) return fail(ctx, CM_EINVAL, "read offsets not monotone at pair %llu", (unsigned long long)i);
-        const uint64_t l1 = rd->off1[i + 1] - rd->off1[i], l2 = rd->off2[i + 1] - rd->off2[i];
-        if (l1 > (uint64_t)ctx->P.max_read_len || l2 > (uint64_t)ctx->P.max_read_len)
-            return fail(ctx, CM_EINVAL, "pair %llu longer than max_read_len %d", (unsigned long long)i, ctx->P.max_read_len);
-        if ((int)l1 > max_len) max_len = (int)l1;
-        if ((int)l2 > max_len) max_len = (int)l2;
+        const uint64_t l1 = rd->off1[i + 1] - rd->off1[i], l2 = rd->off2[i + 1] - rd->off2[i];     // wraps to huge when not monotone
+        const uint64_t m = l1 > l2 ? l1 : l2;
+        if (m > lim && !bad) bad = i + 1;
+        if (m > longest) longest = m;
     }
+    if (bad) {
+        const uint64_t i = bad - 1;
+        if (rd->off1[i + 1] < rd->off1[i] || rd->off2[i + 1] < rd->off2[i]) return fail(ctx, CM_EINVAL, "read offsets not monotone at pair %llu", (unsigned long long)i);
+        return fail(ctx, CM_EINVAL, "pair %llu longer than max_read_len %d", (unsigned long long)i, ctx->P.max_read_len);
+    }
+    max_len = (int)longest;
+    if (max_len / ctx->P.kmer > cmc::MAX_SEEDS) return fail(ctx, CM_ELIMIT, "%d seeds per read > %d supported", max_len / ctx->P.kmer, cmc::MAX_SEEDS);
+    *max_len_out = max_len;
+    return CM_OK;
+}
+
+// Per-tile workspace and per-batch state of the batch that is becoming resident (n pairs, longest read max_len).
+static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     ctx->n_seeds = max_len / ctx->P.kmer;
     ctx->max_len = max_len;
-    if (ctx->n_seeds > cmc::MAX_SEEDS) return fail(ctx, CM_ELIMIT, "%d seeds per read > %d supported", ctx->n_seeds, cmc::MAX_SEEDS);
-    const size_t b1 = (size_t)rd->off1[n], b2 = (size_t)rd->off2[n];
-    const size_t pad = cmc::CM_STAGE_PAD;                  // readable slack around the reads (see cmc::stage)
-    HIPCHK(ctx, ensure(ctx, ctx->d_seq1_base, b1 + 2 * pad));
-    HIPCHK(ctx, ensure(ctx, ctx->d_seq2_base, b2 + 2 * pad));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_seq1_base, 0, b1 + 2 * pad, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_seq2_base, 0, b2 + 2 * pad, ctx->stream));
-    ctx->d_seq1 = ctx->d_seq1_base + pad;
-    ctx->d_seq2 = ctx->d_seq2_base + pad;
-    HIPCHK(ctx, ensure(ctx, ctx->d_off1, (n + 1) * sizeof(uint64_t)));
-    HIPCHK(ctx, ensure(ctx, ctx->d_off2, (n + 1) * sizeof(uint64_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_state, n * sizeof(cm_mapped_read)));
     HIPCHK(ctx, ensure(ctx, ctx->d_active, n));
     HIPCHK(ctx, ensure(ctx, ctx->d_cat, n * sizeof(int32_t)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq1, rd->seq1, b1, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq2, rd->seq2, b2, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_off1, rd->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_off2, rd->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    ctx->n_pairs = n;
-    KCore k{};
-    k.P = ctx->P;
-    hipLaunchKernelGGL(k_init_state, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active, ctx->d_cat, n);
-    if (prior) {
-        // carried state of an earlier round: a pair is active unless the caller marks it retired
-        // by type < 0 (never produced by this library); active flags are otherwise all 1.
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, prior, n * sizeof(cm_mapped_read), hipMemcpyHostToDevice, ctx->stream));
-    }
     // workspace for one tile
     uint32_t tile_cap = TILE_PAIRS;
     if (const char *e = getenv("CM_TILE_PAIRS")) {       // tuning knob: pairs per launch group
@@ -1521,9 +1522,9 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     const unsigned long long worst = (unsigned long long)ctx->P.seed_lim * (unsigned long long)(ctx->n_seeds ? ctx->n_seeds : 1);
     if (cap < (8ull << 20)) cap = 8ull << 20;
     if (cap < worst) cap = worst;
-    ctx->cells_cap = cap;
-    HIPCHK(ctx, ensure(ctx, ctx->d_dpscore, cap * sizeof(double)));
-    HIPCHK(ctx, ensure(ctx, ctx->d_dpprev, cap * sizeof(int32_t)));
+    if (cap > ctx->cells_cap || !ctx->d_dpscore) ctx->cells_cap = cap;        // grow-only, like the buffers behind it
+    HIPCHK(ctx, ensure(ctx, ctx->d_dpscore, ctx->cells_cap * sizeof(double)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_dpprev, ctx->cells_cap * sizeof(int32_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, ensure(ctx, ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_high, nprob * 4));
@@ -1554,9 +1555,118 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
     if (pool < (256ull << 20)) pool = 256ull << 20;
     if (pool > (8ull << 30)) pool = 8ull << 30;
-    ctx->pool_bytes = pool;
-    HIPCHK(ctx, ensure(ctx, ctx->d_pool, pool));
+    if (pool > ctx->pool_bytes || !ctx->d_pool) ctx->pool_bytes = pool;
+    HIPCHK(ctx, ensure(ctx, ctx->d_pool, ctx->pool_bytes));
+    return CM_OK;
+}
+
+// Copies of one batch into (grow-only) read buffers on stream `st`: only the CM_STAGE_PAD slack around the reads is
+// cleared (cmc::stage over-reads into it), the reads themselves are overwritten by the copy.
+static int copy_reads(cm_ctx *ctx, const cm_reads *rd, hipStream_t st, uint8_t *&seq1_base, uint8_t *&seq2_base, uint64_t *&off1, uint64_t *&off2) {
+    const uint64_t n = rd->n_pairs;
+    const size_t b1 = (size_t)rd->off1[n] - (size_t)rd->off1[0], b2 = (size_t)rd->off2[n] - (size_t)rd->off2[0];
+    if (rd->off1[0] != 0 || rd->off2[0] != 0) return fail(ctx, CM_EINVAL, "read offsets must start at 0");
+    const size_t pad = cmc::CM_STAGE_PAD;                  // readable slack around the reads (see cmc::stage)
+    HIPCHK(ctx, ensure(ctx, seq1_base, b1 + 2 * pad));
+    HIPCHK(ctx, ensure(ctx, seq2_base, b2 + 2 * pad));
+    HIPCHK(ctx, ensure(ctx, off1, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, ensure(ctx, off2, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, hipMemsetAsync(seq1_base, 0, pad, st));
+    HIPCHK(ctx, hipMemsetAsync(seq1_base + pad + b1, 0, pad, st));
+    HIPCHK(ctx, hipMemsetAsync(seq2_base, 0, pad, st));
+    HIPCHK(ctx, hipMemsetAsync(seq2_base + pad + b2, 0, pad, st));
+    if (b1) HIPCHK(ctx, hipMemcpyAsync(seq1_base + pad, rd->seq1, b1, hipMemcpyHostToDevice, st));
+    if (b2) HIPCHK(ctx, hipMemcpyAsync(seq2_base + pad, rd->seq2, b2, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(off1, rd->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(off2, rd->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    return CM_OK;
+}
+
+int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior) {
+    if (!ctx || !rd) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = rd->n_pairs;
+    ctx->n_pairs = 0;
+    ctx->tile = 0;
+    if (n == 0) {                                  // an empty batch releases the per-batch buffers
+        free_reads(ctx);
+        return CM_OK;
+    }
+    int max_len = 0;
+    int rc = check_reads(ctx, rd, &max_len);
+    if (rc) return rc;
+    if ((rc = copy_reads(ctx, rd, ctx->stream, ctx->d_seq1_base, ctx->d_seq2_base, ctx->d_off1, ctx->d_off2))) return rc;
+    ctx->d_seq1 = ctx->d_seq1_base + cmc::CM_STAGE_PAD;
+    ctx->d_seq2 = ctx->d_seq2_base + cmc::CM_STAGE_PAD;
+    if ((rc = prepare_resident(ctx, n, max_len))) return rc;
+    ctx->n_pairs = n;
+    KCore k{};
+    k.P = ctx->P;
+    hipLaunchKernelGGL(k_init_state, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active, ctx->d_cat, n);
+    if (prior) {
+        // carried state of an earlier round: a pair is active unless the caller marks it retired
+        // by type < 0 (never produced by this library); active flags are otherwise all 1.
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, prior, n * sizeof(cm_mapped_read), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CM_OK;
+}
+
+int cm_reads_stage(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior) {
+    if (!ctx || !rd) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (rd->n_pairs == 0) return fail(ctx, CM_EINVAL, "cm_reads_stage: empty batch");
+    int max_len = 0;
+    int rc = check_reads(ctx, rd, &max_len);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_copy));          // an earlier staged batch that was never swapped in is dropped
+    ctx->staged = false;
+    if ((rc = copy_reads(ctx, rd, ctx->stream_copy, ctx->st_seq1_base, ctx->st_seq2_base, ctx->st_off1, ctx->st_off2))) return rc;
+    ctx->st_has_prior = prior != nullptr;
+    if (prior) {
+        HIPCHK(ctx, ensure(ctx, ctx->st_prior, rd->n_pairs * sizeof(cm_mapped_read)));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_prior, prior, rd->n_pairs * sizeof(cm_mapped_read), hipMemcpyHostToDevice, ctx->stream_copy));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_staged, ctx->stream_copy));
+    ctx->st_n_pairs = rd->n_pairs;
+    ctx->st_max_len = max_len;
+    ctx->staged = true;
+    return CM_OK;
+}
+
+int cm_reads_swap(cm_ctx *ctx) {
+    if (!ctx) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (!ctx->staged) return fail(ctx, CM_ESTATE, "cm_reads_swap: no staged batch");
+    // work already queued on the mapping stream still reads the old buffers: order the swap behind it on the device
+    // (no host wait), and the new batch's first kernel behind the staged copies
+    std::swap(ctx->d_seq1_base, ctx->st_seq1_base);
+    std::swap(ctx->d_seq2_base, ctx->st_seq2_base);
+    std::swap(ctx->d_off1, ctx->st_off1);
+    std::swap(ctx->d_off2, ctx->st_off2);
+    std::swap(ctx->caps[(const void *)&ctx->d_seq1_base], ctx->caps[(const void *)&ctx->st_seq1_base]);
+    std::swap(ctx->caps[(const void *)&ctx->d_seq2_base], ctx->caps[(const void *)&ctx->st_seq2_base]);
+    std::swap(ctx->caps[(const void *)&ctx->d_off1], ctx->caps[(const void *)&ctx->st_off1]);
+    std::swap(ctx->caps[(const void *)&ctx->d_off2], ctx->caps[(const void *)&ctx->st_off2]);
+    ctx->d_seq1 = ctx->d_seq1_base + cmc::CM_STAGE_PAD;
+    ctx->d_seq2 = ctx->d_seq2_base + cmc::CM_STAGE_PAD;
+    ctx->staged = false;
+    const uint64_t n = ctx->st_n_pairs;
+    ctx->n_pairs = 0;
+    int rc = prepare_resident(ctx, n, ctx->st_max_len);
+    if (rc) return rc;
+    ctx->n_pairs = n;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
+    KCore k{};
+    k.P = ctx->P;
+    hipLaunchKernelGGL(k_init_state, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, k, ctx->d_state, ctx->d_active, ctx->d_cat, n);
+    if (ctx->st_has_prior)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state, ctx->st_prior, n * sizeof(cm_mapped_read), hipMemcpyDeviceToDevice, ctx->stream));
+    // the next cm_reads_stage overwrites the buffers this swap retired: it must wait for the mapping stream's work on them
+    HIPCHK(ctx, hipEventRecord(ctx->ev_retired, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_retired, 0));
+    HIPCHK(ctx, hipGetLastError());
     return CM_OK;
 }
 

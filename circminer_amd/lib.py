@@ -163,6 +163,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_load_annotation": (C.c_int, [vp, C.c_int, pp(AnnotView)]),
         "cm_unload_contig": (C.c_int, [vp, C.c_int]),
         "cm_reads_upload": (C.c_int, [vp, pp(Reads), vp]),
+        "cm_reads_stage": (C.c_int, [vp, pp(Reads), vp]),
+        "cm_reads_swap": (C.c_int, [vp]),
         "cm_map_round": (C.c_int, [vp, C.c_int, C.c_int]),
         "cm_reads_download": (C.c_int, [vp, vp, vp, vp]),
         "cm_map_batch": (C.c_int, [vp, C.c_int, C.c_int, pp(Reads), vp, vp, vp]),
@@ -217,7 +219,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
-                    "cm_unload_contig", "cm_reads_upload", "cm_map_round", "cm_reads_download", "cm_map_batch",
+                    "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_reads_download", "cm_map_batch",
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
@@ -227,18 +229,32 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
 
 
 class HostIndex:
-    """Owns the host-side index + annotation of a packed genome (built by the C++ host builders)."""
+    """Owns the host-side index + annotation of a packed genome (built by the C++ host builders).
 
-    def __init__(self, contigs, chr_table, gtf_path, kmer=20, max_read_len=300, n_threads=8):
+    index_dir: take the k-mer index arrays from files written by save_index() (memory-mapped, shared between the rank
+    processes of a node) instead of building them; the annotation is always built here (seconds)."""
+
+    def __init__(self, contigs, chr_table, gtf_path, kmer=20, max_read_len=300, n_threads=8, index_dir=None):
         L = load()
         self.L = L
         self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
         self.views = []
+        self._mapped = []
+        self.kmer = kmer
         for ci, g in enumerate(self.contigs):
             iv = IndexView()
-            rc = L.cm_host_build_index(ptr(g, u8p), len(g), kmer, ci, n_threads, C.byref(iv))
-            if rc != 0:
-                raise RuntimeError(f"cm_host_build_index failed: {rc}")
+            if index_dir is None:
+                rc = L.cm_host_build_index(ptr(g, u8p), len(g), kmer, ci, n_threads, C.byref(iv))
+                if rc != 0:
+                    raise RuntimeError(f"cm_host_build_index failed: {rc}")
+            else:
+                arrs = [np.memmap(os.path.join(index_dir, f"c{ci}.{nm}"), dtype=dt, mode="r")
+                        for nm, dt in (("off", np.uint32), ("cks", np.uint16), ("pos", np.uint32))]
+                if len(arrs[0]) != (1 << 28) + 1 or len(arrs[1]) != len(arrs[2]) or int(arrs[0][-1]) != len(arrs[2]):
+                    raise RuntimeError(f"index files of contig {ci} in {index_dir} are inconsistent")
+                self._mapped.append(arrs)
+                iv = IndexView(ci, len(g), ptr(g, u8p), C.cast(arrs[0].ctypes.data, u32p), C.cast(arrs[1].ctypes.data, u16p),
+                               C.cast(arrs[2].ctypes.data, u32p), len(arrs[2]))
             self.views.append(iv)
         n_con = len(self.contigs)
         self._names = [t[0].encode() for t in chr_table]
@@ -252,10 +268,21 @@ class HostIndex:
         self.chr_table = list(chr_table)
         self.n_contigs = n_con
 
+    def save_index(self, index_dir):
+        """Raw dumps of the flattened index arrays (bucket offsets, checksums, positions) of every contig."""
+        os.makedirs(index_dir, exist_ok=True)
+        for ci, iv in enumerate(self.views):
+            n = int(iv.n_entries)
+            np.ctypeslib.as_array(iv.bucket_off, ((1 << 28) + 1,)).tofile(os.path.join(index_dir, f"c{ci}.off"))
+            np.ctypeslib.as_array(iv.checksum, (max(n, 1),))[:n].tofile(os.path.join(index_dir, f"c{ci}.cks"))
+            np.ctypeslib.as_array(iv.pos, (max(n, 1),))[:n].tofile(os.path.join(index_dir, f"c{ci}.pos"))
+
     def close(self):
         if self.views:
-            for iv in self.views:
-                self.L.cm_host_free_index(C.byref(iv))
+            if not self._mapped:
+                for iv in self.views:
+                    self.L.cm_host_free_index(C.byref(iv))
+            self._mapped = []
             self.L.cm_host_free_annotation(self.annots, self.n_contigs)
             self.views = []
 
@@ -485,6 +512,33 @@ class HotPath:
         self.n = batch.n
         p = prior.ctypes.data if prior is not None else None
         self._chk(self.L.cm_reads_upload(self.h, C.byref(batch.c), p), "cm_reads_upload")
+
+    def stage(self, batch: ReadBatch, prior: np.ndarray = None):
+        """Start copying the next batch (asynchronous for page-locked arrays, see pinned_batch) while the resident one maps."""
+        self._staged_n = batch.n
+        p = prior.ctypes.data if prior is not None else None
+        self._chk(self.L.cm_reads_stage(self.h, C.byref(batch.c), p), "cm_reads_stage")
+
+    def swap(self):
+        self._chk(self.L.cm_reads_swap(self.h), "cm_reads_swap")
+        self.n = self._staged_n
+
+    def pinned_batch(self, seq1: np.ndarray, seq2: np.ndarray) -> "ReadBatch":
+        """A ReadBatch whose arrays live in page-locked memory of this context (copies of (n, L) uint8 matrices)."""
+        n, L1 = seq1.shape
+        L2 = seq2.shape[1]
+        s1 = self.host_array(n * L1, np.uint8)
+        s2 = self.host_array(n * L2, np.uint8)
+        s1[:] = seq1.reshape(-1)
+        s2[:] = seq2.reshape(-1)
+        o1 = self.host_array(n + 1, np.uint64)
+        o2 = self.host_array(n + 1, np.uint64)
+        o1[:] = np.arange(n + 1, dtype=np.uint64) * L1
+        o2[:] = np.arange(n + 1, dtype=np.uint64) * L2
+        b = ReadBatch.__new__(ReadBatch)
+        b.seq1, b.seq2, b.off1, b.off2, b.n = s1, s2, o1, o2, int(n)
+        b.c = Reads(b.n, ptr(s1, u8p), ptr(o1, u64p), ptr(s2, u8p), ptr(o2, u64p))
+        return b
 
     def map_round(self, slot, is_last):
         self._chk(self.L.cm_map_round(self.h, slot, int(is_last)), "cm_map_round")

@@ -180,6 +180,16 @@ int cm_unload_contig(cm_ctx *ctx, int slot);
  * prior may be NULL (= first round, fill_map_info's "cnt != 23" state). */
 int cm_reads_upload(cm_ctx *ctx, const cm_reads *reads, const cm_mapped_read *prior);
 
+/* Double buffering (the reference overlaps nothing: map_reads parses a block, maps it, prints it, src/circminer.cpp:354-400):
+ * cm_reads_stage copies the NEXT batch into a second set of read buffers on a copy stream and returns at once when the host
+ * arrays are page-locked (cm_host_alloc; pageable memory is accepted and copied synchronously by the runtime); the rounds of
+ * the resident batch run meanwhile.  cm_reads_swap makes the staged batch the resident one (first-round state, or `prior`):
+ * it is ordered on the device behind the staged copies and behind the work already queued for the old batch, so the host
+ * does not wait.  The host arrays passed to cm_reads_stage must stay untouched until cm_reads_swap has been followed by a
+ * cm_sync / download / collect, or until the next cm_reads_stage returns. */
+int cm_reads_stage(cm_ctx *ctx, const cm_reads *reads, const cm_mapped_read *prior);
+int cm_reads_swap(cm_ctx *ctx);
+
 /* One mapping round of the resident batch against contig `slot`:
  * FilterRead::process_read for every pair still active + the skip rule of
  * map_reads (src/circminer.cpp:386-397).  Pairs whose carried state says they were

@@ -97,3 +97,25 @@ def map_all_rounds(params, host_index, batch):
         last = ci == host_index.n_contigs - 1
         cats.append(map_round(params, host_index.views[ci], host_index.annots[ci], batch, last, st, act))
     return st, act, cats
+
+
+def map_all_rounds_mt(params, host_index, batch, n_threads=None, p1=None):
+    """map_all_rounds on several host threads (process_read is a pure function of the pair; ctypes releases the GIL):
+    pairs [0, p1) only when p1 is given.  Returns (state, active, category of the last round)."""
+    import threading
+    L = load()
+    n = batch.n if p1 is None else min(int(p1), batch.n)
+    T = max(1, min(n_threads or os.cpu_count() or 1, 64))
+    st, act = default_state(params, batch.n)
+    cat = np.full(max(batch.n, 1), -1, dtype=np.int32)
+
+    def work(a, b):
+        for ci in range(host_index.n_contigs):
+            rc = L.oracle_map_round(C.byref(params), C.byref(host_index.views[ci]), C.byref(host_index.annots[ci]), C.byref(batch.c),
+                                    int(ci == host_index.n_contigs - 1), st.ctypes.data, act.ctypes.data, cat.ctypes.data, a, b)
+            assert rc == 0, rc
+
+    th = [threading.Thread(target=work, args=((n * i) // T, (n * (i + 1)) // T)) for i in range(T)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return st, act, cat[:batch.n]

@@ -421,3 +421,58 @@ def test_genes_with_more_than_64_isoforms(ds_tiny, tmp_path):
     from test_hostemu_parity import _many_isoforms
     sh = _many_isoforms(ds_tiny, tmp_path, 45)
     _run_all_rounds(sh, cl.default_params())
+
+
+def test_staged_batches_overlap_and_match(ds_tiny2r, ds_dirty):
+    """cm_reads_stage / cm_reads_swap: the next batch is copied on the copy stream while the resident one maps; every
+    batch's results equal the oracle's, whatever was resident or staged before (ragged batch, carried prior states,
+    a staged batch that is replaced before it is swapped in)."""
+    ds = ds_tiny2r
+    P = cl.default_params(kmer=ds.kmer)
+    hp = cl.HotPath(P)
+    for ci in range(ds.hi.n_contigs):
+        hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
+    n = ds.batch.n
+    pa = hp.pinned_batch(ds.d.seq1[:n // 2], ds.d.seq2[:n // 2])
+    pb = hp.pinned_batch(ds.d.seq1[n // 2:], ds.d.seq2[n // 2:])
+    want, _, _ = op.map_all_rounds(P, ds.hi, ds.batch)
+    want_dirty, _, _ = op.map_all_rounds(P, ds.hi, ds_dirty.batch)
+
+    def rounds():
+        for ci in range(ds.hi.n_contigs):
+            hp.map_round(ci, ci == ds.hi.n_contigs - 1)
+
+    with pytest.raises(RuntimeError):
+        hp.swap()                                   # nothing staged
+    hp.stage(pa)
+    hp.swap()
+    hp.stage(pb)                                    # in flight while A maps
+    rounds()
+    stA = hp.download()[0]
+    hp.swap()
+    hp.stage(ds_dirty.batch)                        # pageable, ragged
+    rounds()
+    stB = hp.download()[0]
+    hp.swap()
+    hp.stage(pb)                                    # replaced before it is used
+    hp.stage(pa)
+    rounds()
+    stD = hp.download()[0]
+    hp.swap()
+    rounds()
+    stA2 = hp.download()[0]
+    assert stA.tobytes() == want[:n // 2].tobytes() and stA2.tobytes() == stA.tobytes()
+    assert stB.tobytes() == want[n // 2:].tobytes()
+    assert stD.tobytes() == want_dirty.tobytes()
+    # carried states: round 1 resident, survivors staged with their prior state, round 2
+    hp.upload(ds.batch)
+    hp.map_round(0, False)
+    st1, _, act1 = hp.download()
+    idx = np.nonzero(act1)[0]
+    sub = cl.ReadBatch(ds.d.seq1[idx], ds.d.seq2[idx])
+    hp.stage(sub, np.ascontiguousarray(st1[idx]))
+    hp.swap()
+    hp.map_round(1, True)
+    st2 = hp.download()[0]
+    assert st2.tobytes() == want[idx].tobytes()
+    hp.close()

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -502,7 +503,9 @@ void global_banded_alignment(Mat &dp, const uint8_t *s, int n, const uint8_t *t,
     for (i = 0; i <= w; i++) { dp.w(i, 0) = i; dp.w(0, i) = i; }
     for (j = 1; j <= w; j++)
         for (i = 1; i <= j + w; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
-    for (j = w + 1; j <= n - w; j++)
+    // (the reference runs this loop to n - w even when that is beyond column m; those columns read an unset border cell and
+    // feed nothing back into columns <= m, so they are not computed here)
+    for (j = w + 1; j <= std::min(n - w, m); j++)
         for (i = j - w; i <= j + w; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
     for (j = n - w + 1; j <= m; j++)
         for (i = j - w; i <= n; i++) dp.w(i, j) = min3(dp.r(i - 1, j - 1) + D(i, j), dp.r(i - 1, j) + 1, dp.r(i, j - 1) + 1);
@@ -580,6 +583,27 @@ int local_alignment_sc(const Ctx &c, const uint8_t *s, int n, const uint8_t *t, 
         else best.update(cand);         // best.update(...) align.cpp:683
     }
     align_score = score;
+    sc_len = best.sclen;
+    indel = best.indel;
+    return best.ed;
+}
+
+// EditDistAlignment::local_alignment_right_sc / _left_sc, src/align.cpp:602-660 (stage 2 only): full banded edit DP, then the
+// best (soft clip, indel) end cell under AlignCandid's order; align_score = m - sclen - 2 ed.
+int local_alignment_sc_edit(const Ctx &c, const uint8_t *s, int n, const uint8_t *t, int m, int &sc_len, int &indel, int &align_score, bool left) {
+    const int max_sclen = std::min(c.P.max_sc, m);
+    const int max_indel = c.P.band;
+    const uint32_t max_edit = (uint32_t)c.P.max_ed;
+    Mat dp(std::max(std::max(n, m), 0) + 2 * c.P.band + 4, std::max(std::max(n, m), 0) + 2 * c.P.band + 4);
+    global_banded_alignment(dp, s, n, t, m, c.P.band, left);
+    AlignCandid best((int)max_edit + 1, c.P.max_sc + 1, max_indel + 1);
+    for (int j = m; j >= m - max_sclen; j--)
+        for (int i = std::max(0, j - max_indel); i <= std::min(j + max_indel, n); i++) {
+            int64_t v = dp.r(i, j);
+            if ((uint32_t)v <= max_edit) best.update(AlignCandid((int)v, m - j, j - i));
+        }
+    if (m <= c.P.max_ed) best.update(AlignCandid(m, 0, 0));
+    align_score = m - best.sclen - 2 * best.ed;
     sc_len = best.sclen;
     indel = best.indel;
     return best.ed;
@@ -927,8 +951,13 @@ typedef std::map<AllCoord, AlignRes> Memo;
 
 struct Ext {
     const Ctx &c;
-    explicit Ext(const Ctx &cc) : c(cc) {}
+    bool edit;      // false: DropAlignment (FilterRead's extensions), true: EditDistAlignment (ProcessCirc, process_circ.cpp:25)
+    explicit Ext(const Ctx &cc, bool edit_alignment = false) : c(cc), edit(edit_alignment) {}
     int band() const { return c.P.band; }
+    int local_sc(const uint8_t *s, int n, const uint8_t *t, int m, int &sc_len, int &indel, int &align_score, bool left) const {
+        return edit ? local_alignment_sc_edit(c, s, n, t, m, sc_len, indel, align_score, left)
+                    : local_alignment_sc(c, s, n, t, m, sc_len, indel, align_score, left);
+    }
 
     // extend_right_middle / extend_left_middle, extend.cpp:435-461 / :653-679
     bool extend_middle(uint32_t pos, uint32_t exon_len, const uint8_t *qseq, uint32_t qseq_len, int ed_th, AlignRes &best,
@@ -953,7 +982,7 @@ struct Ext {
         std::vector<uint8_t> ref;
         if (!pac2char(c, right ? pos + 1 : pos - ref_len, (int)ref_len, ref)) return;
         int sclen, indel, sc;
-        int edit_dist = local_alignment_sc(c, ref.data(), (int)ref_len, qseq, qseq_len, sclen, indel, sc, !right);
+        int edit_dist = local_sc(ref.data(), (int)ref_len, qseq, qseq_len, sclen, indel, sc, !right);
         uint32_t new_pos = right ? pos + qseq_len - indel : pos - qseq_len + indel;
         exon_res.set(new_pos, edit_dist, sclen, indel, qseq_len, sc);
         int actual_mapped_bp = qseq_len - sclen;
@@ -1131,7 +1160,7 @@ struct Ext {
         std::vector<uint8_t> ref;
         if (!consecutive && pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) {   // intron retention
             int sc;
-            min_ed = local_alignment_sc(c, ref.data(), ref_len, seq, seq_len, sclen_best, indel, sc, !right);
+            min_ed = local_sc(ref.data(), ref_len, seq, seq_len, sclen_best, indel, sc, !right);
             if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
                 uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;
                 curr.set(np, min_ed, sclen_best, indel, seq_len, sc);
@@ -1478,6 +1507,872 @@ void copy_chain(const Chain &s, cm_chain &d) {
     for (uint32_t i = 0; i < s.chain_len && i < CM_MAX_CHAIN_FRAGS; ++i) { d.rpos[i] = s.frags[i].rpos; d.qpos[i] = s.frags[i].qpos; }
 }
 
+
+// ==================================================================================================
+// Stage 2: ProcessCirc, src/process_circ.cpp -- back-splice-junction calling on the
+// CHIBSJ / CHI2BSJ pairs stage 1 left in the last round's remain files.  Restated function by function.
+// ==================================================================================================
+const int S2_FR = 0, S2_RF = 1, S2_CR = 20, S2_NCR = 21, S2_MCR = 22, S2_UD = 30, S2_NF = 40;   // process_circ.h:14-20
+const int S2_TOPCHAIN = 10;                 // process_circ.cpp:19
+const int S2_BPRES = 5, S2_INDELTH = 3;     // common.h:42,45
+const int S2_MAXHIT = 1000;                 // hash_table.cpp:6
+
+// RegionalHashTable, src/hash_table.cpp:28-119: window_size-mers of one gene's sequence, location = offset in the gene
+struct RegionalHT {
+    int ws = 0, size = 0;
+    uint32_t gene_spos = 0, gene_epos = 0;
+    std::vector<std::vector<uint32_t>> loc;   // kept up to MAXHIT entries per bucket
+    std::vector<uint32_t> cnt;                // frag_count (0 when it went above MAXHIT)
+    static int nuc(uint8_t ch) {
+        switch (ch) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; default: return -1; }
+    }
+    int hash_val(const uint8_t *seq) const {   // :99-109 (nuc_hval is indexed by uint8_t: bytes >= 128 read past the table there; -1 here)
+        int val = 0;
+        for (int i = 0; i < ws; ++i) {
+            int b = nuc(seq[i]);
+            if (b == -1) return -1;
+            val = (val << 2) | b;
+        }
+        return val;
+    }
+    void create(int window, uint32_t gs, uint32_t ge, const uint8_t *seq, uint32_t start, int len) {   // init + create_table :28-78
+        ws = window; size = 1 << (2 * ws); gene_spos = gs; gene_epos = ge;
+        loc.assign(size, std::vector<uint32_t>());
+        cnt.assign(size, 0);
+        if (len < ws) return;
+        uint32_t l = start;
+        for (int i = 0; i <= len - ws; i++) {
+            int hv = hash_val(seq + i);
+            if (hv >= 0 && hv < size) {
+                if (cnt[hv] < (uint32_t)S2_MAXHIT) loc[hv].push_back(l);
+                ++cnt[hv];
+            }
+            ++l;
+        }
+        for (int hv = 0; hv < size; ++hv)
+            if (cnt[hv] > (uint32_t)S2_MAXHIT) cnt[hv] = 0;
+    }
+};
+struct RKmer { const uint32_t *frags; uint32_t frag_count; int32_t qpos; };      // GIMatchedKmer copy made by ProcessCirc::chaining
+
+// chain_seeds_sorted_kbest2, src/chain.cpp:310-539.  Seed positions are offsets in the gene sequence; `shift` (the gene start)
+// is added only to the emitted fragments -- the annotation queries (get_upper_bound, check_junction) and the `repeats`
+// test are made with the UNSHIFTED offsets, as in the reference.
+void chain_seeds_sorted_kbest2(const Ctx &c, int seq_len, RKmer *fl, ChainList &best_chain, int kmer, int kmer_cnt, uint32_t shift) {
+    best_chain.best_chain_count = 0;
+    if (kmer_cnt <= 0) return;
+    const uint32_t max_best = (uint32_t)c.P.max_chain_len;
+    while (kmer_cnt >= 1 && fl[kmer_cnt - 1].frag_count <= 0) kmer_cnt--;
+    if (kmer_cnt <= 0) return;
+    std::vector<std::vector<Cell>> dp(kmer_cnt);
+    for (int ii = kmer_cnt - 1; ii >= 0; ii--) dp[ii].assign(fl[ii].frag_count, Cell{(double)kmer, -1, -1});
+    std::map<double, CellList> score2chain;
+    std::vector<uint32_t> lb_ind(kmer_cnt);
+    uint32_t max_exon_end = 0;
+    int ol_exons = -1;
+    for (int ii = kmer_cnt - 2; ii >= 0; ii--) {
+        RKmer *cur_mk = fl + ii;
+        uint32_t read_remain = (uint32_t)(seq_len - cur_mk->qpos - kmer);
+        for (int k = 0; k < kmer_cnt; k++) lb_ind[k] = 0;
+        for (uint32_t i = 0; i < cur_mk->frag_count; i++) {
+            const int32_t cur_info = (int32_t)cur_mk->frags[i];
+            uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
+            uint32_t max_lpos_lim = MAXUB;
+            for (int jj = ii + 1; jj < kmer_cnt; jj++) {
+                RKmer *pc = fl + jj;
+                if (pc->frag_count <= 0 || lb_ind[jj] >= pc->frag_count) continue;
+                if (cur_info + c.P.max_intron < (int32_t)pc->frags[lb_ind[jj]]) continue;
+                while (lb_ind[jj] < pc->frag_count && (int32_t)pc->frags[lb_ind[jj]] <= cur_info) lb_ind[jj]++;
+                if (lb_ind[jj] >= pc->frag_count) continue;
+                if (max_lpos_lim == MAXUB) max_lpos_lim = get_upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol_exons);
+                int distr = pc->qpos - cur_mk->qpos - kmer, read_dist = distr;
+                uint32_t j = lb_ind[jj];
+                while (j < pc->frag_count && pc->frags[j] <= max_lpos_lim) {
+                    uint32_t pinfo = pc->frags[j];
+                    int genome_dist, distt, trans_dist;
+                    if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
+                    else genome_dist = INF_I;
+                    if (std::abs(genome_dist - read_dist) <= c.P.max_ed) distt = genome_dist;
+                    else if (check_junction(c, seg_start, pinfo, ol_exons, kmer, read_dist, trans_dist)) distt = trans_dist;
+                    else { j++; continue; }
+                    int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
+                    double temp_score = dp[jj][j].score + 2e4 * kmer - 0.1 * (maxd - mind);     // score_alpha - score_beta, chain.cpp:13-22
+                    if (temp_score > dp[ii][i].score) {
+                        dp[ii][i] = Cell{temp_score, jj, (int)j};
+                        auto it = score2chain.find(temp_score);
+                        if (it == score2chain.end()) { CellList e; e.count = 0; it = score2chain.insert(std::make_pair(temp_score, e)).first; }
+                        if (it->second.count < max_best) it->second.chain_list[it->second.count++] = Cell{temp_score, ii, (int)i};
+                    }
+                    j++;
+                }
+            }
+        }
+    }
+    uint32_t best_count = 0;
+    double best_score = score2chain.empty() ? (double)kmer : score2chain.rbegin()->first;
+    std::set<uint32_t> repeats;
+    for (auto it = score2chain.rbegin(); it != score2chain.rend(); ++it)
+        for (uint32_t l = 0; l < it->second.count; l++) {
+            if (best_count >= max_best) break;
+            Cell bi = it->second.chain_list[l];
+            uint32_t spos = fl[bi.prev_list].frags[bi.prev_ind];
+            if (bi.score < best_score && repeats.find(spos) != repeats.end()) continue;
+            uint32_t i = 0, j = best_count++;
+            Chain &ch = best_chain.chains[j];
+            ch.frags.clear();
+            while (bi.prev_list != -1) {
+                Frag f{shift + fl[bi.prev_list].frags[bi.prev_ind], fl[bi.prev_list].qpos, (uint32_t)kmer};
+                ch.frags.push_back(f);
+                if (i != 0) repeats.insert(f.rpos);
+                int tl = bi.prev_list;
+                bi.prev_list = dp[tl][bi.prev_ind].prev_list;
+                bi.prev_ind = dp[tl][bi.prev_ind].prev_ind;
+                i++;
+            }
+            ch.score = (float)bi.score;
+            ch.chain_len = i;
+        }
+    if (best_count == 0)
+        for (int ii = kmer_cnt - 1; ii >= 0; ii--)
+            for (uint32_t i = 0; i < fl[ii].frag_count; i++) {
+                if (best_count >= max_best) break;
+                Chain &ch = best_chain.chains[best_count++];
+                ch.frags.assign(1, Frag{shift + fl[ii].frags[i], fl[ii].qpos, (uint32_t)kmer});
+                ch.score = (float)dp[ii][i].score;
+                ch.chain_len = 1;
+            }
+    best_chain.best_chain_count = (int)best_count;
+}
+
+struct Junc { uint32_t beg, end, bp_matched; };
+struct CircRes2 {      // CircRes, src/common.h:406-423
+    int chr_id = -1;
+    uint32_t spos = 0, epos = 0;
+    int type = S2_NF;
+    std::string start_signal, end_signal, start_bp_ref, end_bp_ref;
+    void set_bp(uint32_t sp, uint32_t ep, const std::string &ss, const std::string &es, const std::string &sb, const std::string &eb) {
+        spos = sp; epos = ep; start_signal = ss; end_signal = es; start_bp_ref = sb; end_bp_ref = eb;
+    }
+};
+std::string consensus2(const std::string &a, const std::string &b) {     // get_consensus(s1, s2), utils.cpp:746-756
+    std::string r;
+    if (a.length() != b.length()) return r;
+    for (size_t i = 0; i < a.length(); ++i) r += (a[i] == b[i]) ? a[i] : 'N';
+    return r;
+}
+
+struct CircCaller {
+    Ctx c;                    // current contig
+    Ext ext;
+    int ws;                   // window_size of the regional tables (ProcessCirc ctor argument)
+    const int step = 3;       // process_circ.cpp:59
+    // member state of ProcessCirc that lives across the calls made for one read (process_circ.h:31-41)
+    const uint8_t *fullmap_seq = nullptr, *remain_seq = nullptr, *r1_seq = nullptr, *r2_seq = nullptr;
+    uint32_t fullmap_seq_len = 0, remain_seq_len = 0, r1_seq_len = 0, r2_seq_len = 0;
+    ChainList bc1, bc2;
+    // outputs
+    std::string candid;       // <out>.candidates.pam
+    struct Call { int chr_id; uint32_t spos, epos; int type; uint64_t rec; std::string ss, es, sb, eb; };
+    std::vector<Call> calls;  // circ_res
+    const char *const *chr_names;
+    uint64_t cur_rec = 0;
+    const char *cur_name = "";
+
+    CircCaller(const Ctx &cc, int window, const char *const *names) : c(cc), ext(c, true), ws(window), chr_names(names) {
+        int max_kmer_cnt = (c.P.max_read_len - ws) / step + 1;
+        bc1.chains.resize(c.P.max_chain_len); bc2.chains.resize(c.P.max_chain_len);
+        for (auto &ch : bc1.chains) ch.frags.reserve(max_kmer_cnt);
+        for (auto &ch : bc2.chains) ch.frags.reserve(max_kmer_cnt);
+    }
+
+    // a character of a read the reference indexes without a bounds check (process_circ.cpp:1295-1296 and friends): out of
+    // range is defined as NUL here (index seq_len IS the terminator in the reference)
+    static char at(const uint8_t *s, uint32_t len, int64_t i) { return (s && i >= 0 && i < (int64_t)len) ? (char)s[i] : '\0'; }
+    static std::string two(const uint8_t *s, uint32_t len, int64_t i) { std::string r; r += at(s, len, i); r += at(s, len, i + 1); return r; }
+    std::string ref_bp(uint32_t start, int len) const {   // pac2char_otf(start, len, buf) + string(buf); failure leaves buf unset there, "" here
+        std::vector<uint8_t> b;
+        if (!pac2char_otf(start, len, b)) return std::string();
+        return std::string((const char *)b.data());
+    }
+    // GenomeSeeder::pac2char_otf, src/match_read.cpp:301-332: like pac2char but decodes the packed words, so position 0 has no meaning
+    // (start - 1 underflows): defined as failure here
+    bool pac2char_otf(uint32_t start, int len, std::vector<uint8_t> &out) const {
+        int ref_len = (int)c.X->ref_len;
+        if ((int)start < 0 || (int)start + len - 1 > ref_len || start == 0) return false;
+        out.assign((size_t)std::max(len, 0) + 1, 0);
+        for (int i = 0; i < len; ++i) out[i] = c.X->genome[start - 1 + i];
+        return true;
+    }
+    int gene_overlap(uint32_t pos) const {     // GTFParser::get_gene_overlap(pos, false), gene_annotation.cpp:572-585 -> interval index or -1
+        const cm_annot_view *A = c.A;
+        if (A->n_giv == 0 || pos < A->giv_spos[0]) return -1;
+        int beg = 0, end = (int)A->n_giv;
+        while (end - beg > 1) { int mid = (beg + end) / 2; if (pos < A->giv_spos[mid]) end = mid; else beg = mid; }
+        int ind = end - 1;
+        if (ind < 0 || A->giv_epos[ind] < pos) return -1;
+        if (A->giv_gene_off[ind + 1] == A->giv_gene_off[ind]) return -1;
+        return ind;
+    }
+
+    // set_mm, process_circ.cpp:1710-1752
+    void set_mm(const Chain &ch, uint32_t qspos, int rlen, int dir, MatchedMate &mm) const {
+        uint32_t spos = ch.frags[0].rpos, epos = ch.frags[ch.chain_len - 1].rpos + ch.frags[ch.chain_len - 1].len - 1;
+        uint32_t qepos = qspos + rlen - 1;
+        mm.spos = spos; mm.epos = epos; mm.qspos = qspos; mm.qepos = qepos;            // MatchedMate::set, common.cpp:154-161
+        mm.matched_len = (qepos + 1 >= qspos) ? (qepos - qspos + 1) : 0;
+        mm.dir = dir;
+    }
+    // MatchedMate(const MatchedRead&, r1_2, rlen, partial), common.cpp:196-243
+    MatchedMate mate_of(const cm_mapped_read &mr, int r1_2, int rlen, bool partial) const {
+        MatchedMate m(c);
+        m.type = mr.type; m.right_ed = 0; m.left_ed = 0;
+        if (r1_2 == 1) { m.spos = mr.spos_r1; m.epos = mr.epos_r1; m.qspos = mr.qspos_r1; m.qepos = mr.qepos_r1; m.middle_ed = mr.ed_r1; m.matched_len = mr.mlen_r1; m.dir = mr.r1_forward ? 1 : -1; }
+        else { m.spos = mr.spos_r2; m.epos = mr.epos_r2; m.qspos = mr.qspos_r2; m.qepos = mr.qepos_r2; m.middle_ed = mr.ed_r2; m.matched_len = mr.mlen_r2; m.dir = mr.r2_forward ? 1 : -1; }
+        if (partial) {
+            if ((m.qspos - 1) > (uint32_t)(rlen - (int)m.qepos)) { m.sclen_left = 0; m.sclen_right = rlen - (int)m.qepos; }
+            else { m.sclen_left = (int)m.qspos - 1; m.sclen_right = 0; }
+        } else { m.sclen_left = (int)m.qspos - 1; m.sclen_right = rlen - (int)m.qepos; }
+        // the ctor leaves junc_num / is_concord / left_ok / right_ok unset in the reference; nothing downstream reads them
+        return m;
+    }
+    // MatchedMate::merge_to_right, common.cpp:163-193
+    bool merge_to_right(MatchedMate &l, const MatchedMate &r) const {
+        if (l.dir != r.dir) return false;
+        l.epos = r.epos; l.qepos = r.qepos;
+        l.middle_ed += l.right_ed + r.left_ed;
+        l.right_ed = r.right_ed;
+        l.matched_len += r.matched_len + l.sclen_right + r.sclen_left;
+        l.middle_ed += l.sclen_right + r.sclen_left;
+        l.sclen_right = r.sclen_right;
+        l.right_ok = r.right_ok;
+        l.looked_up_epos = r.looked_up_epos;
+        l.exon_ind_epos = r.exon_ind_epos;
+        return !(l.left_ed + l.middle_ed + l.right_ed > c.P.max_ed);
+    }
+    void tids_of(int iv, std::vector<uint32_t> &out) const {
+        const cm_annot_view *A = c.A;
+        for (uint32_t i = 0; i < iv_nseg(A, iv); i++) { uint32_t g = iv_segid(A, iv, i); for (uint32_t k = A->seg_tid_off[g]; k < A->seg_tid_off[g + 1]; k++) out.push_back(A->seg_tid[k]); }
+    }
+    static void intersect_trans(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, std::vector<uint32_t> &out) {   // utils.cpp:322-333
+        for (uint32_t x : a) for (uint32_t y : b) if (x == y) { out.push_back(x); break; }
+    }
+    // the 3- and 4-interval forms, utils.cpp:356-398 (the 3-interval form intersects (s ^ r) with s again, not with q)
+    bool same_tr3(int s, int r, int q, std::vector<uint32_t> &common) const {
+        common.clear();
+        if (s < 0 || r < 0 || q < 0) return false;
+        std::vector<uint32_t> sr;
+        if (!same_transcript(c, s, r, sr)) return false;
+        std::vector<uint32_t> st;
+        tids_of(s, st);
+        intersect_trans(sr, st, common);
+        return !common.empty();
+    }
+    bool same_tr4(int s, int r, int q, int p, std::vector<uint32_t> &common) const {
+        common.clear();
+        if (s < 0 || r < 0 || q < 0 || p < 0) return false;
+        std::vector<uint32_t> sr, qp;
+        if (!same_transcript(c, s, r, sr)) return false;
+        if (!same_transcript(c, q, p, qp)) return false;
+        intersect_trans(sr, qp, common);
+        return !common.empty();
+    }
+    // same_transcript(vector<MatchedMate>&, size, common_tid), utils.cpp:419-599: tries start/end combinations in a fixed order
+    bool same_transcript_n(std::vector<MatchedMate> &g, int size, std::vector<uint32_t> &common) const {
+        auto S = [&](int i) { return g[i].exons_spos; };
+        auto E = [&](int i) { return g[i].exons_epos; };
+        if (size == 2) {
+            overlap_to_spos(c, g[0]); overlap_to_spos(c, g[1]);
+            if (same_transcript(c, S(0), S(1), common)) return true;
+            overlap_to_epos(c, g[1]);
+            if (same_transcript(c, S(0), E(1), common)) return true;
+            overlap_to_epos(c, g[0]);
+            if (same_transcript(c, E(0), S(1), common)) return true;
+            if (same_transcript(c, E(0), E(1), common)) return true;
+        }
+        if (size == 3) {
+            overlap_to_spos(c, g[0]); overlap_to_spos(c, g[1]); overlap_to_spos(c, g[2]);
+            if (same_tr3(S(0), S(1), S(2), common)) return true;
+            overlap_to_epos(c, g[2]);
+            if (same_tr3(S(0), S(1), E(2), common)) return true;
+            overlap_to_epos(c, g[1]);
+            if (same_tr3(S(0), E(1), S(2), common)) return true;
+            if (same_tr3(S(0), E(1), E(2), common)) return true;
+            overlap_to_epos(c, g[0]);
+            if (same_tr3(E(0), S(1), S(2), common)) return true;
+            if (same_tr3(E(0), S(1), E(2), common)) return true;
+            if (same_tr3(E(0), E(1), S(2), common)) return true;
+            if (same_tr3(E(0), E(1), E(2), common)) return true;
+        }
+        if (size == 4) {
+            overlap_to_spos(c, g[0]); overlap_to_spos(c, g[1]); overlap_to_spos(c, g[2]); overlap_to_spos(c, g[3]);
+            if (same_tr4(S(0), S(1), S(2), S(3), common)) return true;
+            overlap_to_epos(c, g[2]);
+            if (same_tr4(S(0), S(1), E(2), S(3), common)) return true;
+            overlap_to_epos(c, g[1]);
+            if (same_tr4(S(0), E(1), S(2), S(3), common)) return true;
+            if (same_tr4(S(0), E(1), E(2), S(3), common)) return true;
+            overlap_to_epos(c, g[0]);
+            if (same_tr4(E(0), S(1), S(2), S(3), common)) return true;
+            if (same_tr4(E(0), S(1), E(2), S(3), common)) return true;
+            if (same_tr4(E(0), E(1), S(2), S(3), common)) return true;
+            if (same_tr4(E(0), E(1), E(2), S(3), common)) return true;
+            overlap_to_epos(c, g[3]);
+            if (same_tr4(S(0), S(1), S(2), E(3), common)) return true;
+            if (same_tr4(S(0), S(1), E(2), E(3), common)) return true;
+            if (same_tr4(S(0), E(1), S(2), E(3), common)) return true;
+            if (same_tr4(S(0), E(1), E(2), E(3), common)) return true;
+            if (same_tr4(E(0), S(1), S(2), E(3), common)) return true;
+            if (same_tr4(E(0), S(1), E(2), E(3), common)) return true;
+            if (same_tr4(E(0), E(1), S(2), E(3), common)) return true;
+            if (same_tr4(E(0), E(1), E(2), E(3), common)) return true;
+        }
+        return false;
+    }
+    // get_junctions, utils.cpp:686-744
+    void get_junctions(MatchedMate &mm, std::vector<Junc> &ji) const {
+        const cm_annot_view *A = c.A;
+        overlap_to_spos(c, mm);
+        overlap_to_epos(c, mm);
+        ji.clear();
+        if (mm.exons_spos < 0 || mm.exons_epos < 0) return;
+        auto push = [&](uint32_t b, uint32_t e, uint32_t m) { if (b >= e) return; ji.push_back(Junc{b, e, m}); };
+        for (uint32_t i = 0; i < iv_nseg(A, mm.exons_spos); ++i) {
+            uint32_t sg = iv_segid(A, mm.exons_spos, i);
+            for (uint32_t k = A->seg_tid_off[sg]; k < A->seg_tid_off[sg + 1]; ++k) {
+                uint32_t tid = A->seg_tid[k];
+                int start_ind = A->trans_start_ind[tid];
+                uint32_t start_table_ind = (uint32_t)(mm.exon_ind_spos - start_ind);
+                uint32_t end_table_ind = (uint32_t)(mm.exon_ind_epos - start_ind);
+                uint32_t tsz = A->t2s_off[tid + 1] - A->t2s_off[tid];
+                const uint8_t *t2s = A->t2s + A->t2s_off[tid];
+                if (mm.exon_ind_epos < start_ind || end_table_ind >= tsz || t2s[end_table_ind] == 0) continue;
+                if (start_table_ind == end_table_ind) return;
+                uint32_t junc_start = A->iv_epos[mm.exons_spos];
+                uint32_t covered = A->iv_epos[mm.exons_spos] - mm.spos + 1;
+                int this_it_ind = mm.exon_ind_spos;
+                for (uint32_t q = start_table_ind + 1; q < end_table_ind; q++) {
+                    this_it_ind++;
+                    if (q < tsz && t2s[q] != 0) {       // q >= tsz (start index beyond the table) is an out-of-bounds vector read there
+                        push(junc_start, A->iv_spos[this_it_ind], covered);
+                        covered += A->iv_epos[this_it_ind] - A->iv_spos[this_it_ind] + 1;
+                        junc_start = A->iv_epos[this_it_ind];
+                    }
+                }
+                push(junc_start, A->iv_spos[mm.exons_epos], covered);
+                covered += mm.epos - A->iv_spos[mm.exons_epos] + 1;
+                if (std::abs((int32_t)(covered - mm.matched_len)) <= S2_INDELTH) return;
+                ji.clear();
+            }
+        }
+    }
+
+    // ProcessCirc::chaining, process_circ.cpp:677-737
+    void chaining(uint32_t qspos, uint32_t qepos, const RegionalHT &ht, const uint8_t *seq, uint32_t shift, ChainList &bc) {
+        int seq_len = (int)qepos - (int)qspos + 1;
+        if (seq_len < ws) { bc.best_chain_count = 0; return; }
+        int kmer_cnt = (seq_len - ws) / step + 1;
+        std::vector<RKmer> fl(kmer_cnt + 1);
+        int l = 0;
+        for (uint32_t i = qspos - 1; i <= qepos - ws; i += step) {
+            int hv = ht.hash_val(seq + i);
+            if (hv < 0 || hv >= ht.size) continue;       // find_hash == NULL: an N inside the k-mer
+            fl[l] = RKmer{ht.loc[hv].data(), ht.cnt[hv], (int32_t)i};
+            if (fl[l].frag_count > (uint32_t)c.P.seed_lim) fl[l].frag_count = 0;
+            l++;
+        }
+        kmer_cnt = l;
+        chain_seeds_sorted_kbest2(c, (int)qepos, fl.data(), bc, ws, kmer_cnt, shift);
+        int least_miss = INF_I;
+        for (int j = 0; j < bc.best_chain_count; j++) {
+            int missing = kmer_cnt - (int)bc.chains[j].chain_len;
+            if (missing > least_miss) { bc.best_chain_count = j; break; }
+            least_miss = missing;
+        }
+    }
+
+    // ProcessCirc::find_exact_coord, process_circ.cpp:739-789
+    bool find_exact_coord(MatchedMate &mm_r1, MatchedMate &mm_r2, MatchedMate &partial_mm, int dir, uint32_t qspos, const uint8_t *rseq,
+                          int rlen, int whole_len, const Chain &bc) {
+        set_mm(bc, qspos, rlen, dir, partial_mm);
+        --qspos;
+        overlap_to_spos(c, mm_r1); overlap_to_spos(c, mm_r2); overlap_to_spos(c, partial_mm);
+        std::vector<uint32_t> common_tid;
+        std::vector<MatchedMate> segments{mm_r1, mm_r2, partial_mm};
+        if (!same_transcript_n(segments, 3, common_tid)) return false;
+        partial_mm.middle_ed = ext.calc_middle_ed(bc, c.P.max_ed, rseq, rlen);
+        if (partial_mm.middle_ed > c.P.max_ed) return false;
+        partial_mm.is_concord = false;
+        if (bc.chain_len <= 0) { partial_mm.type = CM_ORPHAN; partial_mm.matched_len = 0; return false; }
+        int err = partial_mm.middle_ed;
+        partial_mm.matched_len = (uint32_t)rlen;
+        bool lok = ext.extend_chain_left(common_tid, bc, rseq + qspos, (int32_t)qspos, MINLB, partial_mm, err);
+        bool rok = ext.extend_chain_right(common_tid, bc, rseq, qspos == 0 ? rlen : whole_len, MAXUB, partial_mm, err);
+        update_match_mate_info(c, lok, rok, err, partial_mm);
+        return partial_mm.type == CM_CONCRD;
+    }
+
+    // the (transcript, offset) lists of final_check / check_split_map: exon ends within BPRES of the left piece's end, exon starts
+    // within BPRES of the right piece's start, walking the intervals the piece covers (process_circ.cpp:973-1009, 1193-1243).
+    // get_interval(ind) == NULL (ind off either end of the table) is dereferenced by the reference; the walk stops there here.
+    typedef std::pair<uint32_t, int> pu32i;
+    void end_tids_of(const MatchedMate &m, std::vector<pu32i> &out) const {
+        const cm_annot_view *A = c.A;
+        int ind = m.exon_ind_epos;
+        while (ind >= 0 && ind < (int)A->n_iv && m.spos < A->iv_epos[ind]) {
+            for (uint32_t i = 0; i < iv_nseg(A, ind); ++i) {
+                uint32_t sg = iv_segid(A, ind, i);
+                int diff = (int)(m.epos + m.sclen_right - A->seg_end[sg]);
+                if (std::abs(diff) <= S2_BPRES) for (uint32_t k = A->seg_tid_off[sg]; k < A->seg_tid_off[sg + 1]; ++k) out.push_back(pu32i(A->seg_tid[k], diff));
+            }
+            --ind;
+        }
+    }
+    void start_tids_of(const MatchedMate &m, std::vector<pu32i> &out) const {
+        const cm_annot_view *A = c.A;
+        int ind = m.exon_ind_spos;
+        while (ind >= 0 && ind < (int)A->n_iv && m.epos > A->iv_spos[ind]) {
+            for (uint32_t i = 0; i < iv_nseg(A, ind); ++i) {
+                uint32_t sg = iv_segid(A, ind, i);
+                int diff = (int)(m.spos - m.sclen_left - A->seg_start[sg]);
+                if (std::abs(diff) <= S2_BPRES) for (uint32_t k = A->seg_tid_off[sg]; k < A->seg_tid_off[sg + 1]; ++k) out.push_back(pu32i(A->seg_tid[k], diff));
+            }
+            ++ind;
+        }
+    }
+
+    // ProcessCirc::split_realignment (6-argument form), process_circ.cpp:1343-1392
+    int split_realignment6(uint32_t qcutpos, uint32_t beg_bp, uint32_t end_bp, const uint8_t *seq, uint32_t seq_len, const std::vector<uint32_t> &common_tid) {
+        const int maxEd = c.P.max_ed;
+        if (qcutpos <= 0 || qcutpos >= seq_len) return maxEd + 1;
+        std::vector<uint8_t> bp;
+        int last_bp_err = (pac2char_otf(end_bp, 1, bp) && seq[qcutpos - 1] == bp[0]) ? 0 : 1;
+        int first_bp_err = (pac2char_otf(beg_bp, 1, bp) && seq[qcutpos] == bp[0]) ? 0 : 1;
+        uint32_t lm_pos = end_bp, rm_pos = beg_bp, lb = beg_bp, ub = end_bp;
+        AlignRes bl(lb), br(ub);
+        bool lok = ext.extend_side(common_tid, seq, lm_pos, (int)qcutpos - 1, maxEd - last_bp_err, lb, bl, false);
+        bool rok = ext.extend_side(common_tid, seq + qcutpos + 1, rm_pos, (int)(seq_len - qcutpos - 1), maxEd - first_bp_err, ub, br, true);
+        bl.ed += last_bp_err;
+        br.ed += first_bp_err;
+        if (lok && rok && (bl.ed + br.ed) <= maxEd) return bl.ed + br.ed;
+        return maxEd + 1;
+    }
+    // ProcessCirc::split_realignment (5-argument form), process_circ.cpp:1394-1486
+    int split_realignment5(uint32_t qcutpos, MatchedMate &full_mm, MatchedMate &split_mm_left, MatchedMate &split_mm_right, CircRes2 &cr) {
+        const int maxEd = c.P.max_ed;
+        if (qcutpos <= 0 || qcutpos >= fullmap_seq_len) return S2_UD;
+        qcutpos += full_mm.qspos - 1;
+        if (qcutpos <= 0 || qcutpos >= fullmap_seq_len) return S2_UD;
+        overlap_to_spos(c, split_mm_left); overlap_to_epos(c, split_mm_left);
+        overlap_to_spos(c, split_mm_right); overlap_to_epos(c, split_mm_right);
+        std::vector<uint32_t> common_tid;
+        std::vector<MatchedMate> segments{split_mm_left, split_mm_right};
+        if (!same_transcript_n(segments, 2, common_tid)) return S2_UD;
+        std::vector<uint8_t> bp;
+        int last_bp_err = (pac2char_otf(split_mm_left.epos, 1, bp) && fullmap_seq[qcutpos - 1] == bp[0]) ? 0 : 1;
+        int first_bp_err = (pac2char_otf(split_mm_right.spos, 1, bp) && fullmap_seq[qcutpos] == bp[0]) ? 0 : 1;
+        uint32_t lm_pos = split_mm_left.epos, rm_pos = split_mm_right.spos, lb = split_mm_right.spos, ub = split_mm_left.epos;
+        AlignRes bl(lb), br(ub);
+        bool lok = ext.extend_side(common_tid, fullmap_seq, lm_pos, (int)qcutpos - 1, maxEd - last_bp_err, lb, bl, false);
+        bool rok = ext.extend_side(common_tid, fullmap_seq + qcutpos + 1, rm_pos, (int)(fullmap_seq_len - qcutpos - 1), maxEd - first_bp_err, ub, br, true);
+        bl.ed += last_bp_err;
+        br.ed += first_bp_err;
+        if (!lok || !rok || (bl.ed + br.ed) > maxEd) return S2_UD;
+        MatchedMate nl(c), nr(c);       // default-constructed there: type ORPHAN, *_ed = maxEd + 1 until overwritten, lookups unset
+        nl.spos = lm_pos; nl.epos = split_mm_left.epos; nl.qspos = (uint32_t)bl.sclen; nl.qepos = qcutpos; nl.dir = full_mm.dir;
+        nl.matched_len = qcutpos - (uint32_t)bl.sclen; nl.sclen_left = bl.sclen; nl.sclen_right = 0; nl.left_ed = bl.ed; nl.right_ed = 0;
+        nl.middle_ed = 0; nl.left_ok = true; nl.right_ok = true;
+        nr.spos = split_mm_right.spos; nr.epos = rm_pos; nr.qspos = qcutpos + 1; nr.qepos = fullmap_seq_len - (uint32_t)br.sclen; nr.dir = full_mm.dir;
+        nr.matched_len = fullmap_seq_len - qcutpos - (uint32_t)br.sclen; nr.sclen_left = 0; nr.sclen_right = br.sclen; nr.left_ed = 0;
+        nr.right_ed = br.ed; nr.middle_ed = 0; nr.left_ok = true; nr.right_ok = true;
+        r1_seq = remain_seq; r2_seq = fullmap_seq; r1_seq_len = remain_seq_len; r2_seq_len = fullmap_seq_len;
+        return check_split_map4(split_mm_right, nr, split_mm_left, nl, cr);
+    }
+    // ProcessCirc::rescue_overlapping_bsj, process_circ.cpp:1488-1552
+    int rescue_overlapping_bsj(MatchedMate &full_mm, MatchedMate &split_mm_left, MatchedMate &split_mm_right, CircRes2 &cr) {
+        std::vector<Junc> ji;
+        if (split_mm_right.spos <= full_mm.epos && split_mm_right.spos > full_mm.spos) {
+            get_junctions(full_mm, ji);
+            uint32_t qcutpos = 0;
+            for (auto &j : ji) if (j.end == split_mm_right.spos) qcutpos = j.bp_matched;
+            if (qcutpos == 0) qcutpos = split_mm_right.spos - full_mm.spos;
+            if (split_realignment5(qcutpos, full_mm, split_mm_left, split_mm_right, cr) == S2_CR) return S2_CR;
+        }
+        if (split_mm_left.epos >= full_mm.spos && split_mm_left.epos < full_mm.epos) {
+            get_junctions(full_mm, ji);
+            uint32_t qcutpos = 0;
+            for (auto &j : ji) if (j.beg == split_mm_left.epos) qcutpos = j.bp_matched;
+            if (qcutpos == 0) qcutpos = full_mm.matched_len - (full_mm.epos - split_mm_left.epos);
+            if (split_realignment5(qcutpos, full_mm, split_mm_left, split_mm_right, cr) == S2_CR) return S2_CR;
+        }
+        return S2_UD;
+    }
+    // ProcessCirc::final_check, process_circ.cpp:1136-1341
+    int final_check(MatchedMate &full_mm, MatchedMate &sl, MatchedMate &sr, CircRes2 &cr) {
+        const int maxEd = c.P.max_ed, maxSc = c.P.max_sc;
+        if (sl.epos < sr.spos) {
+            if (full_mm.dir == 1) {
+                if (full_mm.spos <= sl.spos) return S2_FR;
+                else if (full_mm.epos >= sr.epos) return S2_RF;
+            }
+            if (full_mm.dir == -1) {
+                if (full_mm.epos >= sr.epos) return S2_FR;
+                else if (full_mm.spos <= sl.spos) return S2_RF;
+            }
+        } else if (sr.spos <= sl.spos && sl.epos >= sr.epos) {
+            if (full_mm.spos < sr.spos) {
+                int off = (int)(sr.spos - full_mm.spos), sc_remained = maxSc - full_mm.sclen_left;
+                if (off <= sc_remained) { full_mm.spos = sr.spos; full_mm.sclen_left += off; full_mm.qspos += off; full_mm.matched_len -= off; }
+            }
+            if (full_mm.epos > sl.epos) {
+                int off = (int)(full_mm.epos - sl.epos), sc_remained = maxSc - full_mm.sclen_right;
+                if (off <= sc_remained) { full_mm.epos = sl.epos; full_mm.sclen_right += off; full_mm.qepos -= off; full_mm.matched_len -= off; }
+            }
+            if (full_mm.spos >= sr.spos && full_mm.epos <= sl.epos) {
+                overlap_to_spos(c, full_mm); overlap_to_epos(c, full_mm);
+                overlap_to_spos(c, sr); overlap_to_epos(c, sr);
+                overlap_to_spos(c, sl); overlap_to_epos(c, sl);
+                std::vector<pu32i> end_tids, start_tids;
+                end_tids_of(sl, end_tids);
+                start_tids_of(sr, start_tids);
+                int best_ed = maxEd + 1;
+                std::vector<uint32_t> common_tid;
+                for (size_t i = 0; i < start_tids.size(); ++i)
+                    for (size_t j = 0; j < end_tids.size(); ++j) {
+                        int sdiff = start_tids[i].second, ediff = end_tids[j].second;
+                        if (!(start_tids[i].first == end_tids[j].first && sdiff == ediff)) continue;
+                        common_tid.assign(1, start_tids[i].first);
+                        uint32_t qcutpos = sl.qepos + sl.sclen_right - ediff;
+                        uint32_t beg_bp = sr.spos - sr.sclen_left - sdiff;
+                        uint32_t end_bp = sl.epos + sl.sclen_right - ediff;
+                        if (full_mm.sclen_right > 0) {
+                            if (full_mm.epos + full_mm.sclen_right > end_bp) {
+                                uint32_t fm_qcutpos = full_mm.qepos + (end_bp - full_mm.epos);
+                                if (split_realignment6(fm_qcutpos, beg_bp, end_bp, fullmap_seq, fullmap_seq_len, common_tid) > maxEd) continue;
+                            } else if (full_mm.sclen_right > maxSc) continue;
+                        }
+                        if (full_mm.sclen_left > 0) {
+                            if (full_mm.spos - full_mm.sclen_left < beg_bp) {
+                                uint32_t fm_qcutpos = full_mm.sclen_left + (full_mm.spos - beg_bp);
+                                if (split_realignment6(fm_qcutpos, beg_bp, end_bp, fullmap_seq, fullmap_seq_len, common_tid) > maxEd) continue;
+                            } else if (full_mm.sclen_left > maxSc) continue;
+                        }
+                        int ed = split_realignment6(qcutpos, beg_bp, end_bp, remain_seq, remain_seq_len, common_tid);
+                        if (ed < best_ed) {
+                            std::string esignal = two(remain_seq, remain_seq_len, (int64_t)qcutpos - 2), ssignal = two(remain_seq, remain_seq_len, qcutpos);
+                            cr.set_bp(beg_bp, end_bp, ssignal, esignal, ref_bp(beg_bp, 2), ref_bp(end_bp - 1, 2));
+                            if (ed == 0) return S2_CR;
+                            best_ed = ed;
+                        }
+                    }
+                if (best_ed <= maxEd) return S2_CR;
+                uint32_t qcutpos = sl.qepos + sl.sclen_right, beg_bp = sr.spos - sr.sclen_left, end_bp = sl.epos + sl.sclen_right;
+                if (qcutpos < 2 || qcutpos > (remain_seq_len - 2)) return S2_MCR;
+                // (the reference swaps the two names here: "ssignal" holds the two bases before the cut)
+                std::string ssignal = two(remain_seq, remain_seq_len, (int64_t)qcutpos - 2), esignal = two(remain_seq, remain_seq_len, qcutpos);
+                cr.set_bp(beg_bp, end_bp, ssignal, esignal, ref_bp(beg_bp, 2), ref_bp(end_bp - 1, 2));
+                if (!start_tids.empty() && !end_tids.empty()) return S2_NCR;
+                return S2_MCR;
+            }
+        }
+        return rescue_overlapping_bsj(full_mm, sl, sr, cr);
+    }
+    // ProcessCirc::check_split_map (non-overlapping split mates), process_circ.cpp:892-921
+    int check_split_map3(MatchedMate &mm_r1, MatchedMate &mm_r2, MatchedMate &partial_mm, bool r1_partial, CircRes2 &cr) {
+        int valid, split_read_ed;
+        if (r1_partial) {
+            split_read_ed = mm_r1.right_ed + mm_r1.left_ed + mm_r1.middle_ed + partial_mm.right_ed + partial_mm.left_ed + partial_mm.middle_ed;
+            valid = (mm_r1.qspos < partial_mm.qspos) ? final_check(mm_r2, mm_r1, partial_mm, cr) : final_check(mm_r2, partial_mm, mm_r1, cr);
+        } else {
+            split_read_ed = mm_r2.right_ed + mm_r2.left_ed + mm_r2.middle_ed + partial_mm.right_ed + partial_mm.left_ed + partial_mm.middle_ed;
+            valid = (mm_r2.qspos < partial_mm.qspos) ? final_check(mm_r1, mm_r2, partial_mm, cr) : final_check(mm_r1, partial_mm, mm_r2, cr);
+        }
+        if (split_read_ed > c.P.max_ed) valid = S2_UD;
+        return valid;
+    }
+    // ProcessCirc::check_split_map (overlapping split mates), process_circ.cpp:924-1134
+    int check_split_map4(MatchedMate &mm_r1_1, MatchedMate &mm_r2_1, MatchedMate &mm_r1_2, MatchedMate &mm_r2_2, CircRes2 &cr) {
+        const int maxEd = c.P.max_ed;
+        int r1_ed = mm_r1_1.right_ed + mm_r1_1.left_ed + mm_r1_1.middle_ed + mm_r1_2.right_ed + mm_r1_2.left_ed + mm_r1_2.middle_ed;
+        int r2_ed = mm_r2_1.right_ed + mm_r2_1.left_ed + mm_r2_1.middle_ed + mm_r2_2.right_ed + mm_r2_2.left_ed + mm_r2_2.middle_ed;
+        if (r1_ed > maxEd || r2_ed > maxEd) return S2_UD;
+        MatchedMate mm_r1_l = (mm_r1_1.spos <= mm_r1_2.spos) ? mm_r1_1 : mm_r1_2, mm_r1_r = (mm_r1_1.spos <= mm_r1_2.spos) ? mm_r1_2 : mm_r1_1;
+        MatchedMate mm_r2_l = (mm_r2_1.spos <= mm_r2_2.spos) ? mm_r2_1 : mm_r2_2, mm_r2_r = (mm_r2_1.spos <= mm_r2_2.spos) ? mm_r2_2 : mm_r2_1;
+        bool r1_regular_bsj = (mm_r1_l.qspos < mm_r1_r.qspos), r2_regular_bsj = (mm_r2_l.qspos < mm_r2_r.qspos);
+        if (r1_regular_bsj && r2_regular_bsj) {
+            if (mm_r1_l.dir == 1) {
+                if (mm_r1_r.spos <= mm_r2_l.spos) return S2_FR;
+                else if (mm_r1_l.epos >= mm_r2_r.epos) return S2_RF;
+            }
+            if (mm_r1_l.dir == -1) {
+                if (mm_r2_r.spos <= mm_r1_l.spos) return S2_FR;
+                else if (mm_r2_l.epos >= mm_r1_r.epos) return S2_RF;
+            }
+        } else if (r1_regular_bsj && !r2_regular_bsj) {
+            MatchedMate full_mm = mm_r1_l;
+            if (!merge_to_right(full_mm, mm_r1_r)) return S2_UD;
+            remain_seq = r2_seq; remain_seq_len = r2_seq_len;
+            return final_check(full_mm, mm_r2_l, mm_r2_r, cr);
+        } else if (!r1_regular_bsj && r2_regular_bsj) {
+            MatchedMate full_mm = mm_r2_l;
+            if (!merge_to_right(full_mm, mm_r2_r)) return S2_UD;
+            remain_seq = r1_seq; remain_seq_len = r1_seq_len;
+            return final_check(full_mm, mm_r1_l, mm_r1_r, cr);
+        } else {
+            if (mm_r1_l.spos == mm_r2_l.spos && mm_r1_r.epos == mm_r2_r.epos) {
+                overlap_to_spos(c, mm_r1_l);
+                overlap_to_epos(c, mm_r1_r);
+                std::vector<pu32i> end_tids, start_tids;
+                end_tids_of(mm_r1_r, end_tids);
+                start_tids_of(mm_r1_l, start_tids);
+                int best_ed1 = maxEd + 1, best_ed2 = maxEd + 1;
+                uint32_t qcutpos, beg_bp, end_bp;
+                std::vector<uint32_t> common_tid;
+                std::string ssignal1, esignal1, ssignal2, esignal2;
+                for (size_t i = 0; i < start_tids.size(); ++i)
+                    for (size_t j = 0; j < end_tids.size(); ++j) {
+                        int sdiff = start_tids[i].second, ediff = end_tids[j].second;
+                        if (!(start_tids[i].first == end_tids[j].first && sdiff == ediff)) continue;
+                        common_tid.assign(1, start_tids[i].first);
+                        beg_bp = mm_r1_l.spos - mm_r1_l.sclen_left - sdiff;
+                        end_bp = mm_r1_r.epos + mm_r1_r.sclen_right - ediff;
+                        qcutpos = mm_r1_r.qepos + mm_r1_r.sclen_right - ediff;
+                        int ed1 = split_realignment6(qcutpos, beg_bp, end_bp, r1_seq, r1_seq_len, common_tid);
+                        if (qcutpos < 2 || qcutpos + 2 > r1_seq_len) { esignal1 = ""; ssignal1 = ""; }
+                        else { esignal1 = two(r1_seq, r1_seq_len, (int64_t)qcutpos - 2); ssignal1 = two(r1_seq, r1_seq_len, qcutpos); }
+                        qcutpos = mm_r2_r.qepos + mm_r2_r.sclen_right - ediff;
+                        int ed2 = split_realignment6(qcutpos, beg_bp, end_bp, r2_seq, r2_seq_len, common_tid);
+                        if (qcutpos < 2 || qcutpos + 2 > r2_seq_len) { ssignal2 = ""; esignal2 = ""; }
+                        else { esignal2 = two(r2_seq, r2_seq_len, (int64_t)qcutpos - 2); ssignal2 = two(r2_seq, r2_seq_len, qcutpos); }
+                        if (ed1 < best_ed1 && ed2 < best_ed2) {
+                            std::string nsb = ref_bp(beg_bp, 2), neb = ref_bp(end_bp - 1, 2);
+                            if (ssignal1 == "") cr.set_bp(beg_bp, end_bp, ssignal2, esignal2, nsb, neb);
+                            else if (ssignal2 == "") cr.set_bp(beg_bp, end_bp, ssignal1, esignal1, nsb, neb);
+                            else cr.set_bp(beg_bp, end_bp, consensus2(ssignal1, ssignal2), consensus2(esignal1, esignal2), nsb, neb);
+                            best_ed1 = ed1;
+                            best_ed2 = ed2;
+                        }
+                    }
+                if (best_ed1 <= maxEd && best_ed2 <= maxEd) return S2_CR;
+                qcutpos = mm_r1_r.qepos + mm_r1_r.sclen_right;
+                beg_bp = mm_r1_l.spos - mm_r1_l.sclen_left;
+                end_bp = mm_r1_r.epos + mm_r1_r.sclen_right;
+                if (qcutpos < 2 || qcutpos > (r1_seq_len - 2) || qcutpos > (r2_seq_len - 2)) return S2_MCR;
+                esignal1 = two(r1_seq, r1_seq_len, (int64_t)qcutpos - 2); ssignal1 = two(r1_seq, r1_seq_len, qcutpos);
+                esignal2 = two(r2_seq, r2_seq_len, (int64_t)qcutpos - 2); ssignal2 = two(r2_seq, r2_seq_len, qcutpos);
+                cr.set_bp(beg_bp, end_bp, consensus2(ssignal1, ssignal2), consensus2(esignal1, esignal2), ref_bp(beg_bp, 2), ref_bp(end_bp - 1, 2));
+                if (!start_tids.empty() && !end_tids.empty()) return S2_NCR;
+                return S2_MCR;
+            }
+        }
+        return S2_UD;
+    }
+
+    // print_split_mapping (both forms), process_circ.cpp:1670-1708, followed by fprintf(candid_file, "%d\n", type)
+    void print_split(const MatchedMate &mm_r1, const MatchedMate &mm_r2, const MatchedMate *parts, int n_parts, int chr_row, int type) {
+        char buf[512];
+        const uint32_t sh = c.A->chr_shift[chr_row];
+        int k = snprintf(buf, sizeof buf, "%s\t%s\t", cur_name, chr_names[c.A->chr_id[chr_row]]);
+        candid.append(buf, k);
+        auto one = [&](const MatchedMate &m) {
+            int q = snprintf(buf, sizeof buf, "%u\t%u\t%d\t%d\t%d\t", m.spos - sh, m.epos - sh, m.qspos, m.matched_len, m.dir);
+            candid.append(buf, q);
+        };
+        for (int i = 0; i < n_parts; ++i) one(parts[i]);
+        one(mm_r1);
+        one(mm_r2);
+        k = snprintf(buf, sizeof buf, "%d\n", type);
+        candid.append(buf, k);
+    }
+    void push_call(const CircRes2 &b) { calls.push_back(Call{b.chr_id, b.spos, b.epos, b.type, cur_rec, b.start_signal, b.end_signal, b.start_bp_ref, b.end_bp_ref}); }
+    // the best_cr bookkeeping shared by both callers (process_circ.cpp:456-478, 614-634): returns true when the caller must return
+    bool consider(int type, const CircRes2 &cr, int chr_row, CircRes2 &best_cr) {
+        if (type < S2_CR) { best_cr.type = type; return true; }
+        if (type >= S2_CR && type <= S2_MCR && type < best_cr.type) {
+            const uint32_t sh = c.A->chr_shift[chr_row];
+            best_cr.chr_id = c.A->chr_id[chr_row];
+            best_cr.spos = cr.spos - sh; best_cr.epos = cr.epos - sh; best_cr.type = type;
+            best_cr.start_signal = cr.start_signal; best_cr.end_signal = cr.end_signal;
+            best_cr.start_bp_ref = cr.start_bp_ref; best_cr.end_bp_ref = cr.end_bp_ref;
+            if (type == S2_CR) { push_call(best_cr); return true; }
+        }
+        return false;
+    }
+
+    struct Rd { const uint8_t *seq, *rcseq; uint32_t len; };
+    std::map<uint32_t, RegionalHT> tables;       // get_hash_table_smart's pool, keyed by gene (the pool only saves rebuilding)
+    const RegionalHT &table_of(uint32_t gene) {
+        auto it = tables.find(gene);
+        if (it != tables.end()) return it->second;
+        const cm_annot_view *A = c.A;
+        const uint32_t gs = A->gene_start[gene], ge = A->gene_end[gene];
+        const int gene_len = (int)(ge - gs + 1);
+        std::vector<uint8_t> gseq;
+        RegionalHT &t = tables[gene];
+        if (!pac2char_otf(gs, gene_len, gseq)) gseq.assign((size_t)gene_len + 1, 0);   // buffer left unset by a failed pac2char_otf there
+        t.create(ws, gs, ge, gseq.data(), 0, gene_len);
+        return t;
+    }
+
+    // ProcessCirc::call_circ_single_split, process_circ.cpp:360-482; mr in chromosome coordinates (as parsed from the header)
+    void single_split(const Rd &rec1, const Rd &rec2, const cm_mapped_read &mr_in, uint32_t chr_shift) {
+        cm_mapped_read mr = mr_in;
+        bool r1_partial = mr.mlen_r1 < mr.mlen_r2;
+        remain_seq = r1_partial ? (mr.r1_forward ? rec1.seq : rec1.rcseq) : (mr.r2_forward ? rec2.seq : rec2.rcseq);
+        fullmap_seq = !r1_partial ? (mr.r1_forward ? rec1.seq : rec1.rcseq) : (mr.r2_forward ? rec2.seq : rec2.rcseq);
+        remain_seq_len = r1_partial ? rec1.len : rec2.len;
+        fullmap_seq_len = !r1_partial ? rec1.len : rec2.len;
+        mr.spos_r1 += chr_shift; mr.epos_r1 += chr_shift; mr.spos_r2 += chr_shift; mr.epos_r2 += chr_shift;      // chrloc2conloc
+        MatchedMate mm_r1 = mate_of(mr, 1, (int)rec1.len, r1_partial), mm_r2 = mate_of(mr, 2, (int)rec2.len, !r1_partial);
+        const MatchedMate &pm = r1_partial ? mm_r1 : mm_r2;
+        const uint32_t plen = r1_partial ? rec1.len : rec2.len;
+        const bool right_matched = (pm.qspos - 1) > (plen - pm.qepos);
+        uint32_t qspos = right_matched ? 1 : pm.qepos + 1;
+        uint32_t qepos = right_matched ? pm.qspos - 1 : plen;
+        int whole_seq_len = (int)plen;
+        int remain_len = (int)(qepos - qspos + 1);
+        if (qepos < qspos || remain_len < ws) return;
+        int gi = gene_overlap(mm_r1.spos);
+        if (gi < 0) return;
+        const cm_annot_view *A = c.A;
+        CircRes2 best_cr;
+        best_cr.type = S2_NF;
+        for (uint32_t g = A->giv_gene_off[gi]; g < A->giv_gene_off[gi + 1]; ++g) {
+            const uint32_t gene = A->giv_gene[g];
+            const RegionalHT &ht = table_of(gene);
+            chaining(qspos, qepos, ht, remain_seq, A->gene_start[gene], bc1);
+            if (bc1.best_chain_count <= 0) continue;
+            bool forward = r1_partial ? mr.r1_forward : mr.r2_forward;
+            int dir = forward ? 1 : -1;
+            for (int j = 0; j < std::min(bc1.best_chain_count, S2_TOPCHAIN); ++j) {
+                MatchedMate partial_mm(c);
+                find_exact_coord(mm_r1, mm_r2, partial_mm, dir, qspos, remain_seq, remain_len, whole_seq_len, bc1.chains[j]);
+                if (partial_mm.type != CM_CONCRD) continue;
+                int chr_row = get_shift(c, mm_r1.spos);
+                CircRes2 cr;
+                int type = check_split_map3(mm_r1, mm_r2, partial_mm, r1_partial, cr);
+                print_split(mm_r1, mm_r2, &partial_mm, 1, chr_row, type);
+                if (consider(type, cr, chr_row, best_cr)) return;
+            }
+        }
+        if (best_cr.type >= S2_CR && best_cr.type <= S2_MCR) push_call(best_cr);
+    }
+    // ProcessCirc::call_circ_double_split, process_circ.cpp:484-645
+    void double_split(const Rd &rec1, const Rd &rec2, const cm_mapped_read &mr_in, uint32_t chr_shift) {
+        cm_mapped_read mr = mr_in;
+        const uint8_t *r1_remain_seq = mr.r1_forward ? rec1.seq : rec1.rcseq, *r2_remain_seq = mr.r2_forward ? rec2.seq : rec2.rcseq;
+        r1_seq = r1_remain_seq; r2_seq = r2_remain_seq; r1_seq_len = rec1.len; r2_seq_len = rec2.len;
+        const bool r1_right = (mr.qspos_r1 - 1) > (rec1.len - mr.qepos_r1), r2_right = (mr.qspos_r2 - 1) > (rec2.len - mr.qepos_r2);
+        uint32_t r1_qspos = r1_right ? 1 : mr.qepos_r1 + 1, r2_qspos = r2_right ? 1 : mr.qepos_r2 + 1;
+        uint32_t r1_qepos = r1_right ? mr.qspos_r1 - 1 : rec1.len, r2_qepos = r2_right ? mr.qspos_r2 - 1 : rec2.len;
+        int r1_remain_len = (int)(r1_qepos - r1_qspos + 1), r2_remain_len = (int)(r2_qepos - r2_qspos + 1);
+        if (r1_remain_len < ws && r2_remain_len < ws) return;
+        if (r1_remain_len < ws || r2_remain_len < ws) single_split(rec1, rec2, mr_in, chr_shift);      // ... and carries on (no return there)
+        mr.spos_r1 += chr_shift; mr.epos_r1 += chr_shift; mr.spos_r2 += chr_shift; mr.epos_r2 += chr_shift;
+        int gi = gene_overlap(mr.spos_r1);
+        if (gi < 0) return;
+        MatchedMate mm_r1 = mate_of(mr, 1, (int)rec1.len, true), mm_r2 = mate_of(mr, 2, (int)rec2.len, true);
+        const cm_annot_view *A = c.A;
+        CircRes2 best_cr;
+        best_cr.type = S2_NF;
+        for (uint32_t g = A->giv_gene_off[gi]; g < A->giv_gene_off[gi + 1]; ++g) {
+            const uint32_t gene = A->giv_gene[g];
+            const RegionalHT &ht = table_of(gene);
+            chaining(r1_qspos, r1_qepos, ht, r1_remain_seq, A->gene_start[gene], bc1);
+            chaining(r2_qspos, r2_qepos, ht, r2_remain_seq, A->gene_start[gene], bc2);
+            if (bc1.best_chain_count <= 0 && bc2.best_chain_count <= 0) continue;
+            if (bc1.best_chain_count <= 0 || bc2.best_chain_count <= 0) { single_split(rec1, rec2, mr_in, chr_shift); continue; }
+            for (int j = 0; j < std::min(bc1.best_chain_count, S2_TOPCHAIN); ++j)
+                for (int k = 0; k < std::min(bc2.best_chain_count, S2_TOPCHAIN); ++k) {
+                    MatchedMate r1_partial_mm(c), r2_partial_mm(c);
+                    set_mm(bc1.chains[j], r1_qspos, r1_remain_len, mm_r1.dir, r1_partial_mm);
+                    set_mm(bc2.chains[k], r2_qspos, r2_remain_len, mm_r2.dir, r2_partial_mm);
+                    overlap_to_spos(c, mm_r1); overlap_to_spos(c, mm_r2); overlap_to_spos(c, r1_partial_mm); overlap_to_spos(c, r2_partial_mm);
+                    std::vector<uint32_t> common_tid;
+                    std::vector<MatchedMate> segments{mm_r1, mm_r2, r1_partial_mm, r2_partial_mm};
+                    if (!same_transcript_n(segments, 4, common_tid)) continue;
+                    bool success;
+                    if (bc1.chains[j].frags[0].rpos <= bc2.chains[k].frags[0].rpos)
+                        success = ext.extend_both_mates(bc1.chains[j], bc2.chains[k], common_tid, r1_remain_seq, r2_remain_seq, (int)r1_qspos, (int)r2_qspos,
+                                                        (int)r1_qepos, (int)r2_qepos, r1_partial_mm, r2_partial_mm);
+                    else
+                        success = ext.extend_both_mates(bc2.chains[k], bc1.chains[j], common_tid, r2_remain_seq, r1_remain_seq, (int)r2_qspos, (int)r1_qspos,
+                                                        (int)r2_qepos, (int)r1_qepos, r2_partial_mm, r1_partial_mm);
+                    if (!success) continue;
+                    if (!(r1_partial_mm.type == CM_CONCRD && r2_partial_mm.type == CM_CONCRD)) continue;
+                    int chr_row = get_shift(c, mm_r1.spos);
+                    CircRes2 cr;
+                    int type = check_split_map4(mm_r1, mm_r2, r1_partial_mm, r2_partial_mm, cr);
+                    MatchedMate parts[2] = {r1_partial_mm, r2_partial_mm};
+                    print_split(mm_r1, mm_r2, parts, 2, chr_row, type);
+                    if (consider(type, cr, chr_row, best_cr)) return;
+                }
+        }
+        if (best_cr.type >= S2_CR && best_cr.type <= S2_MCR) push_call(best_cr);
+        else single_split(rec1, rec2, mr_in, chr_shift);
+    }
+    // ProcessCirc::call_circ, process_circ.cpp:334-358
+    void call_circ(const Rd &rec1, const Rd &rec2, const cm_mapped_read &mr, uint32_t chr_shift, uint64_t rec_index, const char *name) {
+        fullmap_seq = remain_seq = r1_seq = r2_seq = nullptr;
+        fullmap_seq_len = remain_seq_len = r1_seq_len = r2_seq_len = 0;
+        cur_rec = rec_index;
+        cur_name = name;
+        if (mr.type == CM_CHIBSJ) single_split(rec1, rec2, mr, chr_shift);
+        else if (mr.type == CM_CHI2BSJ) double_split(rec1, rec2, mr, chr_shift);
+    }
+};
+
+
+// ProcessCirc::report_events + both_side_consensus + get_consensus(vector), process_circ.cpp:1554-1631, utils.cpp:758-816;
+// CircRes::operator< / ==, common.cpp:479-493 (chr compared as strings; std::sort, unstable, like the reference)
+std::string consensus_n(const std::vector<std::string> &v) {
+    std::string res;
+    if (v.empty()) return res;
+    for (size_t i = 1; i < v.size(); ++i) if (v[i].length() != v[i - 1].length()) return res;
+    const char nuc[4] = {'A', 'C', 'G', 'T'};
+    for (size_t i = 0; i < v[0].length(); ++i) {
+        unsigned counts[256];
+        memset(counts, 0, sizeof counts);
+        for (auto &x : v) ++counts[(uint8_t)x[i]];
+        counts['A'] += counts['a']; counts['C'] += counts['c']; counts['G'] += counts['g']; counts['T'] += counts['t'];
+        unsigned max_cnt = 0;
+        char ch = 'N';
+        for (int k = 0; k < 4; ++k) if (counts[(uint8_t)nuc[k]] > max_cnt) { max_cnt = counts[(uint8_t)nuc[k]]; ch = nuc[k]; }
+        res += (max_cnt >= (v.size() / 2)) ? ch : 'N';
+    }
+    return res;
+}
+struct RepRow { std::string chr, rname; uint32_t spos, epos; int type; std::string ss, es, sb, eb; };
+bool rep_less(const RepRow &a, const RepRow &b) {
+    if (a.chr != b.chr) return a.chr < b.chr;
+    if (a.spos != b.spos) return a.spos < b.spos;
+    if (a.epos != b.epos) return a.epos < b.epos;
+    return a.type < b.type;
+}
+void report_events(std::vector<RepRow> &res, FILE *f) {
+    if (res.empty()) return;
+    std::sort(res.begin(), res.end(), rep_less);
+    auto same = [](const RepRow &a, const RepRow &b) { return a.chr == b.chr && a.spos == b.spos && a.epos == b.epos; };
+    auto flush = [&](const RepRow &last, const std::vector<RepRow> &grp, int cnt) {
+        if (last.type != S2_CR) return;
+        std::vector<std::string> ss, es;
+        for (auto &g : grp) { ss.push_back(g.ss); es.push_back(g.es); }
+        std::string ssc = consensus_n(ss), esc = consensus_n(es);
+        // compare() against start_bp_ref: both are C-string based in the reference (set_bp assigns char* to string)
+        bool pass = (ssc.compare(last.sb) == 0) && (esc.compare(last.eb) == 0);
+        fprintf(f, "%s\t%u\t%u\t%d\t%s\t%s-%s\t%s-%s\t%s\t", last.chr.c_str(), last.spos, last.epos, cnt, "STC", ssc.c_str(), esc.c_str(),
+                last.sb.c_str(), last.eb.c_str(), pass ? "Pass" : "Fail");
+        for (size_t j = 0; j + 1 < grp.size(); ++j) fprintf(f, "%s,", grp[j].rname.c_str());
+        fprintf(f, "%s\n", grp.back().rname.c_str());
+    };
+    int cnt = 1;
+    RepRow last = res[0];
+    std::vector<RepRow> grp{res[0]};
+    for (size_t i = 1; i < res.size(); ++i) {
+        if (same(res[i], last)) { cnt++; grp.push_back(res[i]); }
+        else { flush(last, grp, cnt); cnt = 1; last = res[i]; grp.assign(1, res[i]); }
+    }
+    flush(last, grp, cnt);
+}
 }  // namespace
 
 // ============================ C entry points for tests / bench ============================
@@ -1580,5 +2475,47 @@ int oracle_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t
     return local_alignment_sc(c, s, n, t, m, *sclen, *indel, *score, left != 0);
 }
 int oracle_one_side(const uint8_t *s, int n, const uint8_t *t, int m, int w) { return global_one_side_banded_alignment(s, n, t, m, w); }
+
+
+// Stage 2 over records already in the order of the sorted remain files (ProcessCirc::do_process, process_circ.cpp:195-331):
+// states[i] is the carried MatchedRead of pair i as fill_map_info parses it (chromosome coordinates, chr_id = row of the
+// chromosome table, contig_num); X / A are the packed contigs and their annotation; chr_contig / chr_shift the chromosome
+// table.  Writes <out>.candidates.pam and <out>.circ_report.
+int oracle_circ_run(const cm_params *P, int window, uint32_t n_contigs, const cm_index_view *X, const cm_annot_view *A, uint32_t n_chr,
+                    const char *const *chr_names, const uint32_t *chr_contig, const uint32_t *chr_shift, uint64_t n_rec,
+                    const char *const *names, const cm_reads *R, const cm_mapped_read *states, const char *candid_path,
+                    const char *report_path) {
+    FILE *fc = fopen(candid_path, "w");
+    if (!fc) return CM_EINVAL;
+    std::vector<RepRow> rows;
+    int cur_contig = -1;
+    CircCaller *cc = nullptr;
+    for (uint64_t i = 0; i < n_rec; ++i) {
+        const cm_mapped_read &mr = states[i];
+        if (mr.contig_num < 0 || (uint32_t)mr.contig_num >= n_contigs || mr.chr_id < 0 || (uint32_t)mr.chr_id >= n_chr) continue;
+        if (cur_contig != mr.contig_num) {        // load_genome + refresh_hash_table_list
+            if (cc) { fwrite(cc->candid.data(), 1, cc->candid.size(), fc); for (auto &c : cc->calls) rows.push_back(RepRow{chr_names[c.chr_id], names[c.rec], c.spos, c.epos, c.type, c.ss, c.es, c.sb, c.eb}); delete cc; }
+            cur_contig = mr.contig_num;
+            Ctx c{*P, X + cur_contig, A + cur_contig};
+            cc = new CircCaller(c, window, chr_names);
+        }
+        Rec r1, r2;
+        make_rec(r1, R->seq1 + R->off1[i], (int)(R->off1[i + 1] - R->off1[i]));
+        make_rec(r2, R->seq2 + R->off2[i], (int)(R->off2[i + 1] - R->off2[i]));
+        r1.rc.push_back(0); r2.rc.push_back(0);
+        CircCaller::Rd a{r1.seq, r1.rc.data(), (uint32_t)r1.seq_len}, b{r2.seq, r2.rc.data(), (uint32_t)r2.seq_len};
+        // check_removables: tables of genes that end before this pair (the pool only saves rebuilding; results do not depend on it)
+        for (auto it = cc->tables.begin(); it != cc->tables.end();) it = (mr.spos_r1 + chr_shift[mr.chr_id] > it->second.gene_epos) ? cc->tables.erase(it) : ++it;
+        cc->call_circ(a, b, mr, chr_shift[mr.chr_id], i, names[i]);
+    }
+    if (cc) { fwrite(cc->candid.data(), 1, cc->candid.size(), fc); for (auto &c : cc->calls) rows.push_back(RepRow{chr_names[c.chr_id], names[c.rec], c.spos, c.epos, c.type, c.ss, c.es, c.sb, c.eb}); delete cc; }
+    fclose(fc);
+    (void)chr_contig;
+    FILE *fr = fopen(report_path, "w");
+    if (!fr) return CM_EINVAL;
+    report_events(rows, fr);
+    fclose(fr);
+    return 0;
+}
 
 }  // extern "C"

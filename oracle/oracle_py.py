@@ -119,3 +119,23 @@ def map_all_rounds_mt(params, host_index, batch, n_threads=None, p1=None):
     [t.start() for t in th]
     [t.join() for t in th]
     return st, act, cat[:batch.n]
+
+
+def circ_run(params, host_index, chr_table, names, batch, states, candid_path, report_path, window=8):
+    """Stage 2 (ProcessCirc::do_process) on records given in the order of the sorted remain files: names[i], batch pair i and
+    states[i] (the MatchedRead carried in R1's header, chromosome coordinates).  Writes candidates.pam and circ_report."""
+    L = load()
+    L.oracle_circ_run.restype = C.c_int
+    n_con = host_index.n_contigs
+    views = (cl.IndexView * n_con)(*host_index.views)
+    keep = [n.encode() if isinstance(n, str) else n for n in names]
+    name_arr = (C.c_char_p * max(len(keep), 1))(*keep)
+    chr_keep = [t[0].encode() for t in chr_table]
+    chr_arr = (C.c_char_p * len(chr_keep))(*chr_keep)
+    chr_contig = np.asarray([t[1] - 1 for t in chr_table], dtype=np.uint32)
+    chr_shift = np.asarray([t[2] for t in chr_table], dtype=np.uint32)
+    st = np.ascontiguousarray(states)
+    rc = L.oracle_circ_run(C.byref(params), C.c_int(window), C.c_uint32(n_con), views, host_index.annots, C.c_uint32(len(chr_table)), chr_arr,
+                           C.c_void_p(chr_contig.ctypes.data), C.c_void_p(chr_shift.ctypes.data), C.c_uint64(len(keep)), name_arr,
+                           C.byref(batch.c), C.c_void_p(st.ctypes.data), candid_path.encode(), report_path.encode())
+    assert rc == 0, rc

@@ -138,9 +138,13 @@ constexpr int SC_MAT = 1, SC_MIS = -3, SC_IND = -3, SC_XD = 8;   // score_mat.in
 constexpr int MAX_SEEDS = CM_MAX_CHAIN_FRAGS;   // seeds per read the device path supports
 constexpr int MAX_BAND = 8;                 // bandWidth supported by the private DP rows
 constexpr int MAX_TID = 64;                 // |common_tid| kept in registers / scratch per mate pair (larger sets: TidList)
+#if defined(CM_STAGE2_HOST)
+constexpr int MEMO_N = 512;                 // host (stage 2): room for every exon piece of every common transcript
+#else
 constexpr int MEMO_N = 8;                   // memoised exon alignments per extend call
+#endif
 
-enum { ERR_POOL = 1, ERR_SEEDS = 4, ERR_BAND = 8 };
+enum { ERR_POOL = 1, ERR_SEEDS = 4, ERR_BAND = 8, ERR_MEMO = 16 };
 
 struct KCore {          // what the host passes as a kernel argument (plain pointers to device memory)
     cm_params P;
@@ -1098,6 +1102,9 @@ __device__ inline void cm_tick(Tick *tk, int id) {
 #define CM_TICK(sm_, id) ((void)0)
 #endif
 struct DpMem { LBuf a, b; g_err err; Tick *tk; };
+#elif defined(CM_STAGE2_HOST)
+#define CM_TICK(sm_, id) ((void)0)
+struct DpMem { LBuf a, b; g_err err; bool edit; };      // edit: EditDistAlignment instead of DropAlignment (ProcessCirc, src/process_circ.cpp:25)
 #else
 #define CM_TICK(sm_, id) ((void)0)
 struct DpMem { LBuf a, b; g_err err; };
@@ -1132,9 +1139,63 @@ CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &
     return c.P.band == 3 ? local_alignment_side_impl<3>(c, sm.a, n, sm.b, m, indel, align_score)
                          : local_alignment_side_impl<0>(c, sm.a, n, sm.b, m, indel, align_score);
 }
+#if defined(CM_STAGE2_HOST)
+// EditDistAlignment::local_alignment_right_sc / _left_sc (src/align.cpp:602-660), host only (stage 2): the banded edit DP of
+// global_banded_alignment (:395-450; full DP when n <= 2w or m <= w) over the staged strings, then the end cell (i, j), j = m down
+// to m - min(maxSc, m), |i - j| <= w, with dp <= maxEd that is best under AlignCandid's order (first seen wins ties):
+// soft clip m - j, indel j - i; a query of at most maxEd bases may also be taken as all mismatches.  Score = m - clip - 2 ed.
+inline int local_alignment_sc_edit(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
+    const int w = c.P.band, BIG = DPTINF;
+    const bool banded = !(w < 0 || n <= 2 * w || m <= w);
+    const int W = m + 1;
+    int *dp = new int[(size_t)(n + 1) * (size_t)W];
+    auto in_band = [&](int i, int j) { return !banded || (i - j <= w && j - i <= w); };
+    for (int i = 0; i <= n; ++i)
+        for (int j = 0; j <= m; ++j) {
+            int v;
+            if (!in_band(i, j)) v = BIG;
+            else if (i == 0) v = j;
+            else if (j == 0) v = i;
+            else {
+                const int d = dp[(size_t)(i - 1) * W + (j - 1)] + ldiff(s.get(i - 1), t.get(j - 1));
+                const int u = dp[(size_t)(i - 1) * W + j] + 1, l = dp[(size_t)i * W + (j - 1)] + 1;
+                v = cmin(d, cmin(u, l));
+                if (v > BIG) v = BIG;
+            }
+            dp[(size_t)i * W + j] = v;
+        }
+    const int max_sclen = cmin(c.P.max_sc, m);
+    Cand best{c.P.max_ed + 1, c.P.max_sc + 1, w + 1, -(c.P.max_sc + 1) - 2 * (c.P.max_ed + 1)};
+    for (int j = m; j >= m - max_sclen; --j)
+        for (int i = cmax(0, j - w); i <= cmin(j + w, n); ++i) {
+            const int v = dp[(size_t)i * W + j];
+            if (v <= c.P.max_ed) {
+                const Cand x{v, m - j, j - i, -(m - j) - 2 * v};
+                if (cand_less(x, best)) best = x;
+            }
+        }
+    delete[] dp;
+    if (m <= c.P.max_ed) {
+        const Cand x{m, 0, 0, -2 * m};
+        if (cand_less(x, best)) best = x;
+    }
+    align_score = m - best.sclen - 2 * best.ed;
+    sc_len = best.sclen;
+    indel = best.indel;
+    return best.ed;
+}
+#endif
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
     CM_TICK(sm, 24);
+#if defined(CM_STAGE2_HOST)
+    if (sm.edit) {
+        if (!dp_fits(sm, n, m)) { sc_len = c.P.max_sc + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
+        stage(s, n, sm.a, 4);
+        stage(t, m, sm.b, 5);
+        return local_alignment_sc_edit(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+    }
+#endif
     if (m >= 1 && n >= m && prefix_mismatches(s, t, m) == 0) {
         CM_STAT(9, 1);
         sc_len = 0;
@@ -1296,7 +1357,7 @@ CM_HD inline int estimate_middle_error(const Core &c, const CH &ch) {
         }
     return mid;
 }
-CM_HD inline bool is_concord_impl(const CH &a, uint32_t seq_len, MM &mr, bool v2) {
+template <class CHT> CM_HD inline bool is_concord_impl(const CHT &a, uint32_t seq_len, MM &mr, bool v2) {
     if (a.len() < 2) {
         mr.is_concord = false;
     } else if ((uint32_t)(a.qend_excl() - a.qpos(0)) >= seq_len) {
@@ -1542,20 +1603,26 @@ struct Memo {
     MemoKey k[MEMO_N];
     AlignRes v[MEMO_N];
     int n;
+    int flags;          // bit 0: an insert was dropped (table full); bit 1: an end piece shorter than its query was seen
 };
 CM_HD inline int memo_find(const Memo &m, const MemoKey &k) {
     for (int i = 0; i < m.n; ++i)
         if (m.k[i].rspos == k.rspos && m.k[i].rlen == k.rlen && m.k[i].qspos == k.qspos && m.k[i].qlen == k.qlen) return i;
     return -1;
 }
-// std::map::insert semantics (no overwrite).  A full table just stops memoising: a memo entry is a
-// pure function of its key except for the middle-vs-end key collision described in DESIGN.md §5.
-CM_HD inline void memo_put(Memo &m, const MemoKey &k, const AlignRes &v) {
-    if (m.n < MEMO_N && memo_find(m, k) < 0) {
+// std::map::insert semantics (no overwrite).  The reference's memo (std::map<AllCoord, AlignRes>, src/extend.cpp:299,375) is a
+// pure cache -- same key, same computation -- EXCEPT when a "middle" piece and an "end" piece share a key, where it serves the
+// first-inserted kind to both.  A middle key has rlen < qlen; an end key has rlen = min(remaining window, exon) >= qlen unless
+// the indels of the pieces before it sum to less than -band (rlen = qlen + band + sum(indel)).  So a full table that stops
+// memoising (recomputing instead) is exact unless BOTH happen in one extend call: an insert was dropped and an end piece with
+// rlen < qlen was seen.  extend_side reports that combination as ERR_MEMO (CM_ELIMIT) instead of returning a result that
+// may differ from the reference's.
+CM_HD inline void memo_put(Memo &m, const MemoKey &k, const AlignRes &v) {      // callers have just looked k up and missed
+    if (m.n < MEMO_N) {
         m.k[m.n] = k;
         m.v[m.n] = v;
         ++m.n;
-    }
+    } else m.flags |= 1;
 }
 
 struct Ext {
@@ -1615,6 +1682,7 @@ struct Ext {
     CM_HD void end_step(Memo &memo, const MemoKey &key, uint32_t pos, uint32_t ref_len, const SV &q, int qlen, int ed_th, AlignRes &best,
                         AlignRes &curr, AlignRes &exon_res, bool right) const {
         CM_TICK(sm, 16);
+        if (key.rlen < key.qlen) memo.flags |= 2;
         const int f = memo_find(memo, key);
         if (f >= 0) {
             const AlignRes &r = memo.v[f];
@@ -1746,6 +1814,7 @@ struct Ext {
         ar_set(best, pos, ed_th + 1, len + 1, c.P.band + 1, 0, 0);
         Memo memo;
         memo.n = 0;
+        memo.flags = 0;
         int it_ind = -1, it_seg = -1;
         CM_TICK(sm, 22);
         if (tl.n > 0) it_seg = overlap_ind(c, pos, it_ind);
@@ -1757,6 +1826,7 @@ struct Ext {
         };
         for (int i = 0; i < tl.n; ++i) along(tl.t[i]);
         if (tl.more) common_tids_from(c, tl.s, tl.r, MAX_TID, along);
+        if (memo.flags == 3) flag_err(sm.err, ERR_MEMO);
         int min_ed = best.ed, sclen_best = best.sclen;
         CM_TICK(sm, 11);
         if (min_ed <= ed_th) {
@@ -1791,7 +1861,7 @@ struct Ext {
         return (best.qcovlen >= seq_len && best.ed <= ed_th);
     }
 
-    CM_HD bool chain_right(const TidList &tl, const CH &ch, const SV &seq, int seq_len, uint32_t ub, MM &mr, int &err) const {
+    template <class CHT> CM_HD bool chain_right(const TidList &tl, const CHT &ch, const SV &seq, int seq_len, uint32_t ub, MM &mr, int &err) const {
         uint32_t rm_pos = ch.rend_excl() - 1;
         int remain_end = seq_len - ch.qend_excl();
         bool right_ok = (remain_end <= 0);
@@ -1807,7 +1877,7 @@ struct Ext {
         err += err_right;
         return right_ok;
     }
-    CM_HD bool chain_left(const TidList &tl, const CH &ch, const SV &seq, int32_t qspos, uint32_t lb, MM &mr, int &err) const {
+    template <class CHT> CM_HD bool chain_left(const TidList &tl, const CHT &ch, const SV &seq, int32_t qspos, uint32_t lb, MM &mr, int &err) const {
         uint32_t lm_pos = ch.rpos(0);
         int remain_beg = ch.qpos(0) - qspos;
         bool left_ok = (remain_beg <= 0);
@@ -1823,7 +1893,7 @@ struct Ext {
         err += err_left;
         return left_ok;
     }
-    CM_HD int calc_middle_ed(const CH &ch, int edth, const SV &q) const {
+    template <class CHT> CM_HD int calc_middle_ed(const CHT &ch, int edth, const SV &q) const {
         int mid = 0;
         if (ch.len() == 0) return 0;
         for (uint32_t i = 0; i + 1 < ch.len(); ++i) {

@@ -1297,8 +1297,9 @@ int check_dev_err(cm_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int e = *(const int *)ctx->h_pin;
     if (e) {
-        return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
-                    (e & ~3) ? " DP string longer than the staging buffer" : "");
+        return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
+                    (e & (cmc::ERR_SEEDS | cmc::ERR_BAND)) ? " DP string longer than the staging buffer;" : "",
+                    (e & cmc::ERR_MEMO) ? " extension memo overflowed where the reference's memo would have served a colliding key" : "");
     }
     return CM_OK;
 }

@@ -14,6 +14,7 @@
 // 14-mers whose full k-mer is invalid (HashTable.c:1065-1090) and the [0].info count header
 // (the count is bucket_off[hv+1]-bucket_off[hv]).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -23,15 +24,18 @@
 
 namespace {
 
-inline int base_code(uint8_t ch) {
-    switch (ch) {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T': return 3;
-        default: return 4;
+struct BaseLut {
+    uint8_t v[256];
+    BaseLut() {
+        memset(v, 4, sizeof v);
+        v[(uint8_t)'A'] = 0;
+        v[(uint8_t)'C'] = 1;
+        v[(uint8_t)'G'] = 2;
+        v[(uint8_t)'T'] = 3;
     }
-}
+};
+const BaseLut BASE_LUT;
+inline int base_code(uint8_t ch) { return BASE_LUT.v[ch]; }
 
 // Calls f(bucket, checksum, start1) for every indexable k-mer, in ascending start order.
 template <class F>
@@ -54,12 +58,17 @@ void for_each_kmer(const uint8_t *g, uint32_t n, int k, int c, F f) {
 
 }  // namespace
 
-// Both passes run on n_threads threads that each scan the whole contig and keep only the k-mers of their own
-// bucket range: bucket ranges are disjoint, so the counters / cursors need no atomics and every bucket still
-// receives its entries in ascending position order (pass 2), exactly like the serial scatter of the reference.
-// Pass 1 splits the bucket space evenly, pass 2 by entry count (boundaries taken from the prefix sum).  A rolling
-// 2-bit code costs ~1 ns per base, so T scans in parallel are cheap next to the random scatter they divide by T:
-// a 1.06 Gbp contig builds in ~6 s on 16 threads instead of ~40 s on one.
+// Parallel build without a shared random-access phase.  The 4^14 buckets are cut into 4096 ranges (top 12 bits of the bucket
+// number); the contig is cut into slices.
+//   pass 1  (parallel over slices)  count the indexable k-mers of a slice per range;
+//   pass 2  (parallel over slices)  write each k-mer as one 64-bit word (low 16 bucket bits | checksum | position) into the
+//                                   temp array at [range][slice] order: 4096 sequential write streams per thread;
+//   pass 3  (parallel over ranges)  a range's words are contiguous in temp and already in ascending position; count its 65536
+//                                   buckets, prefix-sum, scatter into the final (checksum, pos) arrays and order each bucket
+//                                   by checksum -- all inside a few hundred KB, i.e. in cache.
+// A range's span in temp IS its span in the final arrays, so bucket offsets are range start + local prefix.  Every bucket
+// receives its entries in ascending position order, like the serial scatter of the reference (HashTable.c:769-821), so the
+// result is identical for any thread count.  1.06 Gbp on 16 threads: a few seconds (was 40-60 s with a random scatter).
 template <class F>
 static void run_threads(int nt, F f) {
     if (nt <= 1) {
@@ -76,82 +85,110 @@ extern "C" int cm_host_build_index(const uint8_t *genome, uint32_t ref_len, int3
     if (!genome || !out || kmer < CM_WINDOW_SIZE || kmer > CM_WINDOW_SIZE + 8) return CM_EINVAL;
     const int c = kmer - CM_WINDOW_SIZE;
     const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
-    int nt = std::max(1, std::min(n_threads, 64));
-    if (ref_len < (1u << 22)) nt = 1;        // small contigs: the scan is the whole cost
-    // off[h+2] counts bucket h during pass 1; after the prefix sum off[h+1] is bucket h's
-    // write cursor, and once pass 2 is done off[h] is bucket h's start.
-    uint32_t *off = (uint32_t *)calloc(nb + 2, sizeof(uint32_t));
-    if (!off) return CM_ENOMEM;
-    std::vector<uint64_t> part(nt, 0);
-    run_threads(nt, [&](int t) {
-        const uint32_t lo = (uint32_t)(nb * (uint64_t)t / nt), span = (uint32_t)(nb * (uint64_t)(t + 1) / nt) - lo;
-        uint64_t cnt = 0;
-        for_each_kmer(genome, ref_len, kmer, c, [&](uint32_t h, uint16_t, uint32_t) {
-            if (h - lo < span) {
-                ++off[h + 2];
-                ++cnt;
+    constexpr int RBITS = 12, NR = 1 << RBITS, LOWBITS = 2 * CM_WINDOW_SIZE - RBITS;      // 4096 ranges of 65536 buckets
+    const int nt = std::max(1, std::min(n_threads, 64));
+    const uint32_t n_slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt * 4, ((uint64_t)ref_len >> 16) + 1));
+    auto slice_lo = [&](uint32_t s) { return (uint32_t)((uint64_t)ref_len * s / n_slices); };
+    // k-mers whose START lies in [lo, hi): scan [lo, min(hi + k - 1, n))
+    auto scan_slice = [&](uint32_t s, auto &&f) {
+        const uint32_t lo = slice_lo(s), hi = slice_lo(s + 1);
+        const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)hi + (uint32_t)kmer - 1, ref_len);
+        const uint64_t kmask = (1ull << (2 * kmer)) - 1, cmask = c ? ((1ull << (2 * c)) - 1) : 0;
+        uint64_t v = 0;
+        int run = 0;
+        for (uint32_t i = lo; i < end; ++i) {
+            const int b = base_code(genome[i]);
+            if (b == 4) {
+                run = 0;
+                v = 0;
+                continue;
             }
-        });
-        part[t] = cnt;
+            v = ((v << 2) | (uint64_t)b) & kmask;
+            if (++run >= kmer) f((uint32_t)(v >> (2 * c)), (uint32_t)(v & cmask), i + 2 - (uint32_t)kmer);
+        }
+    };
+    // pass 1
+    std::vector<uint64_t> cnt((size_t)n_slices * NR, 0);
+    std::atomic<uint32_t> next{0};
+    run_threads(nt, [&](int) {
+        for (uint32_t s; (s = next.fetch_add(1)) < n_slices;) {
+            uint64_t *cs = cnt.data() + (size_t)s * NR;
+            scan_slice(s, [&](uint32_t h, uint32_t, uint32_t) { ++cs[h >> LOWBITS]; });
+        }
     });
+    // temp offsets in [range][slice] order
+    std::vector<uint64_t> base((size_t)n_slices * NR), range_start(NR + 1);
     uint64_t total = 0;
-    for (int t = 0; t < nt; ++t) total += part[t];
-    if (total > 0xffffffffull) {
-        free(off);
-        return CM_ELIMIT;
+    for (int r = 0; r < NR; ++r) {
+        range_start[r] = total;
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            base[(size_t)s * NR + r] = total;
+            total += cnt[(size_t)s * NR + r];
+        }
     }
-    for (uint64_t h = 2; h < nb + 2; ++h) off[h] += off[h - 1];
+    range_start[NR] = total;
+    if (total > 0xffffffffull) return CM_ELIMIT;
+    uint32_t *off = (uint32_t *)malloc((nb + 1) * sizeof(uint32_t));
     uint16_t *cs = (uint16_t *)malloc((total ? total : 1) * sizeof(uint16_t));
     uint32_t *ps = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
-    if (!cs || !ps) {
+    uint64_t *tmp = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
+    if (!off || !cs || !ps || !tmp) {
         free(off);
         free(cs);
         free(ps);
+        free(tmp);
         return CM_ENOMEM;
     }
-    // bucket boundaries that give every thread about the same number of entries (off[h+1] = start of bucket h now)
-    std::vector<uint64_t> cut(nt + 1, 0);
-    cut[nt] = nb;
-    for (int t = 1; t < nt; ++t) {
-        const uint32_t want = (uint32_t)(total * (uint64_t)t / nt);
-        cut[t] = (uint64_t)(std::lower_bound(off + 1, off + 1 + nb, want) - (off + 1));
-        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-    }
-    run_threads(nt, [&](int t) {
-        const uint32_t lo = (uint32_t)cut[t], span = (uint32_t)(cut[t + 1] - cut[t]);
-        if (!span) return;
-        for_each_kmer(genome, ref_len, kmer, c, [&](uint32_t h, uint16_t ck, uint32_t p) {
-            if (h - lo < span) {
-                const uint32_t w = off[h + 1]++;
-                cs[w] = ck;
-                ps[w] = p;
-            }
-        });
+    // pass 2
+    next = 0;
+    run_threads(nt, [&](int) {
+        std::vector<uint64_t> cur(NR);
+        for (uint32_t s; (s = next.fetch_add(1)) < n_slices;) {
+            for (int r = 0; r < NR; ++r) cur[r] = base[(size_t)s * NR + r];
+            scan_slice(s, [&](uint32_t h, uint32_t ck, uint32_t p) {
+                tmp[cur[h >> LOWBITS]++] = ((uint64_t)(h & ((1u << LOWBITS) - 1)) << 48) | ((uint64_t)ck << 32) | p;
+            });
+        }
     });
-    // Per-bucket order (checksum, pos).  Pass 2 wrote ascending pos, so a stable sort on the
-    // checksum is enough.
-    if (c > 0) {
-        run_threads(nt, [&](int t) {
-            std::vector<std::pair<uint16_t, uint32_t>> tmp;
-            for (uint64_t h = cut[t]; h < cut[t + 1]; ++h) {
-                uint32_t a = off[h], b = off[h + 1];
-                if (b - a < 2) continue;
-                bool sorted = true;
-                for (uint32_t i = a + 1; i < b && sorted; ++i) sorted = cs[i - 1] <= cs[i];
-                if (sorted) continue;
-                tmp.resize(b - a);
-                for (uint32_t i = a; i < b; ++i) tmp[i - a] = {cs[i], ps[i]};
-                std::stable_sort(tmp.begin(), tmp.end(),
-                                 [](const std::pair<uint16_t, uint32_t> &x, const std::pair<uint16_t, uint32_t> &y) {
-                                     return x.first < y.first;
-                                 });
-                for (uint32_t i = a; i < b; ++i) {
-                    cs[i] = tmp[i - a].first;
-                    ps[i] = tmp[i - a].second;
+    // pass 3
+    next = 0;
+    run_threads(nt, [&](int) {
+        std::vector<uint32_t> lc((1u << LOWBITS) + 1);
+        std::vector<std::pair<uint16_t, uint32_t>> srt;
+        for (uint32_t r; (r = next.fetch_add(1)) < (uint32_t)NR;) {
+            const uint64_t a = range_start[r], b = range_start[r + 1];
+            std::fill(lc.begin(), lc.end(), 0u);
+            for (uint64_t i = a; i < b; ++i) ++lc[(tmp[i] >> 48) + 1];
+            for (uint32_t h = 0; h < (1u << LOWBITS); ++h) lc[h + 1] += lc[h];
+            uint32_t *o = off + ((uint64_t)r << LOWBITS);
+            for (uint32_t h = 0; h < (1u << LOWBITS); ++h) o[h] = (uint32_t)a + lc[h];
+            for (uint64_t i = a; i < b; ++i) {
+                const uint64_t w = tmp[i];
+                const uint32_t d = (uint32_t)a + lc[w >> 48]++;
+                cs[d] = (uint16_t)(w >> 32);
+                ps[d] = (uint32_t)w;
+            }
+            if (c > 0) {          // per-bucket order (checksum, pos): positions are ascending already, a stable sort on the checksum is enough
+                for (uint32_t h = 0; h < (1u << LOWBITS); ++h) {
+                    const uint32_t x = o[h], y = (h + 1 < (1u << LOWBITS)) ? o[h + 1] : (uint32_t)b;
+                    if (y - x < 2) continue;
+                    bool sorted = true;
+                    for (uint32_t i = x + 1; i < y && sorted; ++i) sorted = cs[i - 1] <= cs[i];
+                    if (sorted) continue;
+                    srt.resize(y - x);
+                    for (uint32_t i = x; i < y; ++i) srt[i - x] = {cs[i], ps[i]};
+                    std::stable_sort(srt.begin(), srt.end(),
+                                     [](const std::pair<uint16_t, uint32_t> &p, const std::pair<uint16_t, uint32_t> &q) { return p.first < q.first; });
+                    for (uint32_t i = x; i < y; ++i) {
+                        cs[i] = srt[i - x].first;
+                        ps[i] = srt[i - x].second;
+                    }
                 }
             }
-        });
-    }
+        }
+    });
+    off[nb] = (uint32_t)total;
+    free(tmp);
     out->contig_num = contig_num;
     out->ref_len = ref_len;
     out->genome = genome;  // borrowed

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 OUT = os.path.join(CSRC, "libcmhot.so")
-SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp", "host_mapping.cpp", "host_circ.cpp"]
+SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp", "host_mapping.cpp", "host_circ.cpp", "host_circ_call.cpp"]
 DEPS = SOURCES + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "circminer_hot.h")]
 
 
@@ -37,6 +37,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                os.path.join(CSRC, s), "-o", o]
         if s.endswith(".hip"):
             cmd[1:1] = ["--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] if verbose else ["--offload-arch=gfx950"]
+        else:
+            cmd[1:1] = ["-x", "c++"]                 # host-only sources: plain C++ (hipcc would otherwise treat .cpp as HIP)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose or r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

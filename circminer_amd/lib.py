@@ -41,6 +41,10 @@ class MappingArgs(C.Structure):
                 ("batch_pairs", C.c_uint64)]
 
 
+class CircStats(C.Structure):
+    _fields_ = [("pairs", C.c_uint64), ("candidate_rows", C.c_uint64), ("calls", C.c_uint64), ("seconds", C.c_double)]
+
+
 class MappingStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("bsj_pairs", C.c_uint64), ("by_type", C.c_uint64 * 14), ("rounds", C.c_int32),
                 ("reserved", C.c_int32), ("seconds_load", C.c_double), ("seconds_map", C.c_double), ("seconds_parse", C.c_double),
@@ -53,6 +57,11 @@ def default_params(**kw) -> Params:
              max_intron=2_000_000, max_chain_len=30, device=0, reserved=0)
     d.update(kw)
     return Params(**d)
+
+
+class CircArgs(C.Structure):
+    _fields_ = [("index_path", C.c_char_p), ("index_info_path", C.c_char_p), ("gtf_path", C.c_char_p), ("out_prefix", C.c_char_p),
+                ("params", Params), ("last_round", C.c_int32), ("window_size", C.c_int32), ("n_threads", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IndexView(C.Structure):
@@ -206,6 +215,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_regional_table_free": (None, [u32p, u32p]),
         "cm_circ_report": (C.c_int, [pp(CircRes), C.c_uint64, C.c_char_p]),
         "cm_mapping_run": (C.c_int, [pp(MappingArgs), pp(MappingStats), C.c_char_p, C.c_uint64]),
+        "cm_circ_call": (C.c_int, [pp(Params), C.c_int32, C.c_uint32, pp(IndexView), pp(AnnotView), pp(ChrInfo), C.c_uint32, pp(FastqBatch),
+                                   C.c_char_p, C.c_char_p, pp(CircStats)]),
+        "cm_circ_run": (C.c_int, [pp(CircArgs), pp(CircStats), C.c_char_p, C.c_uint64]),
         "cm_write_sam_header": (C.c_int, [vp]),
         "cm_write_sam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_writer_close": (None, [vp]),
@@ -225,7 +237,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
 
 class HostIndex:
@@ -407,6 +419,33 @@ def circ_report(calls, path: str):
     rc = load().cm_circ_report(arr, len(keep), path.encode())
     if rc != 0:
         raise RuntimeError(f"cm_circ_report failed ({rc})")
+
+
+def circ_call(params, host_index, chr_table, sorted_batch, candidates_path, report_path, window=0):
+    """cm_circ_call on an in-memory index: sorted_batch = the ParsedBatch read from the sorted remain files."""
+    L = load()
+    n_con = host_index.n_contigs
+    views = (IndexView * n_con)(*host_index.views)
+    chrs = chr_array(list(chr_table))
+    st = CircStats()
+    rc = L.cm_circ_call(C.byref(params), window, n_con, views, host_index.annots, chrs, len(chr_table), C.byref(sorted_batch.fb),
+                        candidates_path.encode(), report_path.encode(), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"cm_circ_call failed ({rc})")
+    return st
+
+
+def run_circ(index_path, gtf, out_prefix, last_round, params=None, n_threads=4, index_info=None, window=0):
+    """cm_circ_run: stage 2 from files to files (the reference's circ_detect(), src/circminer.cpp:347-352)."""
+    L = load()
+    a = CircArgs(index_path.encode(), (index_info or index_path + ".info").encode(), gtf.encode(), out_prefix.encode(),
+                 params if params is not None else default_params(kmer=0), last_round, window, n_threads, 0)
+    st = CircStats()
+    err = C.create_string_buffer(1024)
+    rc = L.cm_circ_run(C.byref(a), C.byref(st), err, len(err))
+    if rc != 0:
+        raise RuntimeError(f"cm_circ_run failed ({rc}): {err.value.decode()}")
+    return st
 
 
 def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report=1, n_threads=4, batch_pairs=0, index_info=None):

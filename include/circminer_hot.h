@@ -379,7 +379,7 @@ typedef struct cm_mapping_stats {
 } cm_mapping_stats;
 int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *err, uint64_t err_cap);
 
-/* ---------------- stage 2, first and last step (SURVEY.md §8(f) N3 -- the BSJ calling in between is not built) -------- */
+/* ---------------- stage 2: ProcessCirc, src/process_circ.cpp -- host code, no GPU involved -------- */
 /* ProcessCirc::sort_fq (src/process_circ.cpp:179-193): the remain FASTQ of the last round ordered like
  * `paste - - - - | sort -k2,2n | tr "\t" "\n"` does in the C locale (key = genome_spos, ties by the whole pasted line). */
 int cm_sort_remain(const char *in_path, const char *out_path);
@@ -397,6 +397,31 @@ typedef struct cm_circ_res {
     const char *start_signal, *end_signal, *start_bp_ref, *end_bp_ref;
 } cm_circ_res;
 int cm_circ_report(const cm_circ_res *res, uint64_t n, const char *report_path);
+/* The back-splice-junction calling between the two (ProcessCirc::do_process, src/process_circ.cpp:195-331: call_circ_single_split /
+ * call_circ_double_split :360-645, chaining of 8-mer seeds inside the overlapping genes :677-737 + src/chain.cpp:310-539,
+ * find_exact_coord :739-789, check_split_map :892-1134, final_check :1136-1341, split_realignment :1343-1486,
+ * rescue_overlapping_bsj :1488-1552) over records that are already in the order of the sorted remain files: `sorted` is one
+ * batch from cm_fastq_next on <out>_<R>_remain_R{1,2}.fastq.srt (its `prior` = the MatchedRead each pair carries in its header).
+ * Writes <out>.candidates.pam rows (print_split_mapping :1670-1708 + type) to candidates_path and the <out>.circ_report rows
+ * (report_events) to report_path.  window_size 0 = 8 (circ_detect, src/circminer.cpp:347-352). */
+typedef struct cm_circ_stats {
+    uint64_t pairs, candidate_rows, calls;
+    double seconds;
+} cm_circ_stats;
+int cm_circ_call(const cm_params *p, int32_t window_size, uint32_t n_contigs, const cm_index_view *contigs, const cm_annot_view *annots,
+                 const cm_chr_info *chrs, uint32_t n_chr, const cm_fastq_batch *sorted, const char *candidates_path,
+                 const char *report_path, cm_circ_stats *stats);
+/* circ_detect() of the reference (src/circminer.cpp:347-352) from files to files: sorts <out>_<last_round>_remain_R{1,2}.fastq
+ * (-> .srt), loads the packed genome from the index file and the GTF, calls the junctions, writes <out>.candidates.pam and
+ * <out>.circ_report.  params.kmer == 0 takes the index file's k. */
+typedef struct cm_circ_args {
+    const char *index_path, *index_info_path, *gtf_path, *out_prefix;
+    cm_params params;
+    int32_t last_round;            /* number of packed contigs = suffix of the remain files */
+    int32_t window_size;           /* 0 = 8 */
+    int32_t n_threads, reserved;
+} cm_circ_args;
+int cm_circ_run(const cm_circ_args *args, cm_circ_stats *stats, char *err, uint64_t err_cap);
 
 #ifdef __cplusplus
 }

@@ -397,6 +397,14 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
         for k, i in enumerate(keep):
             assert lines[4 * k] == py_remain_header(names[i], want[i], chrs)
             assert lines[4 * k + 1:4 * k + 4] == [seqs[i], "+", quals[i % 16]]
+    # stage 2 on the files the device path just wrote (cm_circ_run = circ_detect): candidates.pam and circ_report equal the
+    # oracle's restatement of ProcessCirc fed with the GNU-sorted remain files
+    from stage2_util import gnu_sort, oracle_stage2
+    cs = cl.run_circ(idx, gtf, out, hi.n_contigs, cl.default_params(kmer=0))
+    rem = [f"{out}_{hi.n_contigs}_remain_R{m}.fastq" for m in (1, 2)]
+    want_c, want_r = oracle_stage2(tmp_path, hi, d, P20, gnu_sort(rem[0]), gnu_sort(rem[1]))
+    assert open(out + ".candidates.pam", "rb").read() == want_c and open(out + ".circ_report", "rb").read() == want_r
+    assert cs.pairs == len(keep) and cs.calls > 0 and want_r.count(b"\n") > 0
     # the same run from plain C++ (examples/cm_map.cpp: no Python, no torch in the process): identical files
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -407,7 +415,9 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
     out2 = str(tmp_path / "run_cpp")
     msg = subprocess.check_output([exe, idx, gtf, fq[0], fq[1], out2, "pam" if report == 1 else "sam"], text=True)
     assert msg.startswith(f"{n} pairs, {hi.n_contigs} round(s), {int(act.sum())} BSJ")
-    for suffix in ([".mapping.pam"] if report == 1 else [".mapping.sam"]) + [f"_{hi.n_contigs}_remain_R{m}.fastq" for m in (1, 2)]:
+    assert "stage 2:" in msg
+    for suffix in ([".mapping.pam"] if report == 1 else [".mapping.sam"]) + [f"_{hi.n_contigs}_remain_R{m}.fastq" for m in (1, 2)] + \
+            [".candidates.pam", ".circ_report"]:
         assert open(out + suffix, "rb").read() == open(out2 + suffix, "rb").read(), suffix
     # bad input is an error message, not a crash
     with pytest.raises(RuntimeError, match="k = 20"):

@@ -1218,7 +1218,6 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_bsum, nb, ctx->d_celloff + n_prob);
         hipLaunchKernelGGL(k_scan_c, dim3((n_prob + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, ctx->stream, ctx->d_celloff, ctx->d_bsum, n_prob);
         ctx->launches[3] += 3;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_celloff + n_prob, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1261,11 +1260,12 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
                            (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
         ctx->launches[5] += 4;
     }
-    for (auto &rg : ranges) {
-        unsigned long long base = 0;
-        if (rg.first != 0) base = ctx->h_celloff[rg.first];
-        const uint32_t n = rg.second - rg.first;
-        if (split) {          // the few long problems run on the second stream, concurrently with the bulk
+    // one launch group over problems [a, b) whose DP cells start at `base`: the improvement log of every problem comes out of the
+    // shared pool, whose cursor starts at 0 for every group
+    auto launch_group = [&](uint32_t a, uint32_t b, unsigned long long base, bool use_split) -> int {
+        const uint32_t n = b - a;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
+        if (use_split) {          // the few long problems run on the second stream, concurrently with the bulk
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             {
@@ -1281,13 +1281,67 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         }
         Timer t(ctx, 1);
-        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, rg.first,
-                           rg.second, S, ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
+        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, a, b, S,
+                           ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
                            ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid,
-                           split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cls_ctr + CTR_SUM);
-        if (split) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // timed with the light kernel: the stage ends here
+                           use_split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cls_ctr + CTR_SUM);
+        if (use_split) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // timed with the light kernel: the stage ends here
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
+        return CM_OK;
+    };
+    // did the group run out of log space?  (one small read-back per group; the pair stage must not start on truncated logs)
+    auto pool_lost = [&](bool *lost) -> int {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 2, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const int e = *(const int *)(ctx->h_pin + 2);
+        *lost = (e & cmc::ERR_POOL) != 0;
+        if (*lost) {                                          // the other flags stay for cm_sync to report
+            const int keep = e & ~cmc::ERR_POOL;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_err, &keep, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return CM_OK;
+    };
+    const unsigned long long pool_max = getenv("CM_POOL_MAX") ? strtoull(getenv("CM_POOL_MAX"), nullptr, 10) : (48ull << 30);
+    for (auto &rg : ranges) {
+        unsigned long long base = 0;
+        if (rg.first != 0) base = ctx->h_celloff[rg.first];
+        int rc = launch_group(rg.first, rg.second, base, split);
+        if (rc) return rc;
+        bool lost = false;
+        if ((rc = pool_lost(&lost))) return rc;
+        // The reference's score2chain has no capacity limit.  When the log pool ran out: first a larger pool (x4 up to pool_max)
+        // and the same group again; then the group in halves on the one-lane-per-problem kernel, every piece with the whole pool
+        // to itself.  Every retry recomputes its problems from the seeds, so nothing of the failed attempt survives.
+        while (lost && ctx->pool_bytes < pool_max) {
+            unsigned long long want = ctx->pool_bytes * 4ull;
+            if (want > pool_max) want = pool_max;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+            if (ensure(ctx, ctx->d_pool, want) != hipSuccess) {            // not enough HBM for a larger pool: keep the old size, go to the split path
+                (void)hipGetLastError();
+                HIPCHK(ctx, ensure(ctx, ctx->d_pool, ctx->pool_bytes));
+                break;
+            }
+            ctx->pool_bytes = want;
+            if ((rc = launch_group(rg.first, rg.second, base, split))) return rc;
+            if ((rc = pool_lost(&lost))) return rc;
+        }
+        if (lost) {
+            std::vector<std::pair<uint32_t, uint32_t>> todo{{rg.first, rg.second}};
+            while (!todo.empty()) {
+                const auto pc = todo.back();
+                todo.pop_back();
+                if ((rc = launch_group(pc.first, pc.second, base, false))) return rc;
+                if ((rc = pool_lost(&lost))) return rc;
+                if (!lost) continue;
+                if (pc.second - pc.first <= 1)
+                    return fail(ctx, CM_ELIMIT, "one chaining problem's improvement log does not fit %llu bytes", ctx->pool_bytes);
+                const uint32_t mid = pc.first + (pc.second - pc.first) / 2;
+                todo.push_back({mid, pc.second});
+                todo.push_back({pc.first, mid});
+            }
+        }
     }
     return CM_OK;
 }
@@ -1297,6 +1351,7 @@ int check_dev_err(cm_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int e = *(const int *)ctx->h_pin;
     if (e) {
+        (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);       // reported once: the next batch starts clean
         return fail(ctx, CM_ELIMIT, "device capacity limit hit:%s%s%s", (e & cmc::ERR_POOL) ? " chain improvement-log pool exhausted;" : "",
                     (e & (cmc::ERR_SEEDS | cmc::ERR_BAND)) ? " DP string longer than the staging buffer;" : "",
                     (e & cmc::ERR_MEMO) ? " extension memo overflowed where the reference's memo would have served a colliding key" : "");
@@ -1556,6 +1611,10 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     unsigned long long pool = (unsigned long long)nprob * 2048ull;       // improvement log
     if (pool < (256ull << 20)) pool = 256ull << 20;
     if (pool > (8ull << 30)) pool = 8ull << 30;
+    if (const char *e = getenv("CM_POOL_BYTES")) {       // test knob: start with a small log pool to exercise the recovery path
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 4096 && !ctx->d_pool) pool = v;
+    }
     if (pool > ctx->pool_bytes || !ctx->d_pool) ctx->pool_bytes = pool;
     HIPCHK(ctx, ensure(ctx, ctx->d_pool, ctx->pool_bytes));
     return CM_OK;

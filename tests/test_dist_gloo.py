@@ -80,3 +80,22 @@ def test_two_rank_gather_equals_single_process(ds_tiny):
     idx = np.nonzero(act)[0].astype(np.uint64)
     want = cdist.pack_records(idx, st[idx])
     assert len(got) == len(want) and got.tobytes() == want.tobytes()
+
+
+def test_bench_gpus_n_starts_n_ranks_and_fails_cleanly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two fresh rank processes (RANK / WORLD_SIZE / MASTER_* set,
+    nothing GPU-related touched in the parent); on this GPU-less box both ranks join the process group (gloo rehearsal), find no
+    HIP device, leave the group and exit non-zero -- no hang, no CPU fallback, no JSON line."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the CPU-only rehearsal")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a HIP device") >= 2 and "rank exit codes [1, 1]" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a launcher-provided WORLD_SIZE that disagrees with --gpus is refused up front
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr

@@ -486,3 +486,14 @@ def test_staged_batches_overlap_and_match(ds_tiny2r, ds_dirty):
     st2 = hp.download()[0]
     assert st2.tobytes() == want[idx].tobytes()
     hp.close()
+
+
+@pytest.mark.parametrize("pool_max", [None, 1 << 18])
+def test_improvement_log_pool_recovers(ds_small, monkeypatch, pool_max):
+    """The chain improvement log has no capacity limit in the reference (score2chain, src/chain.cpp:191-206).  Here it comes out
+    of a pool; when that runs out the stage is redone with a larger pool, and beyond CM_POOL_MAX in halves that get the whole
+    pool each -- never a failed batch.  Forced with a 64 KB pool: results must still equal the oracle's."""
+    monkeypatch.setenv("CM_POOL_BYTES", "65536")
+    if pool_max:
+        monkeypatch.setenv("CM_POOL_MAX", str(pool_max))
+    _run_all_rounds(ds_small, cl.default_params(kmer=ds_small.kmer))

@@ -566,7 +566,8 @@ __device__ inline int pair_class(const Core &c, const cm_chain *chains, const ui
     if (!active[p]) return -2;
     const int32_t *nc = nchain + 4 * (uint64_t)t;
     const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
-    if ((a * d + cc * b + a + b + cc + d) > heavy_cost) {
+    // a pair with chains on one mate only is settled without any extension (OEANCH, src/filter.cpp:196-203): never heavy
+    if ((a + b) > 0 && (cc + d) > 0 && (a * d + cc * b + a + b + cc + d) > heavy_cost) {
         if (sub) {          // heavy pairs: cost level as the first radix key, so that k_pair_heavy starts with the longest ones
             const int cost = a * d + cc * b + a + b + cc + d;
             const int lv = cost <= 12 ? 0 : cost <= 16 ? 1 : cost <= 24 ? 2 : cost <= 32 ? 3 : cost <= 48 ? 4 : cost <= 64 ? 5 : cost <= 96 ? 6 : cost <= 128 ? 7
@@ -740,11 +741,13 @@ struct HRes {            // outcome of one mate-pair task, handed from the compu
     int32_t pair_type;
     uint8_t ok, is_left, pad[2];
 };
+constexpr int HEAVY_SCRATCH = 912 * 3;   // bytes of per-block global scratch behind HRes[64]: list[912] (u16) + codes[912]
 struct HeavyLds {
-    CM_L uint8_t *codes;     // pairing predicate per (i, j), i-major          [900]
-    CM_L uint16_t *list;     // accepted (i, j) in order                        [900]
+    CM_G uint8_t *codes;     // pairing predicate per (i, j), i-major          [900]   (global: see res)
+    CM_G uint16_t *list;     // accepted (i, j) in order                        [900]   (global: see res)
     CM_L int *fe, *re;       // exon interval of each chain's first fragment    [32] + [32]
-    CM_G HRes *res;          // [64], this block's slice of a global buffer (LDS is what limits this kernel's occupancy)
+    CM_G HRes *res;          // [64], this block's slice of a global buffer.  LDS is what limits this kernel's occupancy: with the
+                             // two DP strings + fe/re only (< 10 KB per wave) four waves per SIMD fit, with codes/list in LDS three
 };
 
 __device__ inline int nth_set_bit(uint32_t m, int k) {
@@ -764,14 +767,32 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     const int saved_type = mr.type;
     const cmc::Ext ext(c, sm);
     uint32_t tids[cmc::MAX_TID];
-    if (lane < fwd.n) H.fe[lane] = cmc::overlap(c, fwd.ch[lane].rpos[0]);
-    if (lane >= 32 && lane - 32 < bwd.n) H.re[lane - 32] = cmc::overlap(c, bwd.ch[lane - 32].rpos[0]);
+    // lane i < 32 keeps the span of forward chain i, lane 32 + j that of backward chain j: the T = n x m predicate evaluations
+    // below fetch them with shuffles instead of 6 global loads each
+    uint32_t my_r0 = 0, my_rend = 0;
+    if (lane < fwd.n) {
+        const cmc::CHEnds e{fwd.ch + lane, kmer};
+        my_r0 = e.r0;
+        my_rend = e.rend;
+        H.fe[lane] = cmc::overlap(c, e.r0);
+    }
+    if (lane >= 32 && lane - 32 < bwd.n) {
+        const cmc::CHEnds e{bwd.ch + (lane - 32), kmer};
+        my_r0 = e.r0;
+        my_rend = e.rend;
+        H.re[lane - 32] = cmc::overlap(c, e.r0);
+    }
     __syncthreads();
     const int T = fwd.n * bwd.n;
     uint32_t fp = 0, bp = 0;
-    for (int idx = lane; idx < T; idx += 64) {
-        const int i = idx / bwd.n, j = idx - i * bwd.n;
-        const cmc::CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
+    for (int base = 0; base < T; base += 64) {            // uniform trip count: the shuffles need every lane
+        const int idx = base + lane;
+        const int ic = idx < T ? idx / bwd.n : 0, jc = idx < T ? idx - ic * bwd.n : 0;
+        const uint32_t f0 = (uint32_t)__shfl((int)my_r0, ic), f1 = (uint32_t)__shfl((int)my_rend, ic);
+        const uint32_t b0 = (uint32_t)__shfl((int)my_r0, 32 + jc), b1 = (uint32_t)__shfl((int)my_rend, 32 + jc);
+        if (idx >= T) continue;
+        const int i = ic, j = jc;
+        const cmc::CHEnds F{f0, f1}, R{b0, b1};
         const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type);
         H.codes[idx] = (uint8_t)code;
         if (code) {
@@ -908,10 +929,11 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc
     H.res = (CM_G HRes *)(hres + (size_t)blockIdx.x * 64);
     H.fe = (CM_L int *)q;
     H.re = H.fe + 32;
-    q += 64 * sizeof(int);
-    H.list = (CM_L uint16_t *)q;
-    q += 912 * sizeof(uint16_t);
-    H.codes = q;
+    {
+        CM_G uint8_t *g = (CM_G uint8_t *)(hres + (size_t)gridDim.x * 64) + (size_t)blockIdx.x * HEAVY_SCRATCH;
+        H.list = (CM_G uint16_t *)g;
+        H.codes = g + 912 * sizeof(uint16_t);
+    }
     const Core c = cmc::to_core(kc);
     const unsigned int n_heavy = *hcount;
     for (unsigned int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
@@ -1590,7 +1612,7 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)4096 * 64 * sizeof(HRes)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)4096 * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_sub, (size_t)tile));
@@ -1747,7 +1769,7 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
             // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
             const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
             const size_t lds_bytes = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
-            const size_t lds_heavy = lds_bytes + 64 * sizeof(int) + 912 * sizeof(uint16_t) + 912;
+            const size_t lds_heavy = lds_bytes + 64 * sizeof(int);
             {
             Timer t(ctx, 5);
             const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;

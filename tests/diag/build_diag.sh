@@ -5,8 +5,9 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="$ROOT/tests/_hostemu"; mkdir -p "$OUT"
-for f in cm_hot.hip host_index.cpp host_annot.cpp host_index_io.cpp host_fastq.cpp host_mapping.cpp host_circ.cpp; do
-  /opt/rocm/bin/hipcc -c -O3 -std=c++17 -fPIC -ffp-contract=off ${DIAG_FLAGS--DCM_DIAG} --offload-arch=gfx950 -I"$ROOT/include" -I"$ROOT/circminer_amd/csrc" \
+for f in cm_hot.hip host_index.cpp host_annot.cpp host_index_io.cpp host_fastq.cpp host_mapping.cpp host_circ.cpp host_circ_call.cpp; do
+  if [ "${f##*.}" = "hip" ]; then X="--offload-arch=gfx950"; else X="-x c++"; fi
+  /opt/rocm/bin/hipcc $X -c -O3 -std=c++17 -fPIC -ffp-contract=off ${DIAG_FLAGS--DCM_DIAG} -I"$ROOT/include" -I"$ROOT/circminer_amd/csrc" \
       "$ROOT/circminer_amd/csrc/$f" -o "$OUT/${DIAG_NAME-diag}_${f%.*}.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libcmhot_${DIAG_NAME-diag}.so" "$OUT/${DIAG_NAME-diag}"_*.o -lpthread -lz

@@ -4,10 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ['CM_LIB'] = os.path.join(ROOT, 'tests/_hostemu/libcmhot_diag.so'); os.environ['CM_LANE_CLK'] = '1'
 from circminer_amd import lib as cl, synth
-N = 262144
-d = synth.generate('chr21', n_pairs=N, seed=21)
+N = int(os.environ.get('PAIRS', '262144'))
+d = synth.generate(os.environ.get('PRESET', 'chr21'), n_pairs=N, seed=int(os.environ.get('SEED', '21')))
 open('/tmp/c.gtf', 'w').write(d.gtf_text)
-hi = cl.HostIndex(d.contigs, d.chr_table, '/tmp/c.gtf')
+hi = cl.HostIndex(d.contigs[:1], [t for t in d.chr_table if t[1] == 1], '/tmp/c.gtf', n_threads=32)
 P = cl.default_params(); hp = cl.HotPath(P); hp.load_contig(0, hi.views[0], hi.annots[0])
 hp.L.cm_debug_lane_clk.argtypes = [C.c_void_p, C.c_void_p]
 b = cl.ReadBatch(d.seq1, d.seq2); hp.upload(b)

@@ -615,153 +615,10 @@ CM_HD inline int chain_kbest_t(const Core &c, int seq_len, int kc, ST &S, CM_G c
     return (int)best_count;
 }
 
-// chain_seeds_sorted_kbest for the commonest shape of problem: at most UQ seeds, every seed with at most ONE retained hit (a read
-// from unique sequence).  Same recurrence, same improvement log and same back-tracking as chain_kbest_t, but one cell per seed
-// means every array is indexed by the seed ordinal: with the loops fully unrolled all state lives in registers (no scratch rows,
-// no DP cells in global memory, no log pool).  ev[ii][jj] = score logged when cell ii improved through cell jj (generation order
-// = ii descending, jj ascending = the reference's insertion order), NO_EV = no improvement there.
-constexpr int UQ = 8;
-template <class T> CM_HD inline T uq_sel(const T (&a)[UQ], int i) {          // a[i] for a register array: select chain, no dynamic indexing
-    T v = a[0];
-#pragma unroll
-    for (int x = 1; x < UQ; ++x) v = (i == x) ? a[x] : v;
-    return v;
-}
-CM_HD inline int chain_unique(const Core &c, int seq_len, int kc, const uint32_t *start, const uint32_t *cnt, CM_G cm_chain *out) {
-    const int kmer = c.P.kmer;
-    const uint32_t max_best = (uint32_t)c.P.max_chain_len;
-    const double NO_EV = -1.0;
-    bool has[UQ];
-    uint32_t pos[UQ];
-    double sc[UQ];
-    int pv[UQ];
-    double ev[UQ][UQ];
-#pragma unroll
-    for (int s = 0; s < UQ; ++s) {
-        has[s] = s < kc && cnt[s] == 1;
-        pos[s] = has[s] ? c.X.pos[start[s]] : 0u;
-        sc[s] = (double)kmer;
-        pv[s] = -1;
-#pragma unroll
-        for (int t = 0; t < UQ; ++t) ev[s][t] = NO_EV;
-    }
-    bool any_ev = false;
-    double best_score = 0;
-#pragma unroll
-    for (int ii = UQ - 2; ii >= 0; --ii) {
-        if (!has[ii] || ii > kc - 2) continue;
-        const uint32_t read_remain = (uint32_t)(seq_len - ii * kmer - kmer);
-        const int32_t cur_info = (int32_t)pos[ii];
-        const uint32_t seg_start = (uint32_t)cur_info, seg_end = (uint32_t)cur_info + kmer - 1;
-        uint32_t max_lpos_lim = MAXUB, max_exon_end = 0;
-        int ol = -1;
-        double my_score = sc[ii];
-#pragma unroll
-        for (int jj = ii + 1; jj < UQ; ++jj) {
-            if (!has[jj]) continue;
-            const uint32_t pinfo = pos[jj];
-            if (cur_info + c.P.max_intron < (int32_t)pinfo) continue;
-            if ((int32_t)pinfo <= cur_info) continue;
-            if (max_lpos_lim == MAXUB) max_lpos_lim = upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
-            if (pinfo > max_lpos_lim) continue;
-            const int distr = (jj - ii) * kmer - kmer;
-            int genome_dist, distt, trans_dist;
-            if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
-            else genome_dist = INF_I;
-            if (cabs(genome_dist - distr) <= c.P.max_ed) distt = genome_dist;
-            else if (check_junction(c, seg_start, pinfo, ol, kmer, distr, trans_dist)) distt = trans_dist;
-            else continue;
-            const int maxd = distr < distt ? distt : distr, mind = distr < distt ? distr : distt;
-            const double beta = 0.1 * (double)(maxd - mind);
-            const double alpha = 2e4 * (double)kmer;
-            const double t1 = sc[jj] + alpha;                       // (prev + alpha) - beta, no contraction
-            const double temp_score = t1 - beta;
-            if (temp_score > my_score) {
-                my_score = temp_score;
-                pv[ii] = jj;
-                ev[ii][jj] = temp_score;
-                best_score = (!any_ev || temp_score > best_score) ? temp_score : best_score;
-                any_ev = true;
-            }
-        }
-        sc[ii] = my_score;
-    }
-    uint32_t best_count = 0;
-    if (any_ev) {
-        uint32_t inner = 0;                  // seeds emitted as a non-first fragment so far (`repeats` holds their positions)
-        double cur = best_score;
-        bool have = true;
-        while (have && best_count < max_best) {
-            uint32_t in_group = 0;
-            bool stop = false;
-#pragma unroll
-            for (int ii = UQ - 2; ii >= 0; --ii) {
-#pragma unroll
-                for (int jj = ii + 1; jj < UQ; ++jj) {
-                    if (stop || best_count >= max_best || !(ev[ii][jj] == cur)) continue;
-                    if (in_group >= max_best) { stop = true; continue; }
-                    ++in_group;
-                    const uint32_t spos = pos[ii];
-                    if (cur < best_score) {
-                        bool rep = false;
-#pragma unroll
-                        for (int x = 0; x < UQ; ++x) rep |= ((inner >> x) & 1u) && pos[x] == spos;
-                        if (rep) continue;
-                    }
-                    CM_G cm_chain &ch = out[best_count++];
-                    uint32_t n = 0;
-                    int bl = ii;
-                    while (bl >= 0) {
-                        ch.rpos[n] = uq_sel(pos, bl);
-                        ch.qpos[n] = bl * kmer;
-                        if (n) inner |= 1u << bl;
-                        ++n;
-                        bl = uq_sel(pv, bl);
-                    }
-                    ch.score = (float)cur;
-                    ch.chain_len = n;
-                }
-            }
-            have = false;                    // next lower score
-            double nxt = 0;
-#pragma unroll
-            for (int ii = 0; ii < UQ - 1; ++ii)
-#pragma unroll
-                for (int jj = ii + 1; jj < UQ; ++jj) {
-                    const double e = ev[ii][jj];
-                    if (e != NO_EV && e < cur && (!have || e > nxt)) {
-                        nxt = e;
-                        have = true;
-                    }
-                }
-            cur = nxt;
-        }
-    }
-    if (best_count == 0) {      // singletons, src/chain.cpp:283-298
-#pragma unroll
-        for (int ii = UQ - 1; ii >= 0; --ii) {
-            if (!has[ii] || best_count >= max_best) continue;
-            CM_G cm_chain &ch = out[best_count++];
-            ch.rpos[0] = pos[ii];
-            ch.qpos[0] = ii * kmer;
-            ch.score = (float)sc[ii];
-            ch.chain_len = 1;
-        }
-    }
-    return (int)best_count;
-}
-
 CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint32_t *start, const uint32_t *cnt, ChainWork &w, CM_G cm_chain *out) {
     int kc = n_seeds;
     while (kc >= 1 && cnt[kc - 1] == 0) --kc;
     if (kc <= 0) return 0;
-#if !defined(CM_NO_UNIQUE_CHAIN)
-    if (kc <= UQ) {
-        bool uniq = true;
-        for (int s = 0; s < kc; ++s) uniq &= cnt[s] <= 1u;
-        if (uniq) return chain_unique(c, seq_len, kc, start, cnt, out);
-    }
-#endif
     uint32_t base[MAX_SEEDS + 1];
     base[0] = 0;
     unsigned long long pairs = 0;

@@ -245,8 +245,7 @@ def main():
         # H2D of the next batch on the copy stream, concurrent with the rounds of the resident one
         turn[0] ^= 1
         hp.stage(batches[turn[0]])
-        for ci in range(hi.n_contigs):
-            hp.map_round(ci, ci == hi.n_contigs - 1)
+        hp.map_rounds(list(range(hi.n_contigs)), True)
         # BSJ hand-off to stage 2: records assembled on the device.  One GPU: one small D2H.  N GPUs: gatherv to rank 0 over
         # RCCL from HBM; rank 0's D2H of the gathered records overlaps the next step's rounds and is waited for in fence().
         if multi:

@@ -619,7 +619,7 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
 }
 __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
                                                  const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost,
-                                                 int8_t *cls_sub, int8_t *cls_sub2) {
+                                                 int8_t *cls_sub, int8_t *cls_sub2, uint8_t *act_out) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
@@ -628,7 +628,10 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chai
     cls[t] = (int8_t)k;
     cls_sub[t] = (int8_t)(k < 0 ? -2 : (k == HEAVY_CLS ? 0 : (sub & 15)));    // secondary key
     cls_sub2[t] = (int8_t)(k < 0 ? -2 : (sub >> 4));                           // tertiary key (first pass of the radix sort)
-    if (k == -2) cat[pair0 + t] = -1;                  // retired in an earlier round: not mapped
+    if (k == -2) {                                     // retired in an earlier round: not mapped, stays retired
+        cat[pair0 + t] = -1;
+        act_out[pair0 + t] = 0;
+    }
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
 __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high,
@@ -1013,6 +1016,9 @@ __global__ void __launch_bounds__(BLK) k_gather_records(const uint32_t *perm, co
     out[i].state = state[p];
 }
 
+__global__ void k_err_clear(int *err, int mask) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAnd(err, ~mask);
+}
 __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
@@ -1041,6 +1047,11 @@ struct cm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // heavy work of a stage, concurrent with the light kernel on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The pair stage of round r runs on its own pair of streams while `stream` / `stream2` already seed and chain round r + 1
+    // (cm_map_rounds): seeds and chains are functions of (read, contig) only, the carried state enters in the pair stage.
+    hipStream_t stream_p = nullptr, stream_p2 = nullptr;
+    hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
+    bool pair_pending[2] = {false, false};
     unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
     std::string err = "";
     Slot slots[MAX_SLOTS];
@@ -1049,7 +1060,8 @@ struct cm_ctx {
     uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr, *d_seq1_base = nullptr, *d_seq2_base = nullptr;
     uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
     cm_mapped_read *d_state = nullptr;
-    uint8_t *d_active = nullptr;
+    uint8_t *d_active = nullptr;              // current flags (valid after the last completed round)
+    uint8_t *d_active_b = nullptr;            // the other parity: a round reads one array and writes the other
     int32_t *d_cat = nullptr;
     int n_seeds = 0, max_len = 0;
     // staged batch (cm_reads_stage): a second set of read buffers filled on the copy stream while the resident batch is mapped
@@ -1069,8 +1081,13 @@ struct cm_ctx {
     double *d_dpscore = nullptr;
     int32_t *d_dpprev = nullptr;
     unsigned long long cells_cap = 0;
-    cm_chain *d_chains = nullptr;
-    int32_t *d_nchain = nullptr, *d_high = nullptr;
+    cm_chain *d_chains = nullptr;             // chains of a round: two sets, the pair stage of round r reads set r & 1 while
+    int32_t *d_nchain = nullptr, *d_high = nullptr;       // the chaining of round r + 1 fills the other
+    cm_chain *d_chains_b = nullptr;
+    int32_t *d_nchain_b = nullptr, *d_high_b = nullptr;
+    uint16_t *d_resid_b = nullptr;
+    unsigned int *d_cctr = nullptr, *d_cblk = nullptr;    // class counters / block histograms of the CHAIN stage's sort (own copies: the
+                                                          // pair stage of the previous round uses d_cls_ctr / d_blk_cnt at the same time)
     unsigned long long *d_lane_clk = nullptr;     // diagnostic build of the timing study only
     int8_t *d_cls = nullptr, *d_cls4 = nullptr, *d_cls_sub = nullptr, *d_cls_sub2 = nullptr;
     uint32_t *d_perm1 = nullptr, *d_perm0 = nullptr;
@@ -1156,7 +1173,8 @@ hipError_t ensure(cm_ctx *c, T *&p, size_t bytes) {
 
 void free_reads(cm_ctx *c) {
     dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
-    dfree(c->d_state); dfree(c->d_active); dfree(c->d_cat);
+    dfree(c->d_state); dfree(c->d_active); dfree(c->d_active_b); dfree(c->d_cat);
+    dfree(c->d_chains_b); dfree(c->d_nchain_b); dfree(c->d_high_b); dfree(c->d_resid_b); dfree(c->d_cctr); dfree(c->d_cblk);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
@@ -1215,20 +1233,25 @@ int check_slot(cm_ctx *ctx, int slot, bool need_annot) {
 }
 
 // seeds (+ optionally chains) of one tile; leaves results in the workspace
-int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile) {
+struct RoundBufs { cm_chain *chains; int32_t *nchain, *high; uint16_t *resid; };
+RoundBufs round_bufs(cm_ctx *c, int b) {
+    return b ? RoundBufs{c->d_chains_b, c->d_nchain_b, c->d_high_b, c->d_resid_b} : RoundBufs{c->d_chains, c->d_nchain, c->d_high, c->d_resid};
+}
+
+int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, const uint8_t *act) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     const int S = ctx->n_seeds;
     const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
     if (total == 0) return CM_OK;
     Timer t(ctx, 0);
-    hipLaunchKernelGGL(k_seed, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, core, rd, ctx->d_active, pair0, n_tile, S,
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, core, rd, act, pair0, n_tile, S,
                        ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_counters);
     ++ctx->launches[0];
     HIPCHK(ctx, hipGetLastError());
     return CM_OK;
 }
 
-int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, bool parallel_ok) {
+int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, bool parallel_ok, const uint8_t *act, const RoundBufs &rb) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
@@ -1273,12 +1296,12 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
     if (split) {
         Timer t(ctx, 5);
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
-        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, ctx->d_high,
-                           light_w, light_cells, ctx->d_nchain, ctx->d_resid);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, rb.high,
+                           light_w, light_cells, rb.nchain, rb.resid);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_cblk, nbk, (const uint32_t *)nullptr,
                            (const unsigned int *)nullptr);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm4,
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cblk, nbk, ctx->d_cctr, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_cblk, nbk, ctx->d_cctr, ctx->d_perm4,
                            (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
         ctx->launches[5] += 4;
     }
@@ -1296,17 +1319,17 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
             const uint32_t hb = n < 8192u ? n : 8192u;
             hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
-                               ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_err,
-                               ctx->d_resid, ctx->d_perm4, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1);
+                               ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, ctx->d_err,
+                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1);
             ++ctx->launches[6];
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         }
         Timer t(ctx, 1);
-        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, ctx->d_active, pair0, a, b, S,
+        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, act, pair0, a, b, S,
                            ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
-                           ctx->pool_bytes, ctx->d_pool_cursor, ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_err, ctx->d_resid,
-                           use_split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cls_ctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cls_ctr + CTR_SUM);
+                           ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, rb.high, ctx->d_err, rb.resid,
+                           use_split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + CTR_SUM);
         if (use_split) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // timed with the light kernel: the stage ends here
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
@@ -1318,9 +1341,8 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const int e = *(const int *)(ctx->h_pin + 2);
         *lost = (e & cmc::ERR_POOL) != 0;
-        if (*lost) {                                          // the other flags stay for cm_sync to report
-            const int keep = e & ~cmc::ERR_POOL;
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_err, &keep, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (*lost) {                                          // the other flags stay for cm_sync to report (the pair stage of the
+            hipLaunchKernelGGL(k_err_clear, dim3(1), dim3(64), 0, ctx->stream, ctx->d_err, (int)cmc::ERR_POOL);   // previous round may be setting some right now)
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         return CM_OK;
@@ -1403,6 +1425,15 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     ctx->P = *p;
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_p2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork_p, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join_p, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_prep[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_prep[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pair[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pair[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_retired, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1432,6 +1463,8 @@ void cm_destroy(cm_ctx *ctx) {
     (void)hipSetDevice(ctx->P.device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream_p) (void)hipStreamSynchronize(ctx->stream_p);
+    if (ctx->stream_p2) (void)hipStreamSynchronize(ctx->stream_p2);
     for (auto e : ctx->ev_free) (void)hipEventDestroy(e);
     ctx->ev_free.clear();
     for (auto &r : ctx->recs) {
@@ -1452,6 +1485,10 @@ void cm_destroy(cm_ctx *ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (hipEvent_t e : {ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream_p) (void)hipStreamDestroy(ctx->stream_p);
+    if (ctx->stream_p2) (void)hipStreamDestroy(ctx->stream_p2);
     if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
     if (ctx->ev_retired) (void)hipEventDestroy(ctx->ev_retired);
     if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
@@ -1578,6 +1615,7 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     ctx->max_len = max_len;
     HIPCHK(ctx, ensure(ctx, ctx->d_state, n * sizeof(cm_mapped_read)));
     HIPCHK(ctx, ensure(ctx, ctx->d_active, n));
+    HIPCHK(ctx, ensure(ctx, ctx->d_active_b, n));
     HIPCHK(ctx, ensure(ctx, ctx->d_cat, n * sizeof(int32_t)));
     // workspace for one tile
     uint32_t tile_cap = TILE_PAIRS;
@@ -1606,6 +1644,12 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_chains, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
     HIPCHK(ctx, ensure(ctx, ctx->d_nchain, nprob * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_high, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_chains_b, nprob * CM_BESTCHAINLIM * sizeof(cm_chain)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_nchain_b, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_high_b, nprob * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_resid_b, (size_t)tile * 4 * sizeof(uint16_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cctr, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cblk, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls, (size_t)tile));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls4, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm4, (size_t)tile * 4 * 4));
@@ -1752,76 +1796,127 @@ int cm_reads_swap(cm_ctx *ctx) {
     return CM_OK;
 }
 
-int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) {
-    if (!ctx) return CM_EINVAL;
-    int rc = check_slot(ctx, slot, true);
-    if (rc) return rc;
-    HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    if (ctx->n_pairs == 0) return CM_OK;
-    const KCore core = make_core(ctx, ctx->slots[slot]);
+// The pair stage of one tile and round on the pair streams: waits for that item's chains (ev_prep[b]), reads the flags
+// act_in, writes act_out for every pair of the tile, signals ev_pair[b] when the chain buffers of set b are free again.
+static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t nt, int is_last_round, const uint8_t *act_in, uint8_t *act_out,
+                         const RoundBufs &rb, int b) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
-    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
-        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
-        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
-        {
-            // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
-            // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
-            const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
-            const size_t lds_bytes = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
-            const size_t lds_heavy = lds_bytes + 64 * sizeof(int);
-            {
-            Timer t(ctx, 5);
-            const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
-            static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
-            hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, core, ctx->d_chains, ctx->d_resid, ctx->d_nchain,
-                               ctx->d_active, p0, nt, ctx->d_cls, ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2);
-            // three-pass LSD radix sort, 16 x 16 x 16 classes: by the longest residual, by the set of extensions a pair needs,
-            // then (stable) by its class
-            const uint32_t *no_order = nullptr;
-            const unsigned int *no_count = nullptr;
-            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
-            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
-                               (uint32_t *)nullptr, no_order, no_count);
-            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
-                               (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
-            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
-                               (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-            hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
-                               (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
-            hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
-            hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
-                               ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
-            ctx->launches[5] += 10;
-            }
-            // The heavy pairs go to the second stream: one wave per pair fits into the slots the light kernel leaves
-            // instead of queueing behind it.
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            {
-            Timer t(ctx, 4, ctx->stream2);
-            const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
-            hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, ctx->stream2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS,
-                               ctx->d_chains, ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err,
-                               ctx->d_counters, str_cap, ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres);
-            ++ctx->launches[4];
-            }
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-            {
-            Timer t(ctx, 2);      // = the pair stage: the light kernel and the wait for the second stream
-            hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, ctx->stream, core, rd, p0, nt, ctx->d_chains,
-                               ctx->d_nchain, ctx->d_high, ctx->d_state, ctx->d_active, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters,
-                               str_cap, ctx->d_lane_clk, ctx->d_perm, ctx->d_cls_ctr + CTR_SUM);
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            ++ctx->launches[2];
-            }
-            HIPCHK(ctx, hipGetLastError());
-        }
+    hipStream_t sp = ctx->stream_p, sp2 = ctx->stream_p2;
+    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
+    // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
+    // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
+    const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
+    // The pair kernels are bound by instruction issue of divergent code, not by latency: their time is the same at 2, 3 or 4
+    // waves per SIMD (measured).  Padding their LDS request keeps them at `pair_waves` per SIMD and leaves the
+    // other registers and wave slots to the seeding / chaining of the next round, which runs at the same time.
+    static const int pair_waves = getenv("CM_PAIR_OCC") ? atoi(getenv("CM_PAIR_OCC")) : 2;
+    const size_t lds_need = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
+    size_t lds_bytes = lds_need;
+    if (pair_waves >= 1 && pair_waves <= 3) {
+        const size_t want = ((size_t)160 * 1024 / (size_t)(4 * pair_waves)) - 64 * sizeof(int) - 256;      // heavy adds 64 ints; keep clear of the next step
+        if (want > lds_bytes && want <= 60 * 1024) lds_bytes = want;
     }
+    const size_t lds_heavy = lds_bytes + 64 * sizeof(int);
+    if (lds_heavy > 48 * 1024) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_heavy));
+    }
+    {
+        Timer t(ctx, 5, sp);
+        const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
+        static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
+        hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, core, rb.chains, rb.resid, rb.nchain, act_in, p0, nt, ctx->d_cls,
+                           ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2, act_out);
+        // three-pass LSD radix sort, 16 x 16 x 16 classes: by the longest residual, by the set of extensions a pair needs,
+        // then (stable) by its class
+        const uint32_t *no_order = nullptr;
+        const unsigned int *no_count = nullptr;
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
+                           (uint32_t *)nullptr, no_order, no_count);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
+                           (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
+                           (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
+                           (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
+                           ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
+        ctx->launches[5] += 10;
+    }
+    // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
+    // behind it.
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
+    HIPCHK(ctx, hipStreamWaitEvent(sp2, ctx->ev_fork_p, 0));
+    {
+        Timer t(ctx, 4, sp2);
+        const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
+        hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
+                           rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
+                           ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres);
+        ++ctx->launches[4];
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join_p, sp2));
+    {
+        Timer t(ctx, 2, sp);      // = the pair stage: the light kernel and the wait for the second stream
+        hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
+                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, ctx->d_perm,
+                           ctx->d_cls_ctr + CTR_SUM);
+        HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
+        ++ctx->launches[2];
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp));
+    ctx->pair_pending[b] = true;
+    HIPCHK(ctx, hipGetLastError());
     return CM_OK;
 }
+
+int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final) {
+    if (!ctx || (n_rounds > 0 && !slots) || n_rounds < 0) return CM_EINVAL;
+    int rc;
+    for (int r = 0; r < n_rounds; ++r)
+        if ((rc = check_slot(ctx, slots[r], true))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (ctx->n_pairs == 0 || n_rounds == 0) return CM_OK;
+    // everything queued on the main stream so far (uploads, resets, collects of the previous batch) comes first
+    HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
+    uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
+    int item = 0;
+    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
+        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
+        for (int r = 0; r < n_rounds; ++r, ++item) {
+            const int b = item & 1;
+            const Slot &sl = ctx->slots[slots[r]];
+            const KCore core = make_core(ctx, sl);
+            const RoundBufs rb = round_bufs(ctx, b);
+            // Seeds and chains of round r depend on the reads and the contig only; the flags merely skip pairs that are retired.
+            // While the pair stage of round r - 1 is still writing A[r & 1], this round's seeding reads the flags from before
+            // round r - 1 (a superset: pairs retired by round r - 1 get chains nobody looks at).
+            const uint8_t *act_prep = (r == 0) ? A[0] : A[(r - 1) & 1];
+            if (ctx->pair_pending[b]) {                                       // chain buffers of set b: free once their pair stage is done
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+                ctx->pair_pending[b] = false;
+            }
+            if ((rc = run_seed_tile(ctx, core, p0, nt, act_prep))) return rc;
+            if ((rc = run_chain_tile(ctx, core, p0, nt, sl.chain_parallel_ok, act_prep, rb))) return rc;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
+            const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
+            if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return rc;
+        }
+    }
+    // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
+    HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
+    ctx->pair_pending[0] = ctx->pair_pending[1] = false;                     // covered by the wait above
+    if (n_rounds & 1) std::swap(ctx->d_active, ctx->d_active_b);             // the current flags are in the other array now
+    return CM_OK;
+}
+
+int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) { return cm_map_rounds(ctx, &slot, 1, is_last_round); }
 
 int cm_sync(cm_ctx *ctx) {
     if (!ctx) return CM_EINVAL;
@@ -2001,7 +2096,7 @@ int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt,
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
+        if ((rc = run_seed_tile(ctx, core, p0, nt, ctx->d_active))) return rc;
         const size_t cnt = (size_t)nt * 4 * ctx->n_seeds, o = (size_t)p0 * 4 * ctx->n_seeds;
         HIPCHK(ctx, hipMemcpyAsync(out_start + o, ctx->d_sstart, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(out_cnt + o, ctx->d_scnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2019,9 +2114,9 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, p0, nt))) return rc;
+        if ((rc = run_seed_tile(ctx, core, p0, nt, ctx->d_active))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_chains, 0, (size_t)nt * 4 * CM_BESTCHAINLIM * sizeof(cm_chain), ctx->stream));
-        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok))) return rc;
+        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok, ctx->d_active, round_bufs(ctx, 0)))) return rc;
         const size_t np = (size_t)nt * 4, o = (size_t)p0 * 4;
         HIPCHK(ctx, hipMemcpyAsync(out_chains + o * CM_BESTCHAINLIM, ctx->d_chains, np * CM_BESTCHAINLIM * sizeof(cm_chain), hipMemcpyDeviceToHost,
                                    ctx->stream));

@@ -177,7 +177,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         Result &R = res[k & 1];
         double td = now();
         MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
-        for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_map_round(cm, (int)c, c + 1 == n_con), "cm_map_round");   // asynchronous
+        {
+            std::vector<int> all(n_con);
+            for (uint32_t c = 0; c < n_con; ++c) all[c] = (int)c;
+            MAP_TRY(cm_map_rounds(cm, all.data(), (int)n_con, 1), "cm_map_rounds");   // asynchronous; round r + 1 seeds while r pairs
+        }
         st.seconds_device += now() - td;
         const double tp = now();
         MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");

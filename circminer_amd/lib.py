@@ -175,6 +175,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_reads_stage": (C.c_int, [vp, pp(Reads), vp]),
         "cm_reads_swap": (C.c_int, [vp]),
         "cm_map_round": (C.c_int, [vp, C.c_int, C.c_int]),
+        "cm_map_rounds": (C.c_int, [vp, i32p, C.c_int, C.c_int]),
         "cm_reads_download": (C.c_int, [vp, vp, vp, vp]),
         "cm_map_batch": (C.c_int, [vp, C.c_int, C.c_int, pp(Reads), vp, vp, vp]),
         "cm_sync": (C.c_int, [vp]),
@@ -231,7 +232,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
-                    "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_reads_download", "cm_map_batch",
+                    "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_map_rounds", "cm_reads_download", "cm_map_batch",
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
@@ -581,6 +582,11 @@ class HotPath:
 
     def map_round(self, slot, is_last):
         self._chk(self.L.cm_map_round(self.h, slot, int(is_last)), "cm_map_round")
+
+    def map_rounds(self, slots, last_is_final=True):
+        """All of `slots` in order in one call (round r + 1 is seeded / chained while round r's pair stage runs)."""
+        arr = (C.c_int32 * len(slots))(*slots)
+        self._chk(self.L.cm_map_rounds(self.h, arr, len(slots), int(last_is_final)), "cm_map_rounds")
 
     def sync(self):
         self._chk(self.L.cm_sync(self.h), "cm_sync")

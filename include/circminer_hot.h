@@ -197,6 +197,14 @@ int cm_reads_swap(cm_ctx *ctx);
  * Asynchronous on the ctx stream; cm_sync() or cm_reads_download() waits. */
 int cm_map_round(cm_ctx *ctx, int slot, int is_last_round);
 
+/* Several rounds of the resident batch in one call: rounds slots[0 .. n_rounds) in that order, the last one with
+ * is_last_round = last_is_final -- the rounds loop of mapping() (src/circminer.cpp:229-308) for contigs that are all resident.
+ * Results are those of n_rounds cm_map_round calls.  What differs is the schedule: seeds and chains of a round depend on the
+ * reads and the contig only (the carried MatchedRead enters in the pair stage), so round r + 1 is seeded and chained on the
+ * main streams while the pair stage of round r still runs on a second pair of streams; chain buffers and active flags are
+ * double-buffered.  Asynchronous like cm_map_round. */
+int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final);
+
 /* Copy back the carried state, the per-pair return value of process_read in the last
  * cm_map_round (state[i], -1 if the pair was inactive) and the active flags after it. */
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active);

@@ -1,7 +1,7 @@
 #!/bin/bash
-# knob sweep on the hg38-like bench (5 steps each): chain light/heavy split, pair heavy cost
+# knob sweep on the hg38-like bench (5 steps each); arguments = "VAR=val[ VAR=val]" settings to try
 cd $(dirname $0)/../..
-for kv in "A=1" "CM_CHAIN_LIGHT_W=1024" "CM_CHAIN_LIGHT_W=4096 CM_CHAIN_LIGHT_CELLS=128" "CM_HEAVY_COST=16" "CM_HEAVY_COST=40"; do
+for kv in "A=1" "$@"; do
   echo "== $kv"
   env $kv python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json

@@ -48,8 +48,7 @@ def _compare_all_rounds(d, gtf, P, n_pairs, streamed):
     else:
         hp.upload(batch)
     t = time.time()
-    for ci in range(3):
-        hp.map_round(ci, ci == 2)
+    hp.map_rounds([0, 1, 2], True)
     st1, cat1, act1 = hp.download()
     t_gpu = time.time() - t
     rec = hp.collect_records(0).copy()

@@ -497,3 +497,38 @@ def test_improvement_log_pool_recovers(ds_small, monkeypatch, pool_max):
     if pool_max:
         monkeypatch.setenv("CM_POOL_MAX", str(pool_max))
     _run_all_rounds(ds_small, cl.default_params(kmer=ds_small.kmer))
+
+
+@pytest.mark.parametrize("tile", [None, "512"])
+def test_rounds_in_one_call_match_round_by_round(ds_tiny2r, ds_small, ds_dirty, monkeypatch, tile):
+    """cm_map_rounds: round r + 1 is seeded and chained (other streams, second set of chain buffers, flags of the round before)
+    while the pair stage of round r runs.  Same final state, flags, categories and BSJ records as round-by-round calls and as
+    the oracle; repeated on one context, with several tiles per batch, with a contig used twice and with an even / odd number
+    of rounds (the active-flag arrays swap roles every round)."""
+    if tile:
+        monkeypatch.setenv("CM_TILE_PAIRS", tile)
+    for ds, order in ((ds_tiny2r, [0, 1]), (ds_dirty, [0, 1]), (ds_tiny2r, [1, 0, 1]), (ds_small, [0]), (ds_tiny2r, [0, 1, 0, 1])):
+        P = cl.default_params(kmer=ds.kmer)
+        hp = cl.HotPath(P)
+        for ci in range(ds.hi.n_contigs):
+            hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
+        st0, act0 = op.default_state(P, ds.batch.n)
+        for k, ci in enumerate(order):
+            cat0 = op.map_round(P, ds.hi.views[ci], ds.hi.annots[ci], ds.batch, k == len(order) - 1, st0, act0)
+        for rep in range(2):
+            hp.upload(ds.batch)
+            hp.map_rounds(order, True)
+            st1, cat1, act1 = hp.download()
+            assert st0.tobytes() == st1.tobytes(), first_diff(st0, st1)
+            assert (act0 == act1).all() and (cat0 == cat1).all()
+            rec = hp.collect_records(7)
+            keep = np.nonzero(act1)[0]
+            assert (rec["pair"] == keep + 7).all() and rec["state"].tobytes() == st1[keep].tobytes()
+        # and interleaved with single-round calls on the same context
+        hp.reset()
+        hp.map_round(order[0], len(order) == 1)
+        if len(order) > 1:
+            hp.map_rounds(order[1:], True)
+        st2, cat2, act2 = hp.download()
+        assert st0.tobytes() == st2.tobytes() and (act0 == act2).all() and (cat0 == cat2).all()
+        hp.close()

@@ -221,8 +221,10 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
     const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
     const Core c = cmc::to_core(kc);
-    const uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x;
-    if (slot >= *n_light) return;       // light pairs only, in bucket order (heavy pairs: k_pair_heavy)
+    // persistent grid: the launch places every workgroup at once (gridDim <= resident capacity), so the dispatcher is free
+    // for the kernels of the next round that other streams run at the same time; a block walks the list with a grid stride
+    const uint32_t n_l = *n_light;
+    for (uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x; slot < n_l; slot += gridDim.x * BLK_PAIR) {   // light pairs only, in bucket order
     const uint32_t t = perm[slot];
     const uint64_t p = pair0 + t;
     const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
@@ -260,6 +262,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
 #else
     if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
 #endif
+    }
 }
 
 // ---- wave-cooperative chaining of heavy problems ----------------------------------------------
@@ -1318,7 +1321,8 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             if (heavy_lds > 64u * 1024u)
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
             const uint32_t hb = n < 8192u ? n : 8192u;
-            hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
+            static const size_t heavy_pad = getenv("CM_CHEAVY_LDS_PAD") ? (size_t)atoi(getenv("CM_CHEAVY_LDS_PAD")) : 0;     // occupancy experiment
+            hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
                                ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, ctx->d_err,
                                rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1);
             ++ctx->launches[6];
@@ -1326,7 +1330,8 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_ti
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         }
         Timer t(ctx, 1);
-        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), 0, ctx->stream, core, rd, act, pair0, a, b, S,
+        static const size_t light_pad = getenv("CM_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("CM_CHAIN_LDS_PAD")) : 0;       // occupancy experiment
+        hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), light_pad, ctx->stream, core, rd, act, pair0, a, b, S,
                            ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
                            ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, rb.high, ctx->d_err, rb.resid,
                            use_split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + CTR_SUM);
@@ -1417,6 +1422,10 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     if (p->band < 0 || p->band > cmc::MAX_BAND) return CM_EINVAL;
     if (p->seed_lim < 1 || p->seed_lim > 65535) return CM_EINVAL;
     if (p->max_ed < 0 || p->max_sc < 0 || p->max_read_len < p->kmer) return CM_EINVAL;
+    // Five streams of one context work at the same time (seed / chain, heavy chains, pair stage, heavy pairs, H2D staging); the
+    // runtime's default of 4 hardware queues makes two of them share one and serialises them.  Only effective when this is the
+    // first HIP call of the process; callers that bring up HIP earlier (PyTorch) set the variable themselves (bench.py does).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CM_ENODEV;
     if (p->device < 0 || p->device >= ndev) return CM_ENODEV;
@@ -1806,10 +1815,10 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
     // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
     const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
-    // The pair kernels are bound by instruction issue of divergent code, not by latency: their time is the same at 2, 3 or 4
-    // waves per SIMD (measured).  Padding their LDS request keeps them at `pair_waves` per SIMD and leaves the
-    // other registers and wave slots to the seeding / chaining of the next round, which runs at the same time.
-    static const int pair_waves = getenv("CM_PAIR_OCC") ? atoi(getenv("CM_PAIR_OCC")) : 2;
+    // The pair kernels' time hardly depends on their occupancy (16.0 / 16.2 / 16.4 ms per step at 4 / 3 / 2 waves per SIMD on the
+    // hg38-like bench; 22 ms at 1).  CM_PAIR_OCC = 1..3 pads their LDS request to hold them at that many waves per SIMD, which
+    // leaves registers and wave slots to the seeding / chaining of the next round; measured best overall: no padding (4).
+    static const int pair_waves = getenv("CM_PAIR_OCC") ? atoi(getenv("CM_PAIR_OCC")) : 4;
     const size_t lds_need = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
     size_t lds_bytes = lds_need;
     if (pair_waves >= 1 && pair_waves <= 3) {
@@ -1853,7 +1862,11 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     HIPCHK(ctx, hipStreamWaitEvent(sp2, ctx->ev_fork_p, 0));
     {
         Timer t(ctx, 4, sp2);
-        const unsigned heavy_grid = nt < 4096u ? (nt ? nt : 1u) : 4096u;
+        // both pair kernels are persistent: together they fill `pair_waves` wave slots per SIMD (256 CUs x 4 SIMDs), half each
+        static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
+        const unsigned cap = 256u * 4u * slots_per_simd;
+        const unsigned heavy_cap = cap / 2u;
+        const unsigned heavy_grid = nt < heavy_cap ? (nt ? nt : 1u) : heavy_cap;
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
                            ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres);
@@ -1862,7 +1875,9 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     HIPCHK(ctx, hipEventRecord(ctx->ev_join_p, sp2));
     {
         Timer t(ctx, 2, sp);      // = the pair stage: the light kernel and the wait for the second stream
-        hipLaunchKernelGGL(k_pair, dim3((nt + BLK_PAIR - 1) / BLK_PAIR), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
+        static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
+        const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = 256u * 4u * slots_per_simd;       // light takes the slots heavy leaves: full cap
+        hipLaunchKernelGGL(k_pair, dim3(want < cap ? want : cap), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, ctx->d_perm,
                            ctx->d_cls_ctr + CTR_SUM);
         HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
@@ -1906,6 +1921,8 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
             HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
             const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
             if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return rc;
+            static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: rounds back to back
+            if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
         }
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device

@@ -151,6 +151,54 @@ def make_genes(rng, chr_lens, genes_per_mbp=12.0, max_intron=20000, min_margin=2
     return genes
 
 
+def add_variety(rng, genes: List[Gene], chr_lens, min_margin=2000) -> List[Gene]:
+    """Annotation shapes the plain generator never makes (and where FlatIntervalTree::build / handle_overlap are intricate):
+    genes nested in an intron of another gene on the opposite strand, genes overlapping the 3' end of their neighbour with
+    partially overlapping exons, single-exon genes, identical gene spans, a gene whose first exon lies within maxReadLength
+    of the chromosome start, and GTF gene blocks that are not in coordinate order."""
+    out = list(genes)
+    gcount = len(genes)
+
+    def new_gene(chrom, strand, exons, n_iso=1):
+        nonlocal gcount
+        gid = f"G{gcount:06d}"
+        trs = [Transcript(gcount, f"T{gcount:06d}.0", strand, list(exons))]
+        if n_iso > 1 and len(exons) > 2:
+            trs.append(Transcript(gcount, f"T{gcount:06d}.1", strand, [exons[0]] + list(exons[2:])))
+        out.append(Gene(chrom, gid, exons[0][0], exons[-1][1], strand, trs))
+        gcount += 1
+
+    for g in genes:
+        ex = g.transcripts[0].exons
+        other = "-" if g.strand == "+" else "+"
+        r = rng.random()
+        if r < 0.25:                                    # nested in the longest intron, opposite strand
+            gaps = [(ex[k][1] + 1, ex[k + 1][0] - 1) for k in range(len(ex) - 1)]
+            a, b = max(gaps, key=lambda t: t[1] - t[0])
+            if b - a > 900:
+                p = a + 100
+                new_gene(g.chrom, other, [(p, p + 149), (p + 300, p + 479), (p + 620, p + 760)], n_iso=2)
+        elif r < 0.45:                                  # overlaps the last two exons partially and runs on into the intergenic space
+            s0 = ex[-2][0] + 30
+            e_last = ex[-1][1]
+            if e_last + 900 + min_margin < chr_lens[g.chrom]:
+                new_gene(g.chrom, other, [(s0, ex[-2][1] + 40), (ex[-1][0] - 25, e_last - 10), (e_last + 300, e_last + 520)])
+        elif r < 0.55:                                  # single-exon gene inside the first intron
+            if ex[1][0] - ex[0][1] > 500:
+                p = ex[0][1] + 120
+                new_gene(g.chrom, g.strand, [(p, p + 260)])
+        elif r < 0.62:                                  # a second gene with exactly the same span (merged_genes keeps the first)
+            new_gene(g.chrom, g.strand, [ex[0], ex[-1]] if len(ex) > 1 else list(ex))
+    if chr_lens[0] > 5000:                              # first exon 60 bp from the chromosome start: the left near-border flank wraps
+        new_gene(0, "+", [(60, 260), (700, 900), (1300, 1500)])
+    order = rng.permutation(len(out))                   # gene blocks in file order != coordinate order (ids follow the file)
+    shuffled = [out[i] for i in order]
+    for k, g in enumerate(shuffled):
+        for t in g.transcripts:
+            t.gene = k
+    return shuffled
+
+
 def gtf_text(genes: List[Gene], chr_names) -> str:
     out = []
     for g in genes:
@@ -294,6 +342,9 @@ PRESETS = {
     # name: (chromosome lengths, genes/Mbp, contig size cap, copies per repeat family)
     "tiny": ([120_000, 90_000], 60.0, 1_100_000_000, 6),
     "tiny2r": ([120_000, 90_000], 60.0, 150_000, 6),           # two packed contigs -> two rounds
+    # two rounds with the annotation shapes of add_variety(): nested / overlapping / opposite-strand / single-exon / duplicate-span
+    # genes, an exon next to the chromosome start, GTF gene blocks out of coordinate order
+    "variety": ([130_000, 80_000], 110.0, 160_000, 6),
     "small": ([2_000_000, 1_500_000, 1_000_000], 25.0, 1_100_000_000, 120),
     "chr21": ([46_700_000], 5.5, 1_100_000_000, 2000),         # BASELINE.json configs[1]
     # one full-size packed contig (hg38 chr1-5 lengths, 1.06 Gbp): the scale of one round of configs[2..4]
@@ -318,6 +369,8 @@ def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25
     seqs = make_genome(rng, chr_lens, fam_copies=fam_copies)
     contigs, table = pack_genome(names, seqs, cs)
     genes = make_genes(rng, chr_lens, genes_per_mbp=gpm)
+    if preset == "variety":
+        genes = add_variety(rng, genes, chr_lens)
     gtf = gtf_text(genes, names)
     if read_seed is not None:          # same genome / annotation, an independent shard of reads
         rng = np.random.default_rng([seed, int(read_seed)])

@@ -19,9 +19,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(HERE, "cm_oracle.cpp")
-    hdr = os.path.join(HERE, "..", "include", "circminer_hot.h")
-    if (not force and os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    srcs = [os.path.join(HERE, "cm_oracle.cpp"), os.path.join(HERE, "cm_oracle_build.cpp"), os.path.join(HERE, "..", "include", "circminer_hot.h")]
+    if (not force and os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(x) for x in srcs)):
         return SO
     subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return SO
@@ -139,3 +138,45 @@ def circ_run(params, host_index, chr_table, names, batch, states, candid_path, r
                            C.c_void_p(chr_contig.ctypes.data), C.c_void_p(chr_shift.ctypes.data), C.c_uint64(len(keep)), name_arr,
                            C.byref(batch.c), C.c_void_p(st.ctypes.data), candid_path.encode(), report_path.encode())
     assert rc == 0, rc
+
+
+class OracleIndex:
+    """Index + annotation of a packed genome built by the ORACLE's own builders (oracle/cm_oracle_build.cpp, written from the
+    reference's HashTable.c / gene_annotation.cpp / interval_tree_impl.h), same attributes as circminer_amd.lib.HostIndex.
+    The parity tests feed the oracle from this and the HIP path from the product's builders."""
+
+    def __init__(self, contigs, chr_table, gtf_path, kmer=20, max_read_len=300):
+        L = load()
+        self.L = L
+        self.contigs = [np.ascontiguousarray(c, dtype=np.uint8) for c in contigs]
+        self.views = []
+        for ci, g in enumerate(self.contigs):
+            iv = cl.IndexView()
+            rc = L.oracle_build_index(C.c_void_p(g.ctypes.data), C.c_uint32(len(g)), C.c_int32(kmer), C.c_int32(ci), C.byref(iv))
+            assert rc == 0, rc
+            self.views.append(iv)
+        n_con = len(self.contigs)
+        self._names = [t[0].encode() for t in chr_table]
+        chrs = (cl.ChrInfo * len(chr_table))(*[cl.ChrInfo(self._names[i], t[1], t[2], t[3]) for i, t in enumerate(chr_table)])
+        clen = np.asarray([len(c) for c in self.contigs], dtype=np.uint32)
+        self.annots = (cl.AnnotView * n_con)()
+        self._holders = (C.c_void_p * n_con)()
+        rc = L.oracle_build_annotation(gtf_path.encode(), chrs, C.c_uint32(len(chr_table)), C.c_void_p(clen.ctypes.data), C.c_uint32(n_con),
+                                       C.c_int32(max_read_len), self.annots, self._holders)
+        assert rc == 0, rc
+        self.chr_table = list(chr_table)
+        self.n_contigs = n_con
+        self.kmer = kmer
+
+    def close(self):
+        if self.views:
+            for iv in self.views:
+                self.L.oracle_free_index(C.byref(iv))
+            self.L.oracle_free_annotation(self._holders, C.c_uint32(self.n_contigs))
+            self.views = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

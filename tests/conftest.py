@@ -68,6 +68,11 @@ class DataSet:
         self.hi = cl.HostIndex(self.d.contigs, self.d.chr_table, self.gtf, kmer=kmer)
         self.batch = cl.ReadBatch(self.d.seq1, self.d.seq2)
         self.kmer = kmer
+        # What the ORACLE runs on: index + annotation from its own builders (oracle/cm_oracle_build.cpp, written from the reference's
+        # HashTable.c / gene_annotation.cpp / interval_tree_impl.h), while the HIP path gets the product's (host_index.cpp /
+        # host_annot.cpp).  Single-threaded: small genomes only; the big presets share the product's views.
+        from oracle import oracle_py
+        self.ohi = oracle_py.OracleIndex(self.d.contigs, self.d.chr_table, self.gtf, kmer=kmer) if sum(len(c) for c in self.d.contigs) <= 8_000_000 else self.hi
 
 
 @pytest.fixture(scope="session")
@@ -78,6 +83,13 @@ def ds_tiny(tmp_path_factory, built):
 @pytest.fixture(scope="session")
 def ds_tiny2r(tmp_path_factory, built):
     return DataSet(tmp_path_factory.mktemp("tiny2r"), "tiny2r", 1200, 22)
+
+
+@pytest.fixture(scope="session")
+def ds_variety(tmp_path_factory, built):
+    """two packed contigs with nested / overlapping / opposite-strand / single-exon / duplicate-span genes, an exon next to the
+    chromosome start and GTF gene blocks out of coordinate order (synth.add_variety)"""
+    return DataSet(tmp_path_factory.mktemp("variety"), "variety", 4000, 31, mix=(0.5, 0.2, 0.3))
 
 
 @pytest.fixture(scope="session")
@@ -100,7 +112,7 @@ class _Shim:
     """DataSet-like wrapper: same index / annotation, another read batch."""
 
     def __init__(self, ds, batch):
-        self.d, self.hi, self.kmer, self.batch = ds.d, ds.hi, ds.kmer, batch
+        self.d, self.hi, self.ohi, self.kmer, self.batch = ds.d, ds.hi, ds.ohi, ds.kmer, batch
 
 
 @pytest.fixture(scope="session")

@@ -36,7 +36,7 @@ def _run_all_rounds(ds, P):
     for ci in range(ds.hi.n_contigs):
         last = ci == ds.hi.n_contigs - 1
         hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
-        cat0 = op.map_round(P, ds.hi.views[ci], ds.hi.annots[ci], ds.batch, last, st0, act0)
+        cat0 = op.map_round(P, ds.ohi.views[ci], ds.ohi.annots[ci], ds.batch, last, st0, act0)
         hp.map_round(ci, last)
         st1, cat1, act1 = hp.download()
         assert (cat0 == cat1).all(), np.nonzero(cat0 != cat1)[0][:10]
@@ -70,7 +70,7 @@ def test_seed_parity(name, request):
     hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
     hp.upload(ds.batch)
     a1, b1, c1, S = hp.seeds(0)
-    a0, b0, c0 = op.seeds(P, ds.hi.views[0], ds.batch, S)
+    a0, b0, c0 = op.seeds(P, ds.ohi.views[0], ds.batch, S)
     assert (c0 == c1).all() and (b0 == b1).all()
     m = c0 > 0
     assert (a0[m] == a1[m]).all()
@@ -85,19 +85,19 @@ def test_chain_parity(name, request):
     hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
     hp.upload(ds.batch)
     c1, n1, h1 = hp.chains(0)
-    c0, n0, h0 = op.chains(P, ds.hi.views[0], ds.hi.annots[0], ds.batch)
+    c0, n0, h0 = op.chains(P, ds.ohi.views[0], ds.ohi.annots[0], ds.batch)
     assert (h0 == h1).all()
     _chains_equal(c0, n0, c1, n1)
     hp.close()
 
 
-@pytest.mark.parametrize("name", ["ds_tiny", "ds_tiny2r", "ds_small"])
+@pytest.mark.parametrize("name", ["ds_tiny", "ds_tiny2r", "ds_small", "ds_variety"])
 def test_map_parity_all_rounds(name, request):
     ds = request.getfixturevalue(name)
     st = _run_all_rounds(ds, cl.default_params(kmer=ds.kmer))
     # planted truth: most transcriptomic pairs come back concordant at the planted coordinates
     m = (ds.d.src == 0)
-    assert (st["type"][m] == cl.CAT["CONCRD"]).mean() > 0.9
+    assert (st["type"][m] == cl.CAT["CONCRD"]).mean() > (0.9 if name != "ds_variety" else 0.8)
 
 
 @pytest.mark.parametrize("kw", [dict(scan_level=1), dict(scan_level=2, max_ed=8, seed_lim=1000), dict(max_chain_len=5, max_tlen=300)])
@@ -322,7 +322,7 @@ def test_contigs_streamed_through_one_slot(ds_tiny2r):
     Re-loading slot 0 for every round must give what the all-resident layout gives; the batch goes through twice so the
     second pass starts from buffers the first one left behind."""
     ds, P = ds_tiny2r, cl.default_params()
-    want, _, _ = op.map_all_rounds(P, ds.hi, ds.batch)
+    want, _, _ = op.map_all_rounds(P, ds.ohi, ds.batch)
     hp = cl.HotPath(P)
     for _ in range(2):
         hp.upload(ds.batch)
@@ -370,7 +370,7 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
     # expectation: the oracle on the in-memory builder's views of the same genome
     gtf2 = str(tmp_path / "ref2.gtf")
     open(gtf2, "w").write(d.gtf_text)
-    hi = cl.HostIndex(d.contigs, d.chr_table, gtf2, kmer=20)
+    hi = op.OracleIndex(d.contigs, d.chr_table, gtf2, kmer=20)          # the oracle's own builders; the run above used the product's
     P20 = cl.default_params()
     want, act, _ = op.map_all_rounds(P20, hi, cl.ReadBatch(d.seq1, d.seq2))
     chrs = d.chr_table
@@ -445,8 +445,8 @@ def test_staged_batches_overlap_and_match(ds_tiny2r, ds_dirty):
     n = ds.batch.n
     pa = hp.pinned_batch(ds.d.seq1[:n // 2], ds.d.seq2[:n // 2])
     pb = hp.pinned_batch(ds.d.seq1[n // 2:], ds.d.seq2[n // 2:])
-    want, _, _ = op.map_all_rounds(P, ds.hi, ds.batch)
-    want_dirty, _, _ = op.map_all_rounds(P, ds.hi, ds_dirty.batch)
+    want, _, _ = op.map_all_rounds(P, ds.ohi, ds.batch)
+    want_dirty, _, _ = op.map_all_rounds(P, ds.ohi, ds_dirty.batch)
 
     def rounds():
         for ci in range(ds.hi.n_contigs):
@@ -500,21 +500,21 @@ def test_improvement_log_pool_recovers(ds_small, monkeypatch, pool_max):
 
 
 @pytest.mark.parametrize("tile", [None, "512"])
-def test_rounds_in_one_call_match_round_by_round(ds_tiny2r, ds_small, ds_dirty, monkeypatch, tile):
+def test_rounds_in_one_call_match_round_by_round(ds_tiny2r, ds_small, ds_dirty, ds_variety, monkeypatch, tile):
     """cm_map_rounds: round r + 1 is seeded and chained (other streams, second set of chain buffers, flags of the round before)
     while the pair stage of round r runs.  Same final state, flags, categories and BSJ records as round-by-round calls and as
     the oracle; repeated on one context, with several tiles per batch, with a contig used twice and with an even / odd number
     of rounds (the active-flag arrays swap roles every round)."""
     if tile:
         monkeypatch.setenv("CM_TILE_PAIRS", tile)
-    for ds, order in ((ds_tiny2r, [0, 1]), (ds_dirty, [0, 1]), (ds_tiny2r, [1, 0, 1]), (ds_small, [0]), (ds_tiny2r, [0, 1, 0, 1])):
+    for ds, order in ((ds_tiny2r, [0, 1]), (ds_dirty, [0, 1]), (ds_tiny2r, [1, 0, 1]), (ds_small, [0]), (ds_tiny2r, [0, 1, 0, 1]), (ds_variety, [0, 1])):
         P = cl.default_params(kmer=ds.kmer)
         hp = cl.HotPath(P)
         for ci in range(ds.hi.n_contigs):
             hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
         st0, act0 = op.default_state(P, ds.batch.n)
         for k, ci in enumerate(order):
-            cat0 = op.map_round(P, ds.hi.views[ci], ds.hi.annots[ci], ds.batch, k == len(order) - 1, st0, act0)
+            cat0 = op.map_round(P, ds.ohi.views[ci], ds.ohi.annots[ci], ds.batch, k == len(order) - 1, st0, act0)
         for rep in range(2):
             hp.upload(ds.batch)
             hp.map_rounds(order, True)

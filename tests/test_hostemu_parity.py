@@ -16,8 +16,8 @@ def _emu_rounds(E, ds, P):
     st1, act1 = st0.copy(), act0.copy()
     for ci in range(ds.hi.n_contigs):
         last = ci == ds.hi.n_contigs - 1
-        iv, av = ds.hi.views[ci], ds.hi.annots[ci]
-        cat0 = op.map_round(P, iv, av, ds.batch, last, st0, act0)
+        iv, av = ds.hi.views[ci], ds.hi.annots[ci]                          # the product's builders feed the kernel bodies,
+        cat0 = op.map_round(P, ds.ohi.views[ci], ds.ohi.annots[ci], ds.batch, last, st0, act0)      # the oracle's own feed the oracle
         cat1 = np.full(ds.batch.n, -1, np.int32)
         rc = E.emu_map_round(C.byref(P), C.byref(iv), C.byref(av), C.byref(ds.batch.c), int(last), st1.ctypes.data, act1.ctypes.data,
                              cat1.ctypes.data)
@@ -224,3 +224,10 @@ def test_more_than_64_common_transcripts(emu, ds_tiny, tmp_path):
     assert ntid.max() > 2 * 64 and av.n_trans == 45 * ds_tiny.hi.annots[0].n_trans
     _emu_rounds(emu, sh, cl.default_params())
     _emu_rounds(emu, sh, cl.default_params(scan_level=2, max_ed=6))
+
+
+def test_variety_annotation_all_rounds(emu, ds_variety):
+    """nested / overlapping / opposite-strand / single-exon genes etc. (conftest.ds_variety): kernel bodies on the product's
+    annotation vs the oracle on its own"""
+    _emu_rounds(emu, ds_variety, cl.default_params())
+    _emu_rounds(emu, ds_variety, cl.default_params(scan_level=2, max_ed=6))

@@ -14,8 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 OUT = os.path.join(CSRC, "libcmhot.so")
-SOURCES = ["cm_hot.hip", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp", "host_mapping.cpp", "host_circ.cpp", "host_circ_call.cpp"]
+SOURCES = ["cm_hot.hip", "cm_dispatch.cpp", "host_index.cpp", "host_annot.cpp", "host_index_io.cpp", "host_fastq.cpp", "host_mapping.cpp", "host_circ.cpp",
+           "host_circ_call.cpp"]
 DEPS = SOURCES + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "circminer_hot.h")]
+# cm_hot.hip is compiled twice (reads of <= 16 seeds / <= 24 seeds, see cm_dispatch.cpp): its exported names get a suffix
+KERNEL_EXPORTS = ['cm_create', 'cm_destroy', 'cm_last_error', 'cm_load_contig', 'cm_load_annotation', 'cm_unload_contig', 'cm_reads_upload', 'cm_reads_stage', 'cm_reads_swap', 'cm_map_rounds', 'cm_map_round', 'cm_sync', 'cm_reads_reset', 'cm_collect_active', 'cm_collect_records', 'cm_collect_records_device', 'cm_host_alloc', 'cm_host_free', 'cm_reads_download', 'cm_map_batch', 'cm_seed_batch', 'cm_chain_batch', 'cm_debug_lane_clk', 'cm_prof_enable', 'cm_prof_reset', 'cm_prof_get', 'cm_prof_counters', 'cm_ctx', 'cm_chain']
+VARIANTS = (("k16", []), ("k24", ["-DCM_MAX_CHAIN_FRAGS=24"]))
 
 
 def needs_build() -> bool:
@@ -31,20 +35,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("CM_EXTRA_FLAGS", "").split()
     objs = []
+    jobs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc, "-c", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *extra, "-I", INC, "-I", CSRC,
-               os.path.join(CSRC, s), "-o", o]
+        base = [hipcc, "-c", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *extra, "-I", INC, "-I", CSRC]
         if s.endswith(".hip"):
-            cmd[1:1] = ["--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] if verbose else ["--offload-arch=gfx950"]
+            arch = ["--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] if verbose else ["--offload-arch=gfx950"]
+            for tag, flags in VARIANTS:
+                o = os.path.join(CSRC, s.rsplit(".", 1)[0] + "_" + tag + ".o")
+                ren = [f"-D{n}={n}_{tag}" for n in KERNEL_EXPORTS + ["cmc"]]      # cmc: the kernel bodies' namespace (their structs differ in size)
+                jobs.append((s + " [" + tag + "]", [base[0]] + arch + base[1:] + flags + ren + [os.path.join(CSRC, s), "-o", o]))
+                objs.append(o)
         else:
-            cmd[1:1] = ["-x", "c++"]                 # host-only sources: plain C++ (hipcc would otherwise treat .cpp as HIP)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if verbose or r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {s}")
-        objs.append(o)
+            o = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
+            jobs.append((s, [base[0], "-x", "c++"] + base[1:] + [os.path.join(CSRC, s), "-o", o]))   # host-only sources: plain C++
+            objs.append(o)
+    procs = [(name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for name, cmd in jobs]   # in parallel
+    failed = []
+    for name, pr in procs:
+        out, _ = pr.communicate()
+        if verbose or pr.returncode != 0:
+            sys.stderr.write(out)
+        if pr.returncode != 0:
+            failed.append(name)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread", "-lz"],
                        capture_output=True, text=True)
     if r.returncode != 0:

@@ -358,7 +358,7 @@ PRESETS = {
 
 
 def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25, 0.05),
-             chr_lens=None, genes_per_mbp=None, contig_size=None, fam_copies=None, read_seed=None) -> SynthData:
+             chr_lens=None, genes_per_mbp=None, contig_size=None, fam_copies=None, read_seed=None, frag=None) -> SynthData:
     rng = np.random.default_rng(seed)
     p_lens, p_gpm, p_cs, p_fc = PRESETS[preset]
     fam_copies = fam_copies or p_fc
@@ -374,5 +374,7 @@ def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25
     gtf = gtf_text(genes, names)
     if read_seed is not None:          # same genome / annotation, an independent shard of reads
         rng = np.random.default_rng([seed, int(read_seed)])
-    s1, s2, src, tc, lo, hi = make_reads(rng, seqs, genes, n_pairs, read_len=read_len, mix=mix)
+    if frag is None:
+        frag = (260, 450) if read_len <= 200 else (read_len + 110, read_len + 300)
+    s1, s2, src, tc, lo, hi = make_reads(rng, seqs, genes, n_pairs, read_len=read_len, frag_lo=frag[0], frag_hi=frag[1], mix=mix)
     return SynthData(names, seqs, contigs, table, genes, gtf, s1, s2, src, tc, lo, hi)

@@ -48,7 +48,10 @@ enum {
 
 #define CM_WINDOW_SIZE 14          /* WINDOW_SIZE, src/common.cpp:7                         */
 #define CM_BESTCHAINLIM 30         /* BESTCHAINLIM, src/common.h:51; chain.h:14-17          */
-#define CM_MAX_CHAIN_FRAGS 16      /* >= ceil(maxReadLength/k) used slots (even slots only) */
+#ifndef CM_MAX_CHAIN_FRAGS         /* (the library's second build of the kernels sets 24 for itself: reads of more than 16 seeds) */
+#define CM_MAX_CHAIN_FRAGS 16      /* fragments a cm_chain of THIS ABI holds (cm_chain_batch, a test hook, is limited to reads of <= 16 seeds) */
+#endif
+#define CM_MAX_SEEDS_PER_READ 24   /* floor(read length / k) the mapping entry points accept: 300 bp at k = 14 is 21 (commandline_parser.cpp:14,242-247) */
 #define CM_CONTIG_SIZE 1100000000u /* DEF_CONTIG_SIZE, src/common.h:81 (gspos stride)       */
 
 /* ---- thresholds: the reference keeps these as globals (src/common.h:92-103,

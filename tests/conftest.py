@@ -34,18 +34,24 @@ def emu(built):
     return load_emu()
 
 
-def load_emu():
-    """Host emulation of the kernel bodies (tests/hostemu.cpp) — test infrastructure only."""
+@pytest.fixture(scope="session")
+def emu24(built):
+    return load_emu(wide=True)
+
+
+def load_emu(wide=False):
+    """Host emulation of the kernel bodies (tests/hostemu.cpp) — test infrastructure only.  wide: the kernel bodies as the
+    library's second build compiles them (reads of up to 24 seeds, -DCM_MAX_CHAIN_FRAGS=24)."""
     out_dir = os.path.join(ROOT, "tests", "_hostemu")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libcmemu.so")
-    if os.environ.get("CM_EMU_LIB"):           # e.g. an ASan / UBSan build of tests/hostemu.cpp (see tests/diag/asan_emu.sh)
+    so = os.path.join(out_dir, "libcmemu24.so" if wide else "libcmemu.so")
+    if os.environ.get("CM_EMU_LIB") and not wide:           # e.g. an ASan / UBSan build of tests/hostemu.cpp (see tests/diag/asan_emu.sh)
         so = os.environ["CM_EMU_LIB"]
     srcs = [os.path.join(ROOT, "tests", "hostemu.cpp"), os.path.join(ROOT, "circminer_amd", "csrc", "cm_core.h"),
             os.path.join(ROOT, "include", "circminer_hot.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
-                               "-I", os.path.join(ROOT, "circminer_amd", "csrc"), srcs[0], "-o", so])
+                               "-I", os.path.join(ROOT, "circminer_amd", "csrc"), srcs[0], "-o", so] + (["-DCM_MAX_CHAIN_FRAGS=24"] if wide else []))
     E = C.CDLL(so)
     vp, pp = C.c_void_p, C.POINTER
     E.emu_seed_batch.argtypes = [pp(cl.Params), pp(cl.IndexView), pp(cl.Reads), C.c_uint32, vp, vp, vp]
@@ -90,6 +96,13 @@ def ds_variety(tmp_path_factory, built):
     """two packed contigs with nested / overlapping / opposite-strand / single-exon / duplicate-span genes, an exon next to the
     chromosome start and GTF gene blocks out of coordinate order (synth.add_variety)"""
     return DataSet(tmp_path_factory.mktemp("variety"), "variety", 4000, 31, mix=(0.5, 0.2, 0.3))
+
+
+@pytest.fixture(scope="session")
+def ds_long(tmp_path_factory, built):
+    """2 x 300 bp reads with a k = 14 index: 21 seeds per read, the most the reference's command line allows (maxReadLength 300,
+    k >= 14; src/commandline_parser.cpp:14,242-247) -- the library's 24-seed build"""
+    return DataSet(tmp_path_factory.mktemp("long"), "tiny2r", 900, 41, kmer=14, read_len=300)
 
 
 @pytest.fixture(scope="session")

@@ -532,3 +532,28 @@ def test_rounds_in_one_call_match_round_by_round(ds_tiny2r, ds_small, ds_dirty, 
         st2, cat2, act2 = hp.download()
         assert st0.tobytes() == st2.tobytes() and (act0 == act2).all() and (cat0 == cat2).all()
         hp.close()
+
+
+def test_reads_of_21_seeds_take_the_wide_build(ds_long, ds_tiny2r):
+    """maxReadLength 300 at k = 14 .. 18 needs more than the 16 seeds per read of the default kernels (round 1 returned CM_ELIMIT):
+    cm_create picks the 24-seed build of the kernels; all rounds equal the oracle; cm_chain_batch (16-fragment ABI) declines."""
+    P = cl.default_params(kmer=14)
+    assert P.max_read_len // P.kmer == 21
+    _run_all_rounds(ds_long, P)
+    _run_all_rounds(ds_long, cl.default_params(kmer=14, scan_level=2, max_ed=6, seed_lim=200))
+    hp = cl.HotPath(P)
+    hp.load_contig(0, ds_long.hi.views[0], ds_long.hi.annots[0])
+    hp.upload(ds_long.batch)
+    with pytest.raises(RuntimeError):
+        hp.chains(0)
+    a1, b1, c1, S = hp.seeds(0)
+    assert S == 21
+    a0, b0, c0 = op.seeds(P, ds_long.ohi.views[0], ds_long.batch, S)
+    assert (c0 == c1).all() and (b0 == b1).all() and (a0[c0 > 0] == a1[c0 > 0]).all()
+    hp.close()
+    # the same context type with short reads: a k = 20 index and max_read_len 400 (20 seeds) also lands in the wide build
+    _run_all_rounds(ds_tiny2r, cl.default_params(kmer=ds_tiny2r.kmer, max_read_len=400))
+    # beyond 24 seeds is the documented limit
+    with pytest.raises(RuntimeError):
+        hp = cl.HotPath(cl.default_params(kmer=14, max_read_len=400))
+        hp.upload(cl.ReadBatch(np.full((2, 380), ord("A"), np.uint8), np.full((2, 380), ord("C"), np.uint8)))

@@ -231,3 +231,17 @@ def test_variety_annotation_all_rounds(emu, ds_variety):
     annotation vs the oracle on its own"""
     _emu_rounds(emu, ds_variety, cl.default_params())
     _emu_rounds(emu, ds_variety, cl.default_params(scan_level=2, max_ed=6))
+
+
+def test_reads_of_21_seeds(emu24, ds_long, ds_dirty):
+    """300-bp reads at k = 14 (21 seeds, beyond the 16 of the default build): the kernel bodies as the library's second build
+    compiles them vs the oracle; plus ragged 250 - 300 bp reads"""
+    _emu_rounds(emu24, ds_long, cl.default_params(kmer=14))
+    d = ds_long.d
+    rng = np.random.default_rng(5)
+    l1, l2 = rng.integers(250, 301, d.seq1.shape[0]), rng.integers(250, 301, d.seq1.shape[0])
+    s1 = np.concatenate([d.seq1[i, :l1[i]] for i in range(len(l1))])
+    s2 = np.concatenate([d.seq2[i, :l2[i]] for i in range(len(l2))])
+    from conftest import _Shim
+    _emu_rounds(emu24, _Shim(ds_long, cl.ReadBatch(s1, s2, l1, l2)), cl.default_params(kmer=14, scan_level=1))
+    _emu_rounds(emu24, ds_long, cl.default_params(kmer=14, seed_lim=60, max_ed=6))      # many seeds above the hit limit at k = 14

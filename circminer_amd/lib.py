@@ -641,7 +641,7 @@ class HotPath:
         self._chk(self.L.cm_reads_download(self.h, st.ctypes.data, cat.ctypes.data, act.ctypes.data), "cm_reads_download")
         return st, cat, act
 
-    def seeds(self, slot, n_slots_cap=16):
+    def seeds(self, slot, n_slots_cap=24):
         cap = self.n * 4 * n_slots_cap
         a = np.zeros(cap, np.uint32)
         b = np.zeros(cap, np.uint32)

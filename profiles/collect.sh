@@ -5,7 +5,7 @@
 #   3. the bench line itself (with cpu_baseline)                        -> profiles/rNN_bench_1gpu.json
 # Outputs are written under gpurun_out/profiles/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -e
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p $OUT

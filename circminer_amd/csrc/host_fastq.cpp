@@ -45,19 +45,36 @@ void unmapped_state(cm_mapped_read &m, int type, int max_ed) {        // fill_ma
 
 struct Stream {
     gzFile gz = nullptr;
+    FILE *plain = nullptr;                   // set for uncompressed input: read in big blocks and tokenised on several threads
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
     bool open(const char *path) {
-        gz = gzopen(path, "r");
-        if (!gz) return false;
-        gzbuffer(gz, 1u << 20);
+        FILE *t = fopen(path, "rb");
+        if (!t) return false;
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, t);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {          // gzip: one inflate stream, the record-by-record path
+            fclose(t);
+            gz = gzopen(path, "r");
+            if (!gz) return false;
+            gzbuffer(gz, 1u << 20);
+        } else {
+            rewind(t);
+            plain = t;
+        }
         buf.resize(BLOCK);
         return true;
     }
     void close() {
         if (gz) gzclose(gz);
+        if (plain) fclose(plain);
         gz = nullptr;
+        plain = nullptr;
+    }
+    int read_some(char *dst, size_t cap) {
+        if (plain) return (int)fread(dst, 1, cap > (1u << 30) ? (1u << 30) : cap, plain);
+        return gzread(gz, dst, (unsigned)(cap > (1u << 30) ? (1u << 30) : cap));
     }
     // next line as [ptr, ptr + len) without the '\n'; false at end of input
     bool line(const char *&p, size_t &len) {
@@ -82,7 +99,7 @@ struct Stream {
                 pos = 0;
             }
             if (end == buf.size()) buf.resize(buf.size() * 2);
-            const int got = gzread(gz, buf.data() + end, (unsigned)(buf.size() - end));
+            const int got = read_some(buf.data() + end, buf.size() - end);
             if (got <= 0) eof = true;
             else end += (size_t)got;
         }
@@ -114,6 +131,8 @@ struct cm_fastq {
         std::vector<cm_mapped_read> prior;
     } gen[3];
     int cur = 2;
+    int n_threads = 0;                       // tokeniser threads of the plain-text path (0 = hardware concurrency, at most 32)
+    std::vector<size_t> nl1, nl2;            // newline index of the two block buffers (plain-text path)
     std::vector<std::string> chr_names;
     int max_ed = 4;
     bool any_prior = false;
@@ -128,6 +147,67 @@ int chr_lookup(const cm_fastq *f, const char *tok, size_t len) {
     return -1;
 }
 
+// header line "@tok0 tok1 ...": tokens separated by runs of spaces (strtok); at most FQCOMMENTCNT + 1 are kept, all are counted
+int split_header(const char *p, size_t len, const char **tok, size_t *tl) {
+    int nt = 0;
+    size_t i = 1;
+    while (i < len) {
+        while (i < len && p[i] == ' ') ++i;
+        if (i >= len) break;
+        size_t j = i;
+        while (j < len && p[j] != ' ') ++j;
+        if (nt <= FQCOMMENTCNT) {
+            tok[nt] = p + i;
+            tl[nt] = j - i;
+        }
+        ++nt;
+        i = j;
+    }
+    return nt;
+}
+size_t name_len(int nt, const char *const *tok, const size_t *tl) {
+    size_t nlen = nt ? tl[0] : 0;
+    if (nlen >= 2 && tok[0][nlen - 2] == '/') nlen -= 2;          // extract_map_info :193-194
+    return nlen;
+}
+// fill_map_info (src/fastq_parser.cpp:200-269): the MatchedRead a 23-token header carries, the fresh-read state otherwise
+void state_from_header(const cm_fastq *f, int nt, const char *const *tok, const size_t *tl, cm_mapped_read &out) {
+    cm_mapped_read *st = &out;
+    if (nt != FQCOMMENTCNT) {
+        unmapped_state(*st, CM_NOPROC_NOMATCH, f->max_ed);         // what cm_reads_upload uses for prior == NULL
+    } else {
+        auto num = [&](int k) { return strtoull(std::string(tok[k], tl[k]).c_str(), nullptr, 10); };
+        auto inum = [&](int k) { return atoi(std::string(tok[k], tl[k]).c_str()); };
+        const int type = inum(2);
+        if (mapped_type(type)) {
+            cm_mapped_read &m = *st;
+            memset(&m, 0, sizeof m);
+            m.type = type;
+            m.chr_id = chr_lookup(f, tok[3], tl[3]);
+            m.spos_r1 = (uint32_t)num(4);
+            m.epos_r1 = (uint32_t)num(5);
+            m.mlen_r1 = (uint32_t)inum(6);
+            m.qspos_r1 = (uint32_t)num(7);
+            m.qepos_r1 = (uint32_t)num(8);
+            m.r1_forward = tok[9][0] == '+';
+            m.ed_r1 = inum(10);
+            m.spos_r2 = (uint32_t)num(12);
+            m.epos_r2 = (uint32_t)num(13);
+            m.mlen_r2 = (uint32_t)inum(14);
+            m.qspos_r2 = (uint32_t)num(15);
+            m.qepos_r2 = (uint32_t)num(16);
+            m.r2_forward = tok[17][0] == '+';
+            m.ed_r2 = inum(18);
+            m.tlen = inum(19);
+            m.junc_num = (uint16_t)num(20);
+            m.gm_compatible = tok[21][0] == '1';
+            m.contig_num = inum(22);
+        } else {
+            unmapped_state(*st, type, f->max_ed);
+        }
+    }
+}
+
 // one record of one stream; fills `st` (state carried in the header) when want_state
 // returns 1 = record, 0 = end of input, -1 = format error
 int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_read *st, bool *carried) {
@@ -136,65 +216,16 @@ int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_
     if (!s.line(p, len)) return 0;
     if (len == 0 && s.eof && s.pos >= s.end) return 0;
     if (len == 0 || p[0] != '@') return -1;                       // has_next asserts the '@'
-    // header: tokens separated by runs of spaces (strtok)
     const char *tok[FQCOMMENTCNT + 1];
     size_t tl[FQCOMMENTCNT + 1];
-    int nt = 0;
-    {
-        size_t i = 1;
-        while (i < len) {
-            while (i < len && p[i] == ' ') ++i;
-            if (i >= len) break;
-            size_t j = i;
-            while (j < len && p[j] != ' ') ++j;
-            if (nt <= FQCOMMENTCNT) {
-                tok[nt] = p + i;
-                tl[nt] = j - i;
-            }
-            ++nt;
-            i = j;
-        }
-    }
-    size_t nlen = nt ? tl[0] : 0;
-    if (nlen >= 2 && tok[0][nlen - 2] == '/') nlen -= 2;          // extract_map_info :193-194
+    const int nt = split_header(p, len, tok, tl);
+    size_t nlen = name_len(nt, tok, tl);
     if (nt) side.names.insert(side.names.end(), tok[0], tok[0] + nlen);
     side.names.push_back('\0');
     side.name_off.push_back(side.names.size());
     if (want_state) {
         *carried = nt == FQCOMMENTCNT;
-        if (nt != FQCOMMENTCNT) {
-            unmapped_state(*st, CM_NOPROC_NOMATCH, f->max_ed);         // what cm_reads_upload uses for prior == NULL
-        } else {
-            auto num = [&](int k) { return strtoull(std::string(tok[k], tl[k]).c_str(), nullptr, 10); };
-            auto inum = [&](int k) { return atoi(std::string(tok[k], tl[k]).c_str()); };
-            const int type = inum(2);
-            if (mapped_type(type)) {
-                cm_mapped_read &m = *st;
-                memset(&m, 0, sizeof m);
-                m.type = type;
-                m.chr_id = chr_lookup(f, tok[3], tl[3]);
-                m.spos_r1 = (uint32_t)num(4);
-                m.epos_r1 = (uint32_t)num(5);
-                m.mlen_r1 = (uint32_t)inum(6);
-                m.qspos_r1 = (uint32_t)num(7);
-                m.qepos_r1 = (uint32_t)num(8);
-                m.r1_forward = tok[9][0] == '+';
-                m.ed_r1 = inum(10);
-                m.spos_r2 = (uint32_t)num(12);
-                m.epos_r2 = (uint32_t)num(13);
-                m.mlen_r2 = (uint32_t)inum(14);
-                m.qspos_r2 = (uint32_t)num(15);
-                m.qepos_r2 = (uint32_t)num(16);
-                m.r2_forward = tok[17][0] == '+';
-                m.ed_r2 = inum(18);
-                m.tlen = inum(19);
-                m.junc_num = (uint16_t)num(20);
-                m.gm_compatible = tok[21][0] == '1';
-                m.contig_num = inum(22);
-            } else {
-                unmapped_state(*st, type, f->max_ed);
-            }
-        }
+        state_from_header(f, nt, tok, tl, *st);
     }
     if (!s.line(p, len)) return -1;
     side.seq.insert(side.seq.end(), (const uint8_t *)p, (const uint8_t *)p + len);
@@ -207,7 +238,6 @@ int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_
 }
 
 }  // namespace
-
 // Append-only text buffer in front of a FILE: the writers format integers themselves (a PAM row is 20 of them), which is
 // several times faster than one fprintf per record.
 struct Out {

@@ -12,8 +12,11 @@
 // batch goes to cm_reads_upload without another copy; with cm_host_alloc'ed staging the copy is one DMA.
 // Deliberately defined where the reference has undefined behaviour: names shorter than 2 characters are not
 // inspected for the "/x" suffix, header lines with more than 23 tokens are treated like fresh reads.
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -72,9 +75,39 @@ struct Stream {
         gz = nullptr;
         plain = nullptr;
     }
+    uint64_t file_pos = 0;                   // plain: offset of the next unread byte
+    int read_threads = 1;
     int read_some(char *dst, size_t cap) {
-        if (plain) return (int)fread(dst, 1, cap > (1u << 30) ? (1u << 30) : cap, plain);
-        return gzread(gz, dst, (unsigned)(cap > (1u << 30) ? (1u << 30) : cap));
+        if (cap > (1u << 30)) cap = 1u << 30;
+        if (!plain) return gzread(gz, dst, (unsigned)cap);
+        // page-cache -> buffer copies are what a read() of a hot file is: several pread()s side by side
+        const int fd = fileno(plain);
+        const int nt = (read_threads > 1 && cap >= (8u << 20)) ? read_threads : 1;
+        std::vector<long> got((size_t)nt, 0);
+        auto piece = [&](int t) {
+            const size_t a = cap * (size_t)t / (size_t)nt, b = cap * (size_t)(t + 1) / (size_t)nt;
+            size_t done = 0;
+            while (a + done < b) {
+                const ssize_t r = pread(fd, dst + a + done, b - a - done, (off_t)(file_pos + a + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            got[(size_t)t] = (long)done;
+        };
+        if (nt == 1) piece(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(piece, t);
+            for (auto &x : th) x.join();
+        }
+        size_t total = 0;
+        for (int t = 0; t < nt; ++t) {              // contiguous prefix that was actually read (a short piece means end of file)
+            const size_t want = cap * (size_t)(t + 1) / (size_t)nt - cap * (size_t)t / (size_t)nt;
+            total += (size_t)got[(size_t)t];
+            if ((size_t)got[(size_t)t] < want) break;
+        }
+        file_pos += total;
+        return (int)total;
     }
     // next line as [ptr, ptr + len) without the '\n'; false at end of input
     bool line(const char *&p, size_t &len) {
@@ -106,11 +139,54 @@ struct Stream {
     }
 };
 
+// The part of std::vector the parser uses, without the zero-fill of resize(): the batch arrays are tens of MB and every byte
+// is overwritten by the (parallel) copies right after they are sized.
+template <class T> struct RawVec {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T *end() { return p + n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 1024;
+        while (nc < c) nc *= 2;
+        p = (T *)realloc(p, nc * sizeof(T));
+        cap = nc;
+    }
+    void resize(size_t k) {                 // contents of new elements are unspecified
+        reserve(k);
+        n = k;
+    }
+    void push_back(const T &v) {
+        reserve(n + 1);
+        p[n++] = v;
+    }
+    template <class It> void insert(T *, It a, It b) {       // append only (the parser never inserts elsewhere)
+        const size_t k = (size_t)(b - a);
+        reserve(n + k);
+        memcpy(p + n, &*a, k * sizeof(T));
+        n += k;
+    }
+    void assign(size_t k, const T &v) {
+        resize(k);
+        for (size_t i = 0; i < k; ++i) p[i] = v;
+    }
+};
+
 struct Side {
-    std::vector<uint8_t> seq, qual;
-    std::vector<uint64_t> off;
-    std::vector<char> names;
-    std::vector<uint64_t> name_off;
+    RawVec<uint8_t> seq, qual;
+    RawVec<uint64_t> off;
+    RawVec<char> names;
+    RawVec<uint64_t> name_off;
     void clear() {
         seq.clear();
         qual.clear();
@@ -128,7 +204,7 @@ struct cm_fastq {
     // caller can have batch k-1 with its writer thread, batch k on the GPU and batch k+1 in the parser at the same time
     struct Gen {
         Side a, b;
-        std::vector<cm_mapped_read> prior;
+        RawVec<cm_mapped_read> prior;
     } gen[3];
     int cur = 2;
     int n_threads = 0;                       // tokeniser threads of the plain-text path (0 = hardware concurrency, at most 32)
@@ -238,6 +314,191 @@ int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_
 }
 
 }  // namespace
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Plain-text fast path of cm_fastq_next: the reference tokenises FASTQ inside one lock-protected serial section
+// (src/circminer.cpp:373-379); here both files are read in large blocks and everything after the read() is data parallel:
+//   1. newline index of the block (each thread scans a slice with memchr, slices concatenated in order);
+//   2. four lines = one record; per record the lengths of name / sequence and the header checks (pass A);
+//   3. prefix sums give every record its place in the batch arrays; bytes are copied in parallel (pass B).
+// Records that do not fit the block stay in the buffer for the next call.  Same results as parse_record().
+template <class F> void par_for(int nt, size_t n, F f) {       // f(thread, begin, end) over [0, n) in nt contiguous pieces
+    if (nt <= 1 || n < 4096) {
+        f(0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(f, t, n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt);
+    for (auto &x : th) x.join();
+}
+
+// makes sure s.buf[s.pos .. s.end) holds at least `want` complete records (or everything up to end of input); nl = offsets
+// (relative to s.pos) of the line ends of those bytes.  Returns the number of complete records available.
+size_t fill_and_index(Stream &s, std::vector<size_t> &nl, size_t want, size_t bytes_hint, int nt) {
+    s.read_threads = nt;
+    if (s.pos > 0) {                                              // drop what the previous batch consumed
+        memmove(s.buf.data(), s.buf.data() + s.pos, s.end - s.pos);
+        s.end -= s.pos;
+        s.pos = 0;
+    }
+    nl.clear();
+    size_t scanned = 0;
+    for (;;) {
+        // index the bytes not scanned yet
+        const size_t a = scanned, b = s.end;
+        if (b > a) {
+            std::vector<std::vector<size_t>> part((size_t)std::max(nt, 1));
+            par_for(nt, b - a, [&](int t, size_t lo, size_t hi) {
+                const char *base = s.buf.data();
+                std::vector<size_t> &v = part[(size_t)t];
+                for (const char *q = base + a + lo, *e = base + a + hi; q < e;) {
+                    const char *z = (const char *)memchr(q, '\n', (size_t)(e - q));
+                    if (!z) break;
+                    v.push_back((size_t)(z - base));
+                    q = z + 1;
+                }
+            });
+            for (auto &v : part) nl.insert(nl.end(), v.begin(), v.end());
+            scanned = b;
+        }
+        size_t lines = nl.size();
+        if (s.eof && s.end > 0 && (nl.empty() || nl.back() != s.end - 1)) ++lines;     // last line without a newline
+        if (lines / 4 >= want || s.eof) return lines / 4;
+        // more input: room for the rest of the estimate (at least one block)
+        size_t need = std::max<size_t>(BLOCK, bytes_hint > s.end ? bytes_hint - s.end : BLOCK);
+        if (s.end + need > s.buf.size()) s.buf.resize(s.end + need);
+        while (need > 0) {
+            const int got = s.read_some(s.buf.data() + s.end, need);
+            if (got <= 0) {
+                s.eof = true;
+                break;
+            }
+            s.end += (size_t)got;
+            need -= (size_t)got;
+        }
+    }
+}
+
+// one side of a batch from the indexed block; returns false on a malformed record
+bool build_side(cm_fastq *f, Stream &s, const std::vector<size_t> &nl, size_t n, Side &side, RawVec<cm_mapped_read> *prior, bool *any_prior,
+                int nt) {
+    const char *base = s.buf.data();
+    auto line_of = [&](size_t k, const char *&p, size_t &len) {      // k-th line of the block
+        const size_t b = k ? nl[k - 1] + 1 : 0;
+        const size_t e = k < nl.size() ? nl[k] : s.end;               // the last line may have no newline
+        p = base + b;
+        len = e - b;
+    };
+    RawVec<uint32_t> nlen, slen;
+    nlen.resize(n);
+    slen.resize(n);
+    std::vector<uint8_t> bad((size_t)std::max(nt, 1), 0), carried((size_t)std::max(nt, 1), 0);
+    if (prior) prior->resize(n);
+    par_for(nt, n, [&](int t, size_t lo, size_t hi) {                 // pass A
+        const char *tok[FQCOMMENTCNT + 1];
+        size_t tl[FQCOMMENTCNT + 1];
+        for (size_t i = lo; i < hi; ++i) {
+            const char *p;
+            size_t len, l2, l3, l4;
+            const char *p2, *p3, *p4;
+            line_of(4 * i, p, len);
+            line_of(4 * i + 1, p2, l2);
+            line_of(4 * i + 2, p3, l3);
+            line_of(4 * i + 3, p4, l4);
+            if (len == 0 || p[0] != '@' || l3 == 0 || p3[0] != '+' || l4 != l2) {
+                bad[(size_t)t] = 1;
+                return;
+            }
+            const int ntok = split_header(p, len, tok, tl);
+            nlen[i] = (uint32_t)name_len(ntok, tok, tl);
+            slen[i] = (uint32_t)l2;
+            if (prior) {
+                if (ntok == FQCOMMENTCNT) carried[(size_t)t] = 1;
+                state_from_header(f, ntok, tok, tl, (*prior)[i]);
+            }
+        }
+    });
+    for (uint8_t b : bad) if (b) return false;
+    if (any_prior) for (uint8_t c : carried) *any_prior = *any_prior || c;
+    side.off.resize(n + 1);
+    side.name_off.resize(n + 1);
+    side.off[0] = 0;
+    side.name_off[0] = 0;
+    for (size_t i = 0; i < n; ++i) {
+        side.off[i + 1] = side.off[i] + slen[i];
+        side.name_off[i + 1] = side.name_off[i] + nlen[i] + 1;
+    }
+    side.seq.resize(side.off[n]);
+    side.qual.resize(side.off[n]);
+    side.names.resize(side.name_off[n]);
+    par_for(nt, n, [&](int, size_t lo, size_t hi) {                   // pass B
+        const char *tok[FQCOMMENTCNT + 1];
+        size_t tl[FQCOMMENTCNT + 1];
+        for (size_t i = lo; i < hi; ++i) {
+            const char *p;
+            size_t len;
+            line_of(4 * i, p, len);
+            const int ntok = split_header(p, len, tok, tl);
+            char *nm = side.names.data() + side.name_off[i];
+            if (ntok) memcpy(nm, tok[0], nlen[i]);
+            nm[nlen[i]] = '\0';
+            line_of(4 * i + 1, p, len);
+            memcpy(side.seq.data() + side.off[i], p, len);
+            line_of(4 * i + 3, p, len);
+            memcpy(side.qual.data() + side.off[i], p, len);
+        }
+    });
+    // consumed: everything up to the end of record n - 1
+    const size_t last = 4 * n - 1;
+    s.pos = last < nl.size() ? nl[last] + 1 : s.end;
+    return true;
+}
+
+// cm_fastq_next for two plain-text files; *n_out pairs
+int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_out) {
+    int nt = f->n_threads > 0 ? f->n_threads : (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("CM_FASTQ_THREADS")) nt = atoi(e);
+    nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+    const int half = nt > 1 ? nt / 2 : 1;
+    // ~ 2 x (read length + name) + 8 per record; the estimate only sizes the first read(), more is read on demand
+    const size_t hint = (size_t)std::min<uint64_t>(max_pairs, 1ull << 22) * 360 + (1u << 20);
+    size_t a1 = 0, a2 = 0;
+    const bool trace = getenv("CM_FASTQ_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    {   // the two files are filled and indexed side by side
+        std::thread t2([&]() { a2 = fill_and_index(f->s2, f->nl2, (size_t)max_pairs, hint, half); });
+        a1 = fill_and_index(f->s1, f->nl1, (size_t)max_pairs, hint, half);
+        t2.join();
+    }
+    if (a2 < a1 && a2 < max_pairs) return CM_EINVAL;                  // R2 ends before R1
+    const size_t n = (size_t)std::min<uint64_t>(a1, max_pairs);      // R1 decides; surplus R2 records at the end of input are ignored
+    *n_out = n;
+    if (n == 0) {
+        // a trailing partial record is malformed input unless the stream is simply empty
+        if (f->s1.eof && f->s1.end > f->s1.pos) {
+            size_t k = f->s1.pos;
+            while (k < f->s1.end && f->s1.buf[k] == '\n') ++k;
+            if (k < f->s1.end) return CM_EINVAL;
+        }
+        return CM_OK;
+    }
+    bool ok1 = true, ok2 = true, any = false;
+    const auto t_mid = std::chrono::steady_clock::now();
+    {
+        std::thread t2([&]() { ok2 = build_side(f, f->s2, f->nl2, n, G.b, nullptr, nullptr, half); });
+        ok1 = build_side(f, f->s1, f->nl1, n, G.a, &G.prior, &any, half);
+        t2.join();
+    }
+    if (!ok1 || !ok2) return CM_EINVAL;
+    f->any_prior = any;
+    if (trace) fprintf(stderr, "[fastq] %zu pairs: fill+index %.1f ms, build %.1f ms\n", n, std::chrono::duration<double, std::milli>(t_mid - t0).count(),
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_mid).count());
+    return CM_OK;
+}
+
+}  // namespace
 // Append-only text buffer in front of a FILE: the writers format integers themselves (a PAM row is 20 of them), which is
 // several times faster than one fprintf per record.
 struct Out {
@@ -322,13 +583,19 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     G.b.clear();
     G.prior.clear();
     f->any_prior = false;
+    uint64_t n_fast = 0;
+    const bool fast = f->s1.plain && f->s2.plain && !getenv("CM_FASTQ_SERIAL");
+    if (fast) {
+        const int rc = next_plain(f, max_pairs, G, &n_fast);
+        if (rc != CM_OK) return rc;
+    }
     // The two files are independent streams until the records are paired up: R2 is parsed (and, for .gz input, inflated)
     // on a second thread while this one does R1 and its carried state.  The reference does both inside one lock-protected
     // serial section (src/circminer.cpp:373-379), which is its ingest ceiling.
-    uint64_t n = 0, n2 = 0;
+    uint64_t n = fast ? n_fast : 0, n2 = fast ? n_fast : 0;
     int bad2 = 0;
     std::thread side_b([&]() {
-        while (n2 < max_pairs) {
+        while (!fast && n2 < max_pairs) {
             const int r2 = parse_record(f, f->s2, G.b, false, nullptr, nullptr);
             if (r2 == 0) break;
             if (r2 < 0) {
@@ -339,7 +606,7 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
         }
     });
     int bad1 = 0;
-    while (n < max_pairs) {
+    while (!fast && n < max_pairs) {
         cm_mapped_read st;
         bool carried = false;
         const int r1 = parse_record(f, f->s1, G.a, true, &st, &carried);

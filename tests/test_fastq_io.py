@@ -233,3 +233,66 @@ def test_malformed_fastq_is_an_error_not_a_crash(built, tmp_path):
     b = rd.next_batch(10)
     assert b.n == 3 and [b.name(i, 2) for i in range(3)] == list("abc") and b.seq(2, 2) == b"ACGTA" and b.qual(2, 2) == b"IIIII"
     rd.close()
+
+
+def test_parallel_plain_text_path_equals_the_serial_parser(built, tmp_path, monkeypatch):
+    """Plain-text input is read in blocks and tokenised on several threads (newline index -> records -> prefix sums -> parallel
+    copies); gzip input and CM_FASTQ_SERIAL=1 take the record-by-record parser.  Same batches either way: ragged reads, carried
+    23-token headers mixed with fresh ones, '/1' suffixes, extra header tokens, batch boundaries that cut the block anywhere, a
+    last record without a newline, R2 longer than R1."""
+    rng = np.random.default_rng(12)
+    n = 5000
+    seqs1, quals1 = _rand_reads(rng, n, 20, 301)
+    seqs2, quals2 = _rand_reads(rng, n + 7, 20, 301)
+    st = _rand_states(rng, n)
+    names1, names2 = [], []
+    for i in range(n):
+        base = f"read{i}" if i % 3 else f"r{i}/1"
+        if i % 5 == 0:
+            names1.append(py_remain_header(f"read{i}", st[i], CHRS)[1:])
+        else:
+            names1.append(base + (" extra tokens here" if i % 7 == 0 else ""))
+    for i in range(n + 7):
+        names2.append(f"read{i}/2")
+    p1, p2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    _fastq(p1, names1, seqs1, quals1)
+    _fastq(p2, names2, seqs2, quals2)
+    with open(p1, "rb+") as f:                 # drop the final newline of R1
+        f.seek(-1, 2)
+        f.truncate()
+
+    def read_all(batch):
+        rd = cl.FastqReader(p1, p2, CHRS, 4)
+        out = []
+        while True:
+            b = rd.next_batch(batch)
+            if b is None:
+                break
+            out.append((b.n, [b.name(i) for i in range(b.n)], [b.name(i, 2) for i in range(b.n)], [b.seq(i) for i in range(b.n)], [b.seq(i, 2) for i in range(b.n)],
+                        [b.qual(i) for i in range(b.n)], [b.qual(i, 2) for i in range(b.n)], None if b.prior is None else b.prior.tobytes()))
+        rd.close()
+        return out
+
+    for batch in (n + 100, 777, 1):
+        if batch == 1:
+            continue
+        monkeypatch.delenv("CM_FASTQ_SERIAL", raising=False)
+        monkeypatch.setenv("CM_FASTQ_THREADS", "6")
+        fast = read_all(batch)
+        monkeypatch.setenv("CM_FASTQ_SERIAL", "1")
+        slow = read_all(batch)
+        assert sum(x[0] for x in fast) == n and len(fast) == len(slow)
+        assert fast == slow
+    assert fast[0][1][0] == "read0" and fast[0][3][1] == seqs1[1].encode()
+    # malformed input is refused by both
+    bad = str(tmp_path / "bad_1.fq")
+    open(bad, "w").write("@x\nACGT\n+\nIII\n")              # quality shorter than the sequence
+    for serial in (None, "1"):
+        if serial:
+            monkeypatch.setenv("CM_FASTQ_SERIAL", serial)
+        else:
+            monkeypatch.delenv("CM_FASTQ_SERIAL", raising=False)
+        rd = cl.FastqReader(bad, bad, CHRS, 4)
+        with pytest.raises(RuntimeError):
+            rd.next_batch(10)
+        rd.close()

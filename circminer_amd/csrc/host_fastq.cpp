@@ -516,6 +516,10 @@ struct Out {
     }
     void room(size_t k) {
         if (n + k > buf.size()) {
+            if (!f) {                                  // private buffer of a formatting thread: grow
+                buf.resize(std::max(buf.size() * 2, n + k));
+                return;
+            }
             flush();
             if (k > buf.size()) buf.resize(k);
         }
@@ -735,46 +739,69 @@ int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read 
 }
 
 // write_pam_rec_pe for the selected pairs (names of R1)
+static void pam_row(const cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read &m, uint64_t i, Out &o) {
+    const char *nm = b->names1 + b->name_off1[i];
+    o.str(nm);
+    if (mapped_type(m.type)) {
+        const char *cn = chr_name(w, m.chr_id);
+        // "%s\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%d\t%d\t%d\t%d\n"
+        o.ch('\t'); o.str(cn);
+        o.ch('\t'); o.u64(m.spos_r1);
+        o.ch('\t'); o.u64(m.epos_r1);
+        o.ch('\t'); o.i64((int)m.mlen_r1);
+        o.ch('\t'); o.u64(m.qspos_r1);
+        o.ch('\t'); o.u64(m.qepos_r1);
+        o.ch('\t'); o.ch(m.r1_forward ? '+' : '-');
+        o.ch('\t'); o.i64(m.ed_r1);
+        o.ch('\t'); o.str(cn);
+        o.ch('\t'); o.u64(m.spos_r2);
+        o.ch('\t'); o.u64(m.epos_r2);
+        o.ch('\t'); o.i64((int)m.mlen_r2);
+        o.ch('\t'); o.u64(m.qspos_r2);
+        o.ch('\t'); o.u64(m.qepos_r2);
+        o.ch('\t'); o.ch(m.r2_forward ? '+' : '-');
+        o.ch('\t'); o.i64(m.ed_r2);
+        o.ch('\t'); o.i64(m.tlen);
+        o.ch('\t'); o.i64((int)m.junc_num);
+        o.ch('\t'); o.i64((int)(m.gm_compatible != 0));
+        o.ch('\t'); o.i64(m.type);
+        o.ch('\n');
+    } else {
+        o.str("\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t");
+        o.i64(m.type);
+        o.ch('\n');
+    }
+}
+
 int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel) {
     if (!w || !b || !states) return CM_EINVAL;
     const uint64_t n = sel ? n_sel : b->reads.n_pairs;
-    for (uint64_t k = 0; k < n; ++k) {
-        const uint64_t i = sel ? sel[k] : k;
-        if (i >= b->reads.n_pairs) return CM_EINVAL;
-        const cm_mapped_read &m = states[i];
-        const char *nm = b->names1 + b->name_off1[i];
-        Out &o = w->o1;
-        o.str(nm);
-        if (mapped_type(m.type)) {
-            const char *cn = chr_name(w, m.chr_id);
-            // "%s\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%s\t%u\t%u\t%d\t%u\t%u\t%c\t%d\t%d\t%d\t%d\t%d\n"
-            o.ch('\t'); o.str(cn);
-            o.ch('\t'); o.u64(m.spos_r1);
-            o.ch('\t'); o.u64(m.epos_r1);
-            o.ch('\t'); o.i64((int)m.mlen_r1);
-            o.ch('\t'); o.u64(m.qspos_r1);
-            o.ch('\t'); o.u64(m.qepos_r1);
-            o.ch('\t'); o.ch(m.r1_forward ? '+' : '-');
-            o.ch('\t'); o.i64(m.ed_r1);
-            o.ch('\t'); o.str(cn);
-            o.ch('\t'); o.u64(m.spos_r2);
-            o.ch('\t'); o.u64(m.epos_r2);
-            o.ch('\t'); o.i64((int)m.mlen_r2);
-            o.ch('\t'); o.u64(m.qspos_r2);
-            o.ch('\t'); o.u64(m.qepos_r2);
-            o.ch('\t'); o.ch(m.r2_forward ? '+' : '-');
-            o.ch('\t'); o.i64(m.ed_r2);
-            o.ch('\t'); o.i64(m.tlen);
-            o.ch('\t'); o.i64((int)m.junc_num);
-            o.ch('\t'); o.i64((int)(m.gm_compatible != 0));
-            o.ch('\t'); o.i64(m.type);
-            o.ch('\n');
-        } else {
-            o.str("\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t*\t");
-            o.i64(m.type);
-            o.ch('\n');
+    if (sel)
+        for (uint64_t k = 0; k < n; ++k)
+            if (sel[k] >= b->reads.n_pairs) return CM_EINVAL;
+    // large batches: rows formatted on several threads into private buffers, written out in order
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("CM_WRITER_THREADS")) nt = atoi(e);
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    if (n < 65536 || nt == 1) {
+        for (uint64_t k = 0; k < n; ++k) {
+            const uint64_t i = sel ? sel[k] : k;
+            pam_row(w, b, states[i], i, w->o1);
         }
+        return CM_OK;
     }
+    w->o1.flush();
+    std::vector<Out> part((size_t)nt);
+    par_for(nt, (size_t)n, [&](int t, size_t lo, size_t hi) {
+        Out &o = part[(size_t)t];
+        o.buf.resize((hi - lo) * 160 + 4096);          // grows on demand (room()); never flushed: f == nullptr
+        for (size_t k = lo; k < hi; ++k) {
+            const uint64_t i = sel ? sel[k] : k;
+            pam_row(w, b, states[i], i, o);
+        }
+    });
+    for (Out &o : part)
+        if (o.n && fwrite(o.buf.data(), 1, o.n, w->f1) != o.n) return CM_EINVAL;
     return CM_OK;
 }
 

@@ -296,3 +296,29 @@ def test_parallel_plain_text_path_equals_the_serial_parser(built, tmp_path, monk
         with pytest.raises(RuntimeError):
             rd.next_batch(10)
         rd.close()
+
+
+def test_pam_rows_formatted_in_parallel_are_the_same_bytes(built, tmp_path, monkeypatch):
+    """batches of >= 65536 rows are formatted on several threads (private buffers, written in order)"""
+    rng = np.random.default_rng(3)
+    n = 70000
+    seqs, quals = ["ACGT"] * n, ["IIII"] * n
+    names = [f"q{i}" for i in range(n)]
+    p1, p2 = str(tmp_path / "b_1.fq"), str(tmp_path / "b_2.fq")
+    _fastq(p1, names, seqs, quals)
+    _fastq(p2, names, seqs, quals)
+    st = _rand_states(rng, n)
+    rd = cl.FastqReader(p1, p2, CHRS, 4)
+    b = rd.next_batch(n)
+    out = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("CM_WRITER_THREADS", threads)
+        path = str(tmp_path / f"o{threads}.pam")
+        w = cl.RecordWriter(path, None, CHRS)
+        w.write_pam(b, st)
+        w.write_pam(b, st, np.arange(0, n, 3))
+        w.close()
+        out.append(open(path, "rb").read())
+    rd.close()
+    assert out[0] == out[1] and out[0].count(b"\n") == n + len(range(0, n, 3))
+    assert out[0].split(b"\n")[5].decode() == py_pam_row("q5", st[5], CHRS)

@@ -39,7 +39,7 @@ with tempfile.TemporaryDirectory() as td:
     print(f"fastq written {time.time() - t:.1f}s ({os.path.getsize(fq[0]) * 2 / 1e6:.0f} MB)", flush=True)
     for it in range(2):
         t = time.time()
-        st = cl.run_mapping(idx, gtf, fq[0], fq[1], os.path.join(td, "out"), cl.default_params(kmer=0), report=report, n_threads=16)
+        st = cl.run_mapping(idx, gtf, fq[0], fq[1], os.path.join(td, "out"), cl.default_params(kmer=0), report=report, n_threads=16, batch_pairs=int(os.environ.get("BATCH", "0")))
         wall = time.time() - t
         print(f"run {it}: wall {wall:.2f}s = load {st.seconds_load:.2f}s (index file + GTF -> HBM) + map {st.seconds_map:.2f}s "
               f"({st.pairs / st.seconds_map / 1e6:.2f} M pairs/s from FASTQ text to {'none PAM SAM'.split()[report]} rows); "

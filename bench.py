@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 # one context drives five HIP streams at once (cm_map_rounds: the pair stage of a round overlaps the seeding / chaining of the next,
 # plus the H2D staging copy); the runtime's default of 4 hardware queues would make two of them share a queue.  Must be set
 # before anything initialises HIP (torch does).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNELS = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_chain_heavy"]
@@ -244,20 +244,37 @@ def main():
     base = rank * args.pairs
     gather = cdist.BsjGather(args.pairs, dev) if multi else None
     turn = [0]
+    trace = bool(os.environ.get("CM_BENCH_TRACE"))
 
     def step():
         # H2D of the next batch on the copy stream, concurrent with the rounds of the resident one
         turn[0] ^= 1
         hp.stage(batches[turn[0]])
+        tr = [time.perf_counter()] if trace else None
         hp.map_rounds(list(range(hi.n_contigs)), True)
+        if trace:
+            tr.append(time.perf_counter())
         # BSJ hand-off to stage 2: records assembled on the device.  One GPU: one small D2H.  N GPUs: gatherv to rank 0 over
         # RCCL from HBM; rank 0's D2H of the gathered records overlaps the next step's rounds and is waited for in fence().
-        if multi:
-            gather.submit(hp.collect_records_device(base, args.pairs, gather.send_ptr()))
+        if multi and os.environ.get("CM_BENCH_DIST_NOGATHER"):       # diagnostic: process group up, hand-off as with one GPU
+            rec = hp.collect_records(base)
+        elif multi:
+            ptr = gather.send_ptr()
+            if trace:
+                tr.append(time.perf_counter())
+            nrec = hp.collect_records_device(base, args.pairs, ptr)
+            if trace:
+                tr.append(time.perf_counter())
+            gather.submit(nrec)
             rec = None
         else:
             rec = hp.collect_records(base)
+        if trace:
+            tr.append(time.perf_counter())
         hp.swap()
+        if trace:
+            tr.append(time.perf_counter())
+            print("step parts (ms): map_rounds(host) %.2f" % ((tr[1] - tr[0]) * 1e3), [round((b - a) * 1e3, 2) for a, b in zip(tr[1:], tr[2:])], file=sys.stderr)
         return rec
 
     def fence():

@@ -1425,7 +1425,7 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     // Five streams of one context work at the same time (seed / chain, heavy chains, pair stage, heavy pairs, H2D staging); the
     // runtime's default of 4 hardware queues makes two of them share one and serialises them.  Only effective when this is the
     // first HIP call of the process; callers that bring up HIP earlier (PyTorch) set the variable themselves (bench.py does).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CM_ENODEV;
     if (p->device < 0 || p->device >= ndev) return CM_ENODEV;

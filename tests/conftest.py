@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # see bench.py: before torch brings up HIP
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # see bench.py: before torch brings up HIP
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

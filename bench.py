@@ -170,6 +170,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 harness on a box with ONE GPU (rank start-up, index sharing through memory-mapped files, barriers,
+    # max-over-ranks timing, record gather): `--backend gloo` + CM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and gathers the
+    # records through host tensors.  Not a measurement: the ranks share the card.
+    one_device = bool(os.environ.get("CM_BENCH_ONE_DEVICE"))
+    dev_index = 0 if one_device else local_rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -196,7 +201,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    gather_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import __graft_entry__ as ge
     if multi:                           # one rank compiles (if anything is stale), the others wait: no concurrent writes of the .o / .so
@@ -229,7 +235,7 @@ def main():
             dist.barrier()
             if rank != 0:
                 hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, index_dir=sdir)
-    P = cl.default_params(device=local_rank)
+    P = cl.default_params(device=dev_index)
     prep_s = time.time() - t0
 
     hp = cl.HotPath(P)
@@ -242,7 +248,7 @@ def main():
     batches = [hp.pinned_batch(d.seq1[i * args.pairs:(i + 1) * args.pairs], d.seq2[i * args.pairs:(i + 1) * args.pairs]) for i in range(2)]
     load_s = time.time() - t0 - prep_s
     base = rank * args.pairs
-    gather = cdist.BsjGather(args.pairs, dev) if multi else None
+    gather = cdist.BsjGather(args.pairs, gather_dev) if multi else None
     turn = [0]
     trace = bool(os.environ.get("CM_BENCH_TRACE"))
 
@@ -258,6 +264,10 @@ def main():
         # RCCL from HBM; rank 0's D2H of the gathered records overlaps the next step's rounds and is waited for in fence().
         if multi and os.environ.get("CM_BENCH_DIST_NOGATHER"):       # diagnostic: process group up, hand-off as with one GPU
             rec = hp.collect_records(base)
+        elif multi and gather_dev.type == "cpu":                     # gloo rehearsal: records through host tensors
+            rec0 = hp.collect_records(base)
+            gather.submit(gather.fill(rec0))
+            rec = None
         elif multi:
             ptr = gather.send_ptr()
             if trace:
@@ -312,7 +322,7 @@ def main():
     ms, launches, counters = hp.prof_get()
     hp.prof(False)
     if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -2,6 +2,7 @@
 reference's build rules (mrsfast HashTable.c:769-839; gene_annotation.cpp:191-399;
 interval_tree_impl.h:40-127,186-242)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -287,3 +288,21 @@ def test_product_builders_equal_the_oracles_own(name, request):
         nseg = np.diff(_arr(av.iv_seg_off, av.n_iv + 1))
         assert nseg.max() >= 3 and (np.diff(_arr(av.giv_gene_off, av.n_giv + 1)) >= 2).any()          # overlapping exons, overlapping genes
         assert _arr(av.gene_start, av.n_gene).min() < 300                                          # the gene next to the chromosome start
+
+
+def test_index_shared_between_ranks_through_files(ds_tiny2r, tmp_path):
+    """bench.py with N > 1 ranks: rank 0 builds the index and dumps the arrays, the other ranks memory-map them
+    (HostIndex.save_index / index_dir): same views"""
+    ds = ds_tiny2r
+    d = str(tmp_path / "shared")
+    ds.hi.save_index(d)
+    h2 = cl.HostIndex(ds.d.contigs, ds.d.chr_table, ds.gtf, kmer=ds.kmer, index_dir=d)
+    for a, b in zip(ds.hi.views, h2.views):
+        assert a.n_entries == b.n_entries and a.ref_len == b.ref_len and a.contig_num == b.contig_num
+        assert np.array_equal(_arr(a.bucket_off, 2 ** 28 + 1), _arr(b.bucket_off, 2 ** 28 + 1))
+        assert np.array_equal(_arr(a.checksum, a.n_entries, np.uint16), _arr(b.checksum, b.n_entries, np.uint16))
+        assert np.array_equal(_arr(a.pos, a.n_entries), _arr(b.pos, b.n_entries))
+    h2.close()
+    open(os.path.join(d, "c0.pos"), "ab").write(b"\0\0\0\0")           # a torn file is refused
+    with pytest.raises(RuntimeError):
+        cl.HostIndex(ds.d.contigs, ds.d.chr_table, ds.gtf, kmer=ds.kmer, index_dir=d)

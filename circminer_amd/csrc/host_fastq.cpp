@@ -510,8 +510,9 @@ struct Out {
         buf.resize(4u << 20);
         n = 0;
     }
+    bool failed = false;                         // a write came up short: reported by the cm_write_* calls / cm_writer_flush
     void flush() {
-        if (f && n) fwrite(buf.data(), 1, n, f);
+        if (f && n && fwrite(buf.data(), 1, n, f) != n) failed = true;
         n = 0;
     }
     void room(size_t k) {
@@ -735,7 +736,7 @@ int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read 
             o.ch('\n');
         }
     }
-    return CM_OK;
+    return (w->o1.failed || w->o2.failed) ? CM_EIO : CM_OK;
 }
 
 // write_pam_rec_pe for the selected pairs (names of R1)
@@ -788,7 +789,7 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
             const uint64_t i = sel ? sel[k] : k;
             pam_row(w, b, states[i], i, w->o1);
         }
-        return CM_OK;
+        return w->o1.failed ? CM_EIO : CM_OK;
     }
     w->o1.flush();
     std::vector<Out> part((size_t)nt);
@@ -801,8 +802,11 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
         }
     });
     for (Out &o : part)
-        if (o.n && fwrite(o.buf.data(), 1, o.n, w->f1) != o.n) return CM_EINVAL;
-    return CM_OK;
+        if (o.n && fwrite(o.buf.data(), 1, o.n, w->f1) != o.n) {
+            w->o1.failed = true;
+            return CM_EIO;
+        }
+    return w->o1.failed ? CM_EIO : CM_OK;
 }
 
 // SAMOutput::print_header (src/output.cpp:301-311)
@@ -918,7 +922,15 @@ int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
             o.ch('\n');
         }
     }
-    return CM_OK;
+    return (w->o1.failed || w->o2.failed) ? CM_EIO : CM_OK;
+}
+
+int cm_writer_flush(cm_writer *w) {
+    if (!w) return CM_EINVAL;
+    w->o1.flush();
+    w->o2.flush();
+    if ((w->f1 && fflush(w->f1) != 0) || (w->f2 && fflush(w->f2) != 0)) w->o1.failed = true;
+    return (w->o1.failed || w->o2.failed) ? CM_EIO : CM_OK;
 }
 
 void cm_writer_close(cm_writer *w) {

@@ -217,6 +217,8 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     }
     if (writer.joinable()) writer.join();
     MAP_TRY(writer_rc, "writer");
+    if (w_map) MAP_TRY(cm_writer_flush(w_map), "writing the mapping file");          // a full disk is an error, not a short file
+    MAP_TRY(cm_writer_flush(w_rem), "writing the remain files");
     st.seconds_map = now() - t1;
     st.seconds_write = write_s;
     cleanup();

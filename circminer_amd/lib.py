@@ -221,6 +221,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_circ_run": (C.c_int, [pp(CircArgs), pp(CircStats), C.c_char_p, C.c_uint64]),
         "cm_write_sam_header": (C.c_int, [vp]),
         "cm_write_sam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_writer_flush": (C.c_int, [vp]),
         "cm_writer_close": (None, [vp]),
     }
     for name, (res, args) in sigs.items():
@@ -238,7 +239,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
-                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
+                    "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_flush", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
 
 class HostIndex:
@@ -522,8 +523,11 @@ class RecordWriter:
 
     def close(self):
         if self.h:
+            rc = self.L.cm_writer_flush(self.h)
             self.L.cm_writer_close(self.h)
             self.h = C.c_void_p()
+            if rc != 0:
+                raise RuntimeError(f"writing failed ({rc}): output file is incomplete")
 
 
 class HotPath:

@@ -43,7 +43,8 @@ enum {
     CM_ENOMEM = -3,     /* host or device allocation failed                             */
     CM_EHIP = -4,       /* a HIP runtime call or kernel failed                          */
     CM_ESTATE = -5,     /* contig / annotation not loaded                               */
-    CM_ELIMIT = -6      /* a documented capacity limit of the device path was exceeded  */
+    CM_ELIMIT = -6,     /* a documented capacity limit of the device path was exceeded  */
+    CM_EIO = -7         /* a write to an output file failed (disk full, ...)            */
 };
 
 #define CM_WINDOW_SIZE 14          /* WINDOW_SIZE, src/common.cpp:7                         */
@@ -358,6 +359,9 @@ int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *st
  * CIGAR "*", MAPQ 255, tags AT / NM / JC / TC; TLEN is printed with %u like the reference does. */
 int cm_write_sam_header(cm_writer *w);
 int cm_write_sam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
+/* Pushes buffered rows to the file(s); CM_EIO if any write since the writer was opened came up short (the cm_write_* calls
+ * report the same as soon as they notice).  cm_writer_close flushes too but cannot report. */
+int cm_writer_flush(cm_writer *w);
 void cm_writer_close(cm_writer *w);
 
 /* ---------------- stage 1 end to end: the caller of the hot path ---------------- */

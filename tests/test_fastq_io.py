@@ -322,3 +322,27 @@ def test_pam_rows_formatted_in_parallel_are_the_same_bytes(built, tmp_path, monk
     rd.close()
     assert out[0] == out[1] and out[0].count(b"\n") == n + len(range(0, n, 3))
     assert out[0].split(b"\n")[5].decode() == py_pam_row("q5", st[5], CHRS)
+
+
+def test_write_errors_are_reported(built, tmp_path):
+    """a full device must not leave a silently truncated file behind (/dev/full accepts the open and fails every write)"""
+    import os
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    rng = np.random.default_rng(4)
+    n = 3000
+    names = [f"w{i}" for i in range(n)]
+    p1, p2 = str(tmp_path / "c_1.fq"), str(tmp_path / "c_2.fq")
+    _fastq(p1, names, ["ACGTACGT"] * n, ["IIIIIIII"] * n)
+    _fastq(p2, names, ["ACGTACGT"] * n, ["IIIIIIII"] * n)
+    rd = cl.FastqReader(p1, p2, CHRS, 4)
+    b = rd.next_batch(n)
+    st = _rand_states(rng, n)
+    w = cl.RecordWriter("/dev/full", None, CHRS)
+    w.write_pam(b, st)                      # buffered: may not notice yet
+    with pytest.raises(RuntimeError):
+        w.close()
+    w = cl.RecordWriter(str(tmp_path / "ok.pam"), None, CHRS)
+    w.write_pam(b, st)
+    w.close()
+    rd.close()

@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
     // for the kernels of the next round that other streams run at the same time; a block walks the list with a grid stride
     const uint32_t n_l = *n_light;
     for (uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x; slot < n_l; slot += gridDim.x * BLK_PAIR) {   // light pairs only, in bucket order
+    const unsigned long long it0 = lane_clk ? wall_clock64() : 0ull;
     const uint32_t t = perm[slot];
     const uint64_t p = pair0 + t;
     const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
@@ -260,7 +261,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
         }
     }
 #else
-    if (lane_clk) lane_clk[p] = wall_clock64() - clk0;       // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks
+    // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks, in processing order (64 consecutive slots = one wave iteration):
+    // low word = the lane's own time for this pair, high word = when its wave began the iteration
+    if (lane_clk) lane_clk[slot] = ((wall_clock64() - it0) & 0xFFFFFFFFull) | ((it0 - clk0) << 32);
 #endif
     }
 }

@@ -557,3 +557,26 @@ def test_reads_of_21_seeds_take_the_wide_build(ds_long, ds_tiny2r):
     with pytest.raises(RuntimeError):
         hp = cl.HotPath(cl.default_params(kmer=14, max_read_len=400))
         hp.upload(cl.ReadBatch(np.full((2, 380), ord("A"), np.uint8), np.full((2, 380), ord("C"), np.uint8)))
+
+
+def test_extension_memo_limit_is_reported(ds_tiny, tmp_path):
+    """The three cases of test_hostemu_parity.test_extension_memo_limit on the device: a full memo alone and a short end piece
+    alone equal the oracle; both in one extend call end the batch with CM_ELIMIT, and the context maps the next batch."""
+    from test_hostemu_parity import tiny_exon_case
+    P = cl.default_params(max_ed=6)
+    _run_all_rounds(tiny_exon_case(tmp_path, 10, 0), P)
+    _run_all_rounds(tiny_exon_case(tmp_path, 6, 4), P)
+    both = tiny_exon_case(tmp_path, 10, 4)
+    hp = cl.HotPath(P)
+    hp.upload(both.batch)
+    hp.load_contig(0, both.hi.views[0], both.hi.annots[0])
+    hp.map_round(0, True)                                 # asynchronous: the flag surfaces at the next synchronising call
+    with pytest.raises(RuntimeError, match="memo"):
+        hp.download()
+    hp.upload(ds_tiny.batch)                              # reported once; the next batch starts clean
+    hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
+    st0, act0 = op.default_state(P, ds_tiny.batch.n)
+    op.map_round(P, ds_tiny.ohi.views[0], ds_tiny.ohi.annots[0], ds_tiny.batch, True, st0, act0)
+    hp.map_round(0, True)
+    assert hp.download()[0].tobytes() == st0.tobytes()
+    hp.close()

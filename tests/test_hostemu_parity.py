@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from circminer_amd import lib as cl
+from circminer_amd import lib as cl, synth
 from oracle import oracle_py as op
 from conftest import first_diff
 
@@ -245,3 +245,64 @@ def test_reads_of_21_seeds(emu24, ds_long, ds_dirty):
     from conftest import _Shim
     _emu_rounds(emu24, _Shim(ds_long, cl.ReadBatch(s1, s2, l1, l2)), cl.default_params(kmer=14, scan_level=1))
     _emu_rounds(emu24, ds_long, cl.default_params(kmer=14, seed_lim=60, max_ed=6))      # many seeds above the hit limit at k = 14
+
+
+def tiny_exon_case(tmp_path, n_tiny, n_del, seed=3):
+    """One gene whose single transcript runs E0 (100 bp), `n_tiny` exons of 10 bp (150-bp introns), E_last (200 bp); one read
+    pair: R1 = 50 bases of E0, every tiny exon, the rest from E_last, with one base deleted from the middle of each of the
+    first `n_del` tiny exons (after the first); R2 = reverse complement of E_last's tail.  The two seeds of R1 fall in E0, so
+    the right extension walks 1 + n_tiny middle pieces (one memo key each) before its end piece, and with n_del > band that
+    end piece has rlen < qlen -- the two conditions DESIGN.md's memo note is about."""
+    from conftest import _Shim
+    rng = np.random.default_rng(seed)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    L = 30_000
+    chrom = A[rng.integers(0, 4, L)].copy()
+    exons, pos = [(5001, 5100)], 5100
+    for _ in range(n_tiny):
+        pos += 150
+        exons.append((pos + 1, pos + 10))
+        pos += 10
+    pos += 150
+    exons.append((pos + 1, pos + 200))
+    t = synth.Transcript(0, "T0", "+", exons)
+    g = synth.Gene(0, "G0", exons[0][0], exons[-1][1], "+", [t])
+    gtf = str(tmp_path / f"tiny_exons_{n_tiny}_{n_del}.gtf")
+    open(gtf, "w").write(synth.gtf_text([g], ["chr1"]))
+    pieces = [chrom[5050:5100]]
+    for k in range(n_tiny):
+        s, e = exons[1 + k]
+        ex = chrom[s - 1:e]
+        pieces.append(np.delete(ex, 5) if 1 <= k <= n_del else ex)
+    s, e = exons[-1]
+    r1 = np.concatenate(pieces + [chrom[s - 1:e]])[:150]
+    r2 = synth.revcomp(chrom[e - 150:e])
+    contigs, table = synth.pack_genome(["chr1"], [chrom], 1 << 20)
+
+    class D:
+        pass
+    ds = D()
+    ds.d, ds.kmer = D(), 20
+    ds.d.contigs, ds.d.chr_table = contigs, table
+    ds.hi = cl.HostIndex(contigs, table, gtf, kmer=20)
+    ds.ohi = op.OracleIndex(contigs, table, gtf, kmer=20)
+    return _Shim(ds, cl.ReadBatch(r1[None, :].copy(), r2[None, :].copy()))
+
+
+def test_extension_memo_limit(emu, tmp_path):
+    """The device memo keeps 8 exon alignments per extend call (cm_core.h MEMO_N) where the reference's std::map is unbounded
+    (src/extend.cpp:299,375).  A full table alone, or a short end piece alone, is exact; both together would let the
+    reference serve a colliding key the device recomputes, so the device code reports CM_ELIMIT (ERR_MEMO) instead."""
+    P = cl.default_params(max_ed=6)
+    full_only = tiny_exon_case(tmp_path, 10, 0)           # 11 middle pieces: inserts dropped, no deletions
+    _emu_rounds(emu, full_only, P)
+    st, act = op.default_state(P, 1)
+    assert op.map_round(P, full_only.ohi.views[0], full_only.ohi.annots[0], full_only.batch, True, st, act)[0] == 0     # CONCRD: the extension ran through
+    short_end_only = tiny_exon_case(tmp_path, 6, 4)       # 7 middle pieces + end = 8 keys: nothing dropped, end piece 1 short
+    _emu_rounds(emu, short_end_only, P)
+    both = tiny_exon_case(tmp_path, 10, 4)
+    st1, act1 = op.default_state(P, 1)
+    cat1 = np.full(1, -1, np.int32)
+    rc = emu.emu_map_round(C.byref(P), C.byref(both.hi.views[0]), C.byref(both.hi.annots[0]), C.byref(both.batch.c), 1, st1.ctypes.data,
+                           act1.ctypes.data, cat1.ctypes.data)
+    assert rc == 16                                       # cmc::ERR_MEMO and nothing else

@@ -988,50 +988,68 @@ CM_HD CM_NOINLINE int local_alignment_sc_impl(const Core &c, const LBuf &s, int 
 
 struct XdropW3 {
     int d[9];
-    int pre_optimum, cur_optimum, lb, ub, pre_ub, on_s, on_t, best_score;
+    int pre_optimum, cur_optimum, lb, ub, pre_ub, on_s, on_k;
 };
-// one anti-diagonal k with k & 1 == PAR (so every slot index below is a compile-time constant);
-// returns false when the reference's loop breaks
-template <int PAR>
-CM_HD inline bool xdrop_w3_step(XdropW3 &x, const LBuf &s, int n, const LBuf &t, int m, int k, int wcap) {
+// eight codes starting at code `at` (0 <= at < cap), one per nibble, code `at` lowest
+CM_HD inline uint32_t nib8(const LBuf &b, int at) {
+    const int w = at >> 3;
+    const uint64_t two = ((uint64_t)b.word(w + 1) << 32) | (uint64_t)b.word(w);
+    return (uint32_t)(two >> (4 * (at & 7)));
+}
+// one anti-diagonal k with k & 1 == PAR (so every slot index below is a compile-time constant); EARLY: k <= W is possible
+// (boundary cells).  `tr` holds the read residual REVERSED (tr[x] = t[m - 1 - x]): the cells of an anti-diagonal pair
+// s[i0 - 1 + r] with t[k - i0 - 1 - r] = tr[m - k + i0 + r], r = 0..3, so one 8-nibble window of each string, XORed,
+// gives the match / mismatch bits of all its cells at once.  Returns false when the reference's loop breaks.
+template <int PAR, bool EARLY>
+CM_HD inline bool xdrop_w3_step(XdropW3 &x, const LBuf &s, int n, const LBuf &tr, int m, int k, int top) {
     constexpr int W = 3;
     constexpr int q0 = PAR ? 1 : 2;
     int new_ub = -1;
     CM_STAT(4, x.ub - x.lb + 1);
-    const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot (k + q0 - W - 1 is even)
-    int sb = i0 - 1;                             // bases: s[i0-1+r], t[k-i0-1-r] for r = 0..3
-    sb = sb < 0 ? 0 : (sb > wcap ? wcap : sb);
-    const uint64_t sw = s.window(sb);
-    int tb = k - i0 - 1 - W;
-    tb = tb < 0 ? 0 : (tb > wcap ? wcap : tb);
-    const uint64_t tw = t.window(tb);
+    const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot (k + q0 - W - 1 is even and >= 0)
+    const int a = i0 - 1, b = m - k + i0;        // first code of the two windows; a >= -1, b >= -3 while a cell is valid
+    uint32_t S = nib8(s, a < 0 ? 0 : (a > top ? top : a));
+    S = a < 0 ? S << 4 : S;
+    uint32_t T = nib8(tr, b < 0 ? 0 : (b > top ? top : b));
+    T = b < 0 ? T << (4 * (-b & 7)) : T;
+    uint32_t ne = S ^ T;                         // codes are < 8: three bits tell two of them apart
+    ne = (ne | (ne >> 1) | (ne >> 2)) & 0x11111111u;
     const int lb = x.lb, ub = x.ub, pre = x.pre_optimum;
+    bool took = false;
 #pragma unroll
     for (int r = 0; r <= W; ++r) {
         constexpr int QMAX = 2 * W + 1;
         const int q = q0 + 2 * r;
         if (q > QMAX) continue;                  // the even class has only W slots
-        const int i = i0 + r, j = k - i;
+        const int i = i0 + r;
         const bool valid = (i >= lb) && (i <= ub);
-        const int so = (i - 1) - sb, to = (j - 1) - tb;      // 0..4 whenever the cell is valid
-        const uint32_t sc_ch = (uint32_t)(sw >> (8 * (so & 7))) & 0xFFu, tc_ch = (uint32_t)(tw >> (8 * (to & 7))) & 0xFFu;
-        const int sub = (sc_ch == tc_ch) ? SC_MAT : SC_MIS;
+        const int sub = ((ne >> (4 * r)) & 1u) ? SC_MIS : SC_MAT;
         const int nb = x.d[q - 1] > x.d[q + 1] ? x.d[q - 1] : x.d[q + 1];
         int v = x.d[q] + sub;
         v = v > nb + SC_IND ? v : nb + SC_IND;
-        const bool take = valid && (v >= x.cur_optimum);
+        const bool take = valid && (v >= x.cur_optimum);     // ascending i: a later cell wins a tie, as in the reference
         x.cur_optimum = take ? v : x.cur_optimum;
         x.on_s = take ? i : x.on_s;
-        x.on_t = take ? j : x.on_t;
-        x.best_score = take ? v : x.best_score;
+        took = took || take;
         v = (v + SC_XD < pre) ? -DPTINF : v;
         new_ub = (valid && v > -DPTINF) ? i : new_ub;
-        const bool bnd = (k <= W) && (q == k + W + 1 || q == W + 1 - k);     // boundary cells (k,0), (0,k)
-        x.d[q] = valid ? v : (bnd ? k * SC_IND : -DPTINF);
+        if (EARLY) {
+            const bool bnd = (k <= W) && (q == k + W + 1 || q == W + 1 - k);     // boundary cells (k,0), (0,k)
+            x.d[q] = valid ? v : (bnd ? k * SC_IND : -DPTINF);
+        } else {
+            x.d[q] = valid ? v : -DPTINF;
+        }
     }
-    const int lb_t = k - x.lb;
-    if (lb_t == m || (k > W && ((k - W) % 2 == 0))) ++x.lb;
-    if (x.ub < n && (k <= W || (k > W && ((k - W) % 2 == 1)))) ++x.ub;
+    x.on_k = took ? k : x.on_k;                  // on_t = on_k - on_s
+    if (EARLY) {
+        if (k - x.lb == m || (k > W && ((k - W) % 2 == 0))) ++x.lb;
+        if (x.ub < n && (k <= W || (k > W && ((k - W) % 2 == 1)))) ++x.ub;
+    } else if (PAR) {                            // k > W, k - W even
+        ++x.lb;
+    } else {                                     // k > W, k - W odd
+        if (k - x.lb == m) ++x.lb;
+        if (x.ub < n) ++x.ub;
+    }
     if ((x.pre_ub == -1 && new_ub == -1) || x.lb > x.ub) return false;
     x.pre_ub = new_ub;
     x.pre_optimum = cmax(x.pre_optimum, x.cur_optimum);
@@ -1043,26 +1061,28 @@ CM_HD inline bool xdrop_w3_step(XdropW3 &x, const LBuf &s, int n, const LBuf &t,
 //    d[q] still holds (k-2, q) when (k, q) is computed and d[q +- 1] hold anti-diagonal k-1;
 //  * the loop is unrolled by two anti-diagonals so the slot class of each half is static;
 //  * branch-free cells (selects), at most 4 per anti-diagonal instead of a 9-slot loop;
-//  * the 4 reference and 4 read bases an anti-diagonal needs come from one 5-byte LDS window each.
-CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
+//  * the substitution scores of an anti-diagonal come from one XOR of two nibble windows (the read residual is staged
+//    reversed for this: `tr`); the best cell is kept as (row, anti-diagonal), its score is cur_optimum.
+CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &tr, int m, int &sc_len, int &indel, int &align_score) {
     constexpr int W = 3;
     XdropW3 x;
-    x.on_s = x.on_t = x.best_score = 0;
+    x.on_s = x.on_k = x.cur_optimum = 0;
     if (m > 0 && n > 0) {
 #pragma unroll
         for (int q = 0; q < 2 * W + 3; ++q) x.d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
-        x.pre_optimum = x.cur_optimum = 0;
+        x.pre_optimum = 0;
         x.lb = x.ub = 1;
         x.pre_ub = 0;
-        const int wcap = (s.cap < t.cap ? s.cap : t.cap) - 8;
+        const int top = (s.cap < tr.cap ? s.cap : tr.cap) - 1;
         const int kmax = m + n;
-        for (int k = 2; k <= kmax; k += 2) {
-            if (!xdrop_w3_step<0>(x, s, n, t, m, k, wcap)) break;
+        bool go = xdrop_w3_step<0, true>(x, s, n, tr, m, 2, top) && kmax >= 3 && xdrop_w3_step<1, true>(x, s, n, tr, m, 3, top);
+        for (int k = 4; go && k <= kmax; k += 2) {
+            if (!xdrop_w3_step<0, false>(x, s, n, tr, m, k, top)) break;
             if (k + 1 > kmax) break;
-            if (!xdrop_w3_step<1>(x, s, n, t, m, k + 1, wcap)) break;
+            if (!xdrop_w3_step<1, false>(x, s, n, tr, m, k + 1, top)) break;
         }
     }
-    const int score = x.best_score, on_s = x.on_s, on_t = x.on_t;
+    const int score = x.cur_optimum, on_s = x.on_s, on_t = x.on_k - x.on_s;
     const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
     Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, W + 1, 0};
     if (ed <= (uint32_t)c.P.max_ed) {
@@ -1206,11 +1226,13 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
     }
     CM_TICK(sm, 26);
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
+    const bool w3 = c.P.band == 3;
     stage(s, n, sm.a, 4);
-    stage(t, m, sm.b, 5);
+    stage(w3 ? t.rev(m) : t, m, sm.b, 5);                     // the band-3 DP walks the read residual from its far end
+    CM_STAT(11 + (m > 16) + (m > 32) + (m > 64), 1);          // X-drop DPs by read-residual length (test-only counters)
     CM_TICK(sm, 27);
-    const int r = c.P.band == 3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
-                                : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+    const int r = w3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
+                     : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
     CM_TICK(sm, 28);
     return r;
 }

@@ -261,9 +261,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
         }
     }
 #else
-    // diagnostic only (CM_LANE_CLK=1), 100 MHz ticks, in processing order (64 consecutive slots = one wave iteration):
-    // low word = the lane's own time for this pair, high word = when its wave began the iteration
-    if (lane_clk) lane_clk[slot] = ((wall_clock64() - it0) & 0xFFFFFFFFull) | ((it0 - clk0) << 32);
+    // diagnostic only (CM_LANE_CLK=1), in processing order (64 consecutive slots = one wave iteration): low word = the
+    // wave's time for this iteration (100 MHz ticks; the clock is read after the lanes have reconverged), high word = the pair
+    if (lane_clk) lane_clk[slot] = ((wall_clock64() - it0) & 0xFFFFFFFFull) | ((unsigned long long)t << 32);
 #endif
     }
 }
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint
 // per *wave* by k_pair_heavy (64 lanes share the pairing predicate, the mate-pair extensions and the
 // unpaired-chain extensions; lane 0 folds the outcomes in the reference's order).  Everything else
 // stays one pair per lane in k_pair.
-constexpr int HEAVY_COST = 8;
+constexpr int HEAVY_COST = 6;             // hg38-like bench, ms per step at 3 / 4 / 5 / 6 / 8 / 12 / 16: 32.1 / 31.3 / 26.5 / 26.6 / 28.0 / 30.1 / 31.7
 constexpr int N_BUCKETS = 7;             // residual-length buckets
 constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_heavy (one wave each)
 // class of a pair for the pair stage: -2 inactive, HEAVY_CLS heavy (k_pair_heavy), else
@@ -1868,7 +1868,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         // both pair kernels are persistent: together they fill `pair_waves` wave slots per SIMD (256 CUs x 4 SIMDs), half each
         static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
         const unsigned cap = 256u * 4u * slots_per_simd;
-        const unsigned heavy_cap = cap / 2u;
+        static const unsigned heavy_div = getenv("CM_HEAVY_DIV") ? (unsigned)atoi(getenv("CM_HEAVY_DIV")) : 2u;      // tuning knob
+        const unsigned heavy_cap = cap / (heavy_div ? heavy_div : 2u);
         const unsigned heavy_grid = nt < heavy_cap ? (nt ? nt : 1u) : heavy_cap;
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,

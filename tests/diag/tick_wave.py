@@ -12,6 +12,14 @@ P = cl.default_params(); hp = cl.HotPath(P); hp.load_contig(0, hi.views[0], hi.a
 hp.L.cm_debug_lane_clk.argtypes = [C.c_void_p, C.c_void_p]
 b = cl.ReadBatch(d.seq1, d.seq2); hp.upload(b)
 hp.reset(); hp.map_round(0, True); hp.sync()
+if os.environ.get('ONLY_CAT'):             # a batch of one category only (e.g. 0 = concordant), all pairs different
+    cat = hp.download()[1]
+    sel = np.nonzero(cat == int(os.environ['ONLY_CAT']))[0]
+    if os.environ.get('ONLY_SRC'): sel = sel[d.src[sel] == int(os.environ['ONLY_SRC'])]
+    if os.environ.get('SAME'): sel = sel[int(os.environ['SAME']):int(os.environ['SAME']) + 1]
+    sel = sel[np.arange(b.n) % len(sel)]
+    b = cl.ReadBatch(d.seq1[sel], d.seq2[sel]); hp.upload(b)
+    hp.reset(); hp.map_round(0, True); hp.sync()
 clk = np.zeros(b.n * 33, np.uint64); assert hp.L.cm_debug_lane_clk(hp.h, clk.ctypes.data) == 0
 nw = b.n // 64 + 1
 w = clk[b.n * 16: b.n * 16 + nw * 64].reshape(-1, 64).astype(np.float64)

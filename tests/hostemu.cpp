@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -132,6 +133,12 @@ int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_v
     return e.err;
 }
 
+// diagnostic (tests/diag/lane_cost.py): when set, emu_map_round writes the CPU time of each pair's pair stage (ns) here
+static double *g_pair_ns = nullptr;
+static uint32_t *g_pair_dps = nullptr;      // number of real DPs (cmc::stage calls) of each pair
+void emu_set_cost_out(double *out) { g_pair_ns = out; }
+void emu_set_dp_out(uint32_t *out) { g_pair_dps = out; }
+
 int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last, cm_mapped_read *state,
                   uint8_t *active, int32_t *category) {
     Emu e;
@@ -158,7 +165,11 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
         const int l1 = (int)(R->off1[p + 1] - R->off1[p]), l2 = (int)(R->off2[p + 1] - R->off2[p]);
         uint8_t bufa[1024], bufb[1024];
         const cmc::DpMem sm{cmc::LBuf{bufa, 1024}, cmc::LBuf{bufb, 1024}, &e.err};
+        const auto t0 = std::chrono::steady_clock::now();
+        const unsigned long long dp0 = cm_stats[8];
         const int st = cmc::process_read(e.core, sm, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);
+        if (g_pair_ns) g_pair_ns[p] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+        if (g_pair_dps) g_pair_dps[p] = (uint32_t)(cm_stats[8] - dp0);
         cmc::finish_round(e.core, st, is_last, l1, l2, state[p], active[p]);
         category[p] = st;
     }

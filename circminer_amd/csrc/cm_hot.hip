@@ -1038,6 +1038,7 @@ __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, i
 // ------------------------------------------------------------------ host side
 struct Slot {
     bool loaded = false, has_annot = false;
+    uint64_t gen = 0;                    // bumped by every (un)load: work prepared against an older content of the slot is stale
     bool chain_parallel_ok = false;      // see k_chain_heavy: no annotated hop longer than maxIntronLen
     cm_index_view X{};
     cmc::AnnotDev A{};
@@ -1058,6 +1059,14 @@ struct cm_ctx {
     hipStream_t stream_p = nullptr, stream_p2 = nullptr;
     hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
     bool pair_pending[2] = {false, false};
+    // cross-batch prefetch (cm_map_rounds): the staged batch's first round seeded and chained under this batch's last pair stage
+    int item_base = 0;                        // items (tile x round) mapped so far: item i uses chain-record set (item_base + i) & 1
+    bool pre_launched = false;                // done for the staged batch ...
+    bool pre_ready = false;                   // ... which cm_reads_swap has made the current one
+    int pre_slot = -1, pre_b = 0;
+    uint64_t pre_gen = 0, pre_n = 0;
+    uint8_t *d_ones = nullptr;                // all-active flags of a fresh batch
+    uint64_t ones_cap = 0;
     unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
     std::string err = "";
     Slot slots[MAX_SLOTS];
@@ -1187,6 +1196,9 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
+    dfree(c->d_ones);
+    c->ones_cap = 0;
+    c->pre_launched = c->pre_ready = false;
     c->staged = false;
     c->st_n_pairs = 0;
     c->n_pairs = 0;
@@ -1244,8 +1256,9 @@ RoundBufs round_bufs(cm_ctx *c, int b) {
     return b ? RoundBufs{c->d_chains_b, c->d_nchain_b, c->d_high_b, c->d_resid_b} : RoundBufs{c->d_chains, c->d_nchain, c->d_high, c->d_resid};
 }
 
-int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, const uint8_t *act) {
-    const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
+ReadsDev current_reads(const cm_ctx *ctx) { return ReadsDev{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2}; }
+
+int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const uint8_t *act) {
     const int S = ctx->n_seeds;
     const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
     if (total == 0) return CM_OK;
@@ -1257,8 +1270,8 @@ int run_seed_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_til
     return CM_OK;
 }
 
-int run_chain_tile(cm_ctx *ctx, const KCore &core, uint64_t pair0, uint32_t n_tile, bool parallel_ok, const uint8_t *act, const RoundBufs &rb) {
-    const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
+int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, bool parallel_ok, const uint8_t *act,
+                   const RoundBufs &rb) {
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
     if (n_prob == 0 || S == 0) return CM_OK;
@@ -1519,6 +1532,7 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     Slot &s = ctx->slots[slot];
     free_all(s.idx_allocs);
     s.loaded = false;
+    ++s.gen;
     const size_t nb = ((size_t)1 << (2 * CM_WINDOW_SIZE)) + 1;
     s.X = *iv;
     int rc;
@@ -1547,6 +1561,7 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     Slot &s = ctx->slots[slot];
     free_all(s.ann_allocs);
     s.has_annot = false;
+    ++s.gen;
     cmc::AnnotAosHost aos;
     cmc::build_annot_aos(*av, aos);
     cmc::AnnotDev &A = s.A;
@@ -1593,6 +1608,7 @@ int cm_unload_contig(cm_ctx *ctx, int slot) {
     free_all(ctx->slots[slot].idx_allocs);
     free_all(ctx->slots[slot].ann_allocs);
     ctx->slots[slot].loaded = ctx->slots[slot].has_annot = false;
+    ++ctx->slots[slot].gen;
     return CM_OK;
 }
 
@@ -1725,6 +1741,7 @@ int cm_reads_upload(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t n = rd->n_pairs;
+    ctx->pre_ready = false;                        // a prefetched first round belonged to a batch that came in through cm_reads_swap
     ctx->n_pairs = 0;
     ctx->tile = 0;
     if (n == 0) {                                  // an empty batch releases the per-batch buffers
@@ -1760,6 +1777,7 @@ int cm_reads_stage(cm_ctx *ctx, const cm_reads *rd, const cm_mapped_read *prior)
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_copy));          // an earlier staged batch that was never swapped in is dropped
     ctx->staged = false;
+    ctx->pre_launched = false;
     if ((rc = copy_reads(ctx, rd, ctx->stream_copy, ctx->st_seq1_base, ctx->st_seq2_base, ctx->st_off1, ctx->st_off2))) return rc;
     ctx->st_has_prior = prior != nullptr;
     if (prior) {
@@ -1791,6 +1809,9 @@ int cm_reads_swap(cm_ctx *ctx) {
     ctx->d_seq2 = ctx->d_seq2_base + cmc::CM_STAGE_PAD;
     ctx->staged = false;
     const uint64_t n = ctx->st_n_pairs;
+    ctx->pre_ready = ctx->pre_launched;                            // cm_map_rounds prepared this batch's first round already
+    ctx->pre_launched = false;
+    ctx->pre_n = n;
     ctx->n_pairs = 0;
     int rc = prepare_resident(ctx, n, ctx->st_max_len);
     if (rc) return rc;
@@ -1904,11 +1925,16 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
     uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
+    // Was this batch's first round prepared while the previous batch was in its last pair stage (see the end of this function)?
+    const bool use_pre = ctx->pre_ready && slots[0] == ctx->pre_slot && ctx->slots[slots[0]].gen == ctx->pre_gen && ctx->n_pairs == ctx->pre_n &&
+                         ctx->n_pairs <= ctx->tile && (ctx->item_base & 1) == ctx->pre_b;
+    ctx->pre_ready = ctx->pre_launched = false;            // the rounds below reuse both sets of chain records
+    const ReadsDev rd_cur = current_reads(ctx);
     int item = 0;
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
         for (int r = 0; r < n_rounds; ++r, ++item) {
-            const int b = item & 1;
+            const int b = (ctx->item_base + item) & 1;
             const Slot &sl = ctx->slots[slots[r]];
             const KCore core = make_core(ctx, sl);
             const RoundBufs rb = round_bufs(ctx, b);
@@ -1916,18 +1942,52 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
             // While the pair stage of round r - 1 is still writing A[r & 1], this round's seeding reads the flags from before
             // round r - 1 (a superset: pairs retired by round r - 1 get chains nobody looks at).
             const uint8_t *act_prep = (r == 0) ? A[0] : A[(r - 1) & 1];
-            if (ctx->pair_pending[b]) {                                       // chain buffers of set b: free once their pair stage is done
-                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
-                ctx->pair_pending[b] = false;
+            if (!(use_pre && item == 0)) {                                    // else: set b holds this round's chains, ev_prep[b] is recorded
+                if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+                    ctx->pair_pending[b] = false;
+                }
+                if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return rc;
+                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, act_prep, rb))) return rc;
+                HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
             }
-            if ((rc = run_seed_tile(ctx, core, p0, nt, act_prep))) return rc;
-            if ((rc = run_chain_tile(ctx, core, p0, nt, sl.chain_parallel_ok, act_prep, rb))) return rc;
-            HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
             const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
             if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return rc;
             static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: rounds back to back
             if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
         }
+    }
+    ctx->item_base = (ctx->item_base + item) & 1;
+    // Cross-batch prefetch.  A batch's first round cannot hide behind one of its own pair stages, and its last pair stage has no
+    // later round of its own to cover.  So when this call ends the batch and the next one is already staged (cm_reads_stage),
+    // that batch's first round against slots[0] is seeded and chained now, from the staging buffers (every pair of a fresh batch
+    // is active), into the set of chain records the running pair stage does not read.  cm_reads_swap keeps the result;
+    // the next cm_map_rounds uses it if it starts with the same slot, still holding the same contig.  Conditions: one tile, and
+    // the staged batch fits the workspace as it is sized now (nothing may be reallocated under the kernels in flight).
+    static const bool prefetch_on = !(getenv("CM_PREFETCH") && getenv("CM_PREFETCH")[0] == '0');
+    if (prefetch_on && last_is_final && ctx->staged && ctx->st_n_pairs <= ctx->n_pairs && ctx->n_pairs <= ctx->tile && ctx->st_max_len <= ctx->max_len) {
+        const int b = ctx->item_base;
+        const Slot &sl = ctx->slots[slots[0]];
+        const KCore core = make_core(ctx, sl);
+        const uint32_t nt = (uint32_t)ctx->st_n_pairs;
+        if (ctx->ones_cap < ctx->st_n_pairs) {
+            HIPCHK(ctx, ensure(ctx, ctx->d_ones, ctx->n_pairs));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_ones, 1, ctx->n_pairs, ctx->stream));
+            ctx->ones_cap = ctx->n_pairs;
+        }
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
+        if (ctx->pair_pending[b]) {
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+            ctx->pair_pending[b] = false;
+        }
+        const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
+        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones))) return rc;
+        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, round_bufs(ctx, b)))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
+        ctx->pre_launched = true;
+        ctx->pre_slot = slots[0];
+        ctx->pre_gen = sl.gen;
+        ctx->pre_b = b;
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p));
@@ -2117,7 +2177,7 @@ int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt,
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, p0, nt, ctx->d_active))) return rc;
+        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active))) return rc;
         const size_t cnt = (size_t)nt * 4 * ctx->n_seeds, o = (size_t)p0 * 4 * ctx->n_seeds;
         HIPCHK(ctx, hipMemcpyAsync(out_start + o, ctx->d_sstart, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(out_cnt + o, ctx->d_scnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2135,9 +2195,9 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, p0, nt, ctx->d_active))) return rc;
+        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_chains, 0, (size_t)nt * 4 * CM_BESTCHAINLIM * sizeof(cm_chain), ctx->stream));
-        if ((rc = run_chain_tile(ctx, core, p0, nt, ctx->slots[slot].chain_parallel_ok, ctx->d_active, round_bufs(ctx, 0)))) return rc;
+        if ((rc = run_chain_tile(ctx, core, current_reads(ctx), p0, nt, ctx->slots[slot].chain_parallel_ok, ctx->d_active, round_bufs(ctx, 0)))) return rc;
         const size_t np = (size_t)nt * 4, o = (size_t)p0 * 4;
         HIPCHK(ctx, hipMemcpyAsync(out_chains + o * CM_BESTCHAINLIM, ctx->d_chains, np * CM_BESTCHAINLIM * sizeof(cm_chain), hipMemcpyDeviceToHost,
                                    ctx->stream));

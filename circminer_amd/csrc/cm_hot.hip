@@ -1929,6 +1929,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     const bool use_pre = ctx->pre_ready && slots[0] == ctx->pre_slot && ctx->slots[slots[0]].gen == ctx->pre_gen && ctx->n_pairs == ctx->pre_n &&
                          ctx->n_pairs <= ctx->tile && (ctx->item_base & 1) == ctx->pre_b;
     ctx->pre_ready = ctx->pre_launched = false;            // the rounds below reuse both sets of chain records
+    if (use_pre) ++ctx->launches[7];
     const ReadsDev rd_cur = current_reads(ctx);
     int item = 0;
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {

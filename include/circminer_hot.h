@@ -206,7 +206,11 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round);
  * Results are those of n_rounds cm_map_round calls.  What differs is the schedule: seeds and chains of a round depend on the
  * reads and the contig only (the carried MatchedRead enters in the pair stage), so round r + 1 is seeded and chained on the
  * main streams while the pair stage of round r still runs on a second pair of streams; chain buffers and active flags are
- * double-buffered.  Asynchronous like cm_map_round. */
+ * double-buffered.  Asynchronous like cm_map_round.
+ * Across batches: when last_is_final is set and a batch is staged (cm_reads_stage) that fits the workspace of the resident
+ * one, its first round against slots[0] is seeded and chained under this batch's last pair stage; after cm_reads_swap the next
+ * cm_map_rounds takes that work over if its slots[0] is the same slot, still holding the same contig and annotation
+ * (otherwise it is discarded and redone: results never depend on it). */
 int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final);
 
 /* Copy back the carried state, the per-pair return value of process_read in the last
@@ -265,7 +269,8 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 /* ---------------- timing hooks for bench.py (HIP events on the ctx stream) ---------------- */
 /* Milliseconds spent in each kernel class since the last cm_prof_reset(), and launch counts:
  * [0]=k_seed [1]=k_chain (light problems) [2]=k_pair (light pairs) [3]=k_scan_* [4]=k_pair_heavy
- * [5]=class / counting-sort kernels [6]=k_chain_heavy [7]=0.  [1] and [2] are timed up to the join with the second
+ * [5]=class / counting-sort kernels [6]=k_chain_heavy [7]=no time; launches[7] = first rounds taken over from the
+ * cross-batch prefetch of cm_map_rounds.  [1] and [2] are timed up to the join with the second
  * stream, on which the heavy kernels [6] / [4] run concurrently. */
 int cm_prof_enable(cm_ctx *ctx, int on);
 int cm_prof_reset(cm_ctx *ctx);

@@ -580,3 +580,53 @@ def test_extension_memo_limit_is_reported(ds_tiny, tmp_path):
     hp.map_round(0, True)
     assert hp.download()[0].tobytes() == st0.tobytes()
     hp.close()
+
+
+def test_cross_batch_prefetch_is_used_and_discarded_correctly(ds_tiny2r, ds_dirty):
+    """cm_map_rounds seeds / chains the staged batch's first round under the resident batch's last pair stage.  Every batch
+    equals the oracle whether that work is taken over (same first slot, same contig: launches[7] counts it) or has to be
+    discarded (slot reloaded in between, another first slot, a call that is not the batch's last, a staged batch that does
+    not fit the resident workspace)."""
+    ds = ds_tiny2r
+    P = cl.default_params(kmer=ds.kmer)
+    hp = cl.HotPath(P)
+    for ci in range(ds.hi.n_contigs):
+        hp.load_contig(ci, ds.hi.views[ci], ds.hi.annots[ci])
+    n = ds.batch.n
+    h = n // 2
+    pa = hp.pinned_batch(ds.d.seq1[:h], ds.d.seq2[:h])
+    pb = hp.pinned_batch(ds.d.seq1[h:2 * h], ds.d.seq2[h:2 * h])
+    small = hp.pinned_batch(ds.d.seq1[:h // 2], ds.d.seq2[:h // 2])
+    want, _, _ = op.map_all_rounds(P, ds.ohi, ds.batch)
+    slots = list(range(ds.hi.n_contigs))
+
+    def taken():
+        return hp.prof_get()[1][7]
+
+    hp.prof(True)
+    hp.stage(pa); hp.swap()
+    hp.stage(pb)
+    hp.map_rounds(slots)                                   # prefetches B's first round
+    assert hp.download()[0].tobytes() == want[:h].tobytes() and taken() == 0
+    hp.swap(); hp.stage(pa)
+    hp.map_rounds(slots)                                   # takes it over; prefetches A's
+    assert hp.download()[0].tobytes() == want[h:2 * h].tobytes() and taken() == 1
+    hp.swap(); hp.stage(pb)
+    hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])    # slot 0 reloaded: the prefetched chains are stale
+    hp.map_rounds(slots)
+    assert hp.download()[0].tobytes() == want[:h].tobytes() and taken() == 1
+    hp.swap(); hp.stage(pa)                                # B resident (prefetched under the previous call)
+    hp.map_rounds(slots[::-1], last_is_final=False)        # another first slot: discarded; not the last call: no prefetch
+    hp.reset()
+    hp.map_rounds(slots)
+    assert hp.download()[0].tobytes() == want[h:2 * h].tobytes() and taken() == 1
+    hp.swap(); hp.stage(small)
+    hp.map_rounds(slots)                                   # A again, taken over; prefetches the smaller batch
+    assert hp.download()[0].tobytes() == want[:h].tobytes() and taken() == 2
+    hp.swap(); hp.stage(pb)                                # pb is larger than the resident batch now: no prefetch
+    hp.map_rounds(slots)
+    assert hp.download()[0].tobytes() == want[:h // 2].tobytes() and taken() == 3
+    hp.swap(); hp.stage(ds_dirty.batch)
+    hp.map_rounds(slots)
+    assert hp.download()[0].tobytes() == want[h:2 * h].tobytes() and taken() == 3
+    hp.close()

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(BLK_CHAIN, CM_CHAIN_WAVES) k_chain(KCore kc, R
 __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
                                                    int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
-                                                   const uint32_t *perm, const unsigned int *n_light) {
+                                                   const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
@@ -222,9 +222,14 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
 #endif
     const Core c = cmc::to_core(kc);
     // persistent grid: the launch places every workgroup at once (gridDim <= resident capacity), so the dispatcher is free
-    // for the kernels of the next round that other streams run at the same time; a block walks the list with a grid stride
+    // for the kernels of the next round that other streams run at the same time.  A wave takes the next 64 pairs of the list
+    // (light pairs only, in bucket order: most expensive classes first) from a shared cursor whenever it is done with its
+    // last: waves that drew cheap pairs take more of them, and all of them finish within one chunk of each other.
     const uint32_t n_l = *n_light;
-    for (uint32_t slot = blockIdx.x * BLK_PAIR + threadIdx.x; slot < n_l; slot += gridDim.x * BLK_PAIR) {   // light pairs only, in bucket order
+    auto take = [&]() { return (uint32_t)__shfl((int)(threadIdx.x == 0 ? atomicAdd(next_chunk, 1u) : 0u), 0); };
+    for (uint32_t chunk = take(); (uint64_t)chunk * BLK_PAIR < n_l; chunk = take()) {
+    const uint32_t slot = chunk * BLK_PAIR + threadIdx.x;
+    if (slot >= n_l) continue;
     const unsigned long long it0 = lane_clk ? wall_clock64() : 0ull;
     const uint32_t t = perm[slot];
     const uint64_t p = pair0 + t;
@@ -914,7 +919,7 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
 __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
-                                                         int str_cap, unsigned long long *dbg_rows, HRes *hres) {
+                                                         int str_cap, unsigned long long *dbg_rows, HRes *hres, unsigned int *next_pair) {
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
@@ -945,7 +950,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc
     }
     const Core c = cmc::to_core(kc);
     const unsigned int n_heavy = *hcount;
-    for (unsigned int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    // one pair at a time from a shared cursor (the list starts with the most expensive pairs)
+    auto take = [&]() { return (unsigned int)__shfl((int)(lane == 0 ? atomicAdd(next_pair, 1u) : 0u), 0); };
+    for (unsigned int h = take(); h < n_heavy; h = take()) {
         const uint32_t t = hlist[h];
         const uint64_t p = pair0 + t;
         const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
@@ -1880,6 +1887,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                            ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
     }
+    constexpr int CTR_NEXT = 48;      // spare words of the class counters: the pair kernels' work cursors (light, heavy)
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), sp));
     // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
     // behind it.
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
@@ -1891,20 +1900,24 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         const unsigned cap = 256u * 4u * slots_per_simd;
         static const unsigned heavy_div = getenv("CM_HEAVY_DIV") ? (unsigned)atoi(getenv("CM_HEAVY_DIV")) : 2u;      // tuning knob
         const unsigned heavy_cap = cap / (heavy_div ? heavy_div : 2u);
-        const unsigned heavy_grid = nt < heavy_cap ? (nt ? nt : 1u) : heavy_cap;
+        static const unsigned heavy_fix = getenv("CM_HEAVY_GRID") ? (unsigned)atoi(getenv("CM_HEAVY_GRID")) : 0u;    // tuning knob
+        const unsigned heavy_lim = heavy_fix ? heavy_fix : heavy_cap;
+        const unsigned heavy_grid = nt < heavy_lim ? (nt ? nt : 1u) : heavy_lim;
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
-                           ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres);
+                           ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres,
+                           ctx->d_cls_ctr + CTR_NEXT + 1);
         ++ctx->launches[4];
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join_p, sp2));
     {
         Timer t(ctx, 2, sp);      // = the pair stage: the light kernel and the wait for the second stream
         static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
-        const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = 256u * 4u * slots_per_simd;       // light takes the slots heavy leaves: full cap
+        static const unsigned light_fix = getenv("CM_PAIR_GRID") ? (unsigned)atoi(getenv("CM_PAIR_GRID")) : 0u;       // tuning knob
+        const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = light_fix ? light_fix : 256u * 4u * slots_per_simd;   // light takes the slots heavy leaves: full cap
         hipLaunchKernelGGL(k_pair, dim3(want < cap ? want : cap), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, ctx->d_perm,
-                           ctx->d_cls_ctr + CTR_SUM);
+                           ctx->d_cls_ctr + CTR_SUM, ctx->d_cls_ctr + CTR_NEXT);
         HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
         ++ctx->launches[2];
     }

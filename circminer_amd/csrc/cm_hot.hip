@@ -359,7 +359,10 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
     return n;
 }
 
-__global__ void __launch_bounds__(64) k_chain_heavy(KCore kc_, ReadsDev rd, uint64_t pair0, int S, const uint32_t *sstart, const uint32_t *scnt,
+#ifndef CM_CHEAVY_WAVES
+#define CM_CHEAVY_WAVES 3      // waves per SIMD k_chain_heavy is compiled for (158 VGPRs as it stands)
+#endif
+__global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, ReadsDev rd, uint64_t pair0, int S, const uint32_t *sstart, const uint32_t *scnt,
                                                     const unsigned long long *celloff, double *dp_score, int32_t *dp_prev, uint8_t *pool,
                                                     unsigned long long pool_bytes, unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain,
                                                     int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm) {
@@ -646,9 +649,17 @@ __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chai
 }
 // work class of one chaining problem: number of (hit, later hit) pairs the DP may have to examine
 __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const uint32_t *sraw, int S, uint32_t n_prob, int8_t *cls, int32_t *high,
-                                                  unsigned long long light_w, unsigned int light_cells, int32_t *nchain, uint16_t *resid) {
+                                                  unsigned long long light_w, unsigned int light_cells, int32_t *nchain, uint16_t *resid,
+                                                  const uint8_t *active, uint64_t pair0) {
     const uint32_t r = blockIdx.x * BLK + threadIdx.x;
     if (r >= n_prob) return;
+    if (!active[pair0 + (r >> 2)]) {    // seeded under older flags (a superset), retired since: no chains wanted
+        high[r] = 0;
+        nchain[r] = 0;
+        resid[r] = 0;
+        cls[r] = -2;
+        return;
+    }
     unsigned long long w = 0, suffix = 0;
     int hh = 0;
     for (int s = S - 1; s >= 0; --s) {
@@ -1323,7 +1334,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
         Timer t(ctx, 5);
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
         hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, rb.high,
-                           light_w, light_cells, rb.nchain, rb.resid);
+                           light_w, light_cells, rb.nchain, rb.resid, act, pair0);
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_cblk, nbk, (const uint32_t *)nullptr,
                            (const unsigned int *)nullptr);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cblk, nbk, ctx->d_cctr, -1, N_CLS);
@@ -1956,13 +1967,23 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
             // While the pair stage of round r - 1 is still writing A[r & 1], this round's seeding reads the flags from before
             // round r - 1 (a superset: pairs retired by round r - 1 get chains nobody looks at).
             const uint8_t *act_prep = (r == 0) ? A[0] : A[(r - 1) & 1];
+            // CM_CHAIN_EXACT=1 (diagnostic): the chain kernels wait for the pair stage of round r - 1 and use its output flags
+            // A[r & 1], i.e. skip what it retired (23 % / 47 % of the pairs in rounds 2 / 3 of the hg38-like bench: chain kernels
+            // 8.4 -> 6.7 ms per step).  Measured slower overall (25.1 vs 24.0 ms): the wait removes what overlap the chain
+            // kernels had with the tail of that pair stage.
+            const uint8_t *act_chain = A[r & 1];
             if (!(use_pre && item == 0)) {                                    // else: set b holds this round's chains, ev_prep[b] is recorded
                 if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
                     ctx->pair_pending[b] = false;
                 }
                 if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return rc;
-                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, act_prep, rb))) return rc;
+                static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
+                if (exact_flags && r > 0 && ctx->pair_pending[b ^ 1]) {       // item - 1 = the same tile's round r - 1
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
+                    ctx->pair_pending[b ^ 1] = false;
+                }
+                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, exact_flags ? act_chain : act_prep, rb))) return rc;
                 HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
             }
             const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;

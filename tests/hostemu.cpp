@@ -197,6 +197,16 @@ int emu_drop_sc(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, i
 }
 int emu_leftovers_matter(int T, int min_ret1, int can1, int min_ret2, int can2) { return cmc::leftovers_matter(T, min_ret1, can1 != 0, min_ret2, can2 != 0) ? 1 : 0; }
 int emu_leftover_type(int min_ret1, int min_ret2, int g1, int g2) { return cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0); }
+// one k-mer probe of a forward-strand string: occurrences, first entry and the search-touch count (test_seed_touch_count)
+uint32_t emu_probe(const cm_params *P, const cm_index_view *X, const uint8_t *seq, int qpos, uint32_t *start, uint32_t *touches) {
+    Core c{};
+    c.P = *P;
+    c.X = cmc::to_dev(*X);
+    const cmc::Probe pr = cmc::seed_probe(c, cmc::SV{seq, 0, 1, 0}, qpos);
+    *start = pr.start;
+    *touches = pr.touches;
+    return pr.raw;
+}
 int emu_one_side(const cm_params *P, const uint8_t *s, int n, const uint8_t *t, int m, int w) {
     Core c{};
     c.P = *P;

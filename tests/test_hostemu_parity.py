@@ -306,3 +306,79 @@ def test_extension_memo_limit(emu, tmp_path):
     rc = emu.emu_map_round(C.byref(P), C.byref(both.hi.views[0]), C.byref(both.hi.annots[0]), C.byref(both.batch.c), 1, st1.ctypes.data,
                            act1.ctypes.data, cat1.ctypes.data)
     assert rc == 16                                       # cmc::ERR_MEMO and nothing else
+
+
+def test_seed_touch_count(emu, ds_tiny):
+    """cmc::seed_probe: occurrences, first entry and the search-touch counter (SURVEY 8(d): 8 bytes per element the
+    reference's two binary searches look at, src/match_read.cpp:54-110) against those two searches run literally on the index
+    arrays, for k-mers that occur once, several times (repeat families) and not at all.  (At k = 20 a bucket holds 4 entries on
+    average -- 4^14 buckets -- so a galloping upper bound, tried in round 2, has nothing to save.)"""
+    P = cl.default_params()
+    iv = ds_tiny.hi.views[0]
+    n_ent = int(iv.n_entries)
+    W = 14                                               # CM_WINDOW_SIZE: bases in the bucket hash
+    off = np.ctypeslib.as_array(iv.bucket_off, ((1 << (2 * W)) + 1,))
+    cks = np.ctypeslib.as_array(iv.checksum, (n_ent,))
+    pos = np.ctypeslib.as_array(iv.pos, (n_ent,))
+    g = ds_tiny.d.contigs[0]
+    emu.emu_probe.argtypes = [C.POINTER(cl.Params), C.POINTER(cl.IndexView), C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    emu.emu_probe.restype = C.c_uint32
+    code = np.full(256, -1, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+
+    def reference(kmer):
+        cd = code[kmer]
+        if (cd < 0).any():
+            return 0, 0, 0
+        hv = 0
+        for x in cd[:W]:
+            hv = hv * 4 + int(x)
+        cv = 0
+        for x in cd[W:]:
+            cv = cv * 4 + int(x)
+        target = cv - 65536 if cv >= 32768 else cv
+        b0, b1 = int(off[hv]), int(off[hv + 1])
+        if b1 == b0:
+            return 0, 0, 0
+        it, t = cks[b0:b1].astype(np.int64), 0
+        lb, ub = 1, b1 - b0
+        while lb < ub:
+            mid = (lb + ub) // 2
+            t += 1
+            if target <= it[mid - 1]:
+                ub = mid
+            else:
+                lb = mid + 1
+        t += 1
+        if ub < lb or target != it[lb - 1]:
+            return 0, 0, t
+        LB, ub = lb, b1 - b0
+        while lb < ub:
+            mid = (lb + ub + 1) // 2
+            t += 1
+            if target < it[mid - 1]:
+                ub = mid - 1
+            else:
+                lb = mid
+        t += 1
+        UB = lb if target == it[lb - 1] else LB
+        return UB - LB + 1, b0 + LB - 1, t
+
+    rng = np.random.default_rng(3)
+    runs = np.diff(np.flatnonzero(np.concatenate(([True], cks[1:] != cks[:-1], [True]))))
+    assert runs.max() >= 3                               # the repeat families give runs of equal checksums
+    long_starts = np.flatnonzero(np.concatenate(([True], cks[1:] != cks[:-1])))[runs >= 2]
+    where = list(rng.integers(0, len(g) - 20, 600)) + [int(pos[s]) - 1 for s in long_starts[-400:]]
+    seen_multi = 0
+    for p in where:
+        kmer = g[p:p + 20].copy()
+        for mutate in (False, True):
+            if mutate:
+                kmer[int(rng.integers(W, 20))] = ord("ACGT"[int(rng.integers(0, 4))])
+            st, tc = C.c_uint32(0), C.c_uint32(0)
+            raw = emu.emu_probe(C.byref(P), C.byref(iv), kmer.ctypes.data, 0, C.byref(st), C.byref(tc))
+            want = reference(kmer)
+            assert (raw, tc.value) == (want[0], want[2]) and (raw == 0 or st.value == want[1]), (p, mutate, raw, st.value, tc.value, want)
+            seen_multi += raw >= 2
+    assert seen_multi >= 100

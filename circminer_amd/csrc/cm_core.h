@@ -150,17 +150,20 @@ struct KCore {          // what the host passes as a kernel argument (plain poin
     cm_params P;
     cm_index_view X;
     AnnotDev A;
+    const uint32_t *desc = nullptr;       // optional bucket descriptors (desc_pack below), null = none
 };
 struct Core {
     cm_params P;
     IndexV X;
     AnnotV A;
+    g_u32 desc = nullptr;
 };
 CM_HD inline Core to_core(const KCore &k) {
     Core c;
     c.P = k.P;
     c.X = to_dev(k.X);
     c.A = to_dev(k.A);
+    c.desc = (g_u32)k.desc;
     return c;
 }
 
@@ -196,6 +199,64 @@ struct Probe {
     uint32_t raw;       // occurrences (0 == frags NULL)
     uint32_t touches;   // binary-search element touches (algorithmic-byte counter)
 };
+// The two binary searches of get_exact_locs_hash (src/match_read.cpp:54-110) over the n checksums of one bucket, element i
+// (1-based in the reference) read through at(i - 1).  Counts every element looked at, like the reference's loops.
+template <class AT> CM_HD inline void probe_search(const AT &at, uint32_t n, int target, uint32_t b0, Probe &r) {
+    uint32_t lb = 1, ub = n, mid;
+    while (lb < ub) {
+        mid = (lb + ub) / 2;
+        ++r.touches;
+        if (target <= at(mid - 1)) ub = mid;
+        else lb = mid + 1;
+    }
+    ++r.touches;
+    if (ub < lb || target != at(lb - 1)) return;
+    const uint32_t LB = lb;
+    uint32_t UB = lb;
+    ub = n;
+    while (lb < ub) {
+        mid = (lb + ub + 1) / 2;
+        ++r.touches;
+        if (target < at(mid - 1)) ub = mid - 1;
+        else lb = mid;
+    }
+    ++r.touches;
+    if (target == at(lb - 1)) UB = lb;
+    r.start = b0 + (LB - 1);
+    r.raw = UB - LB + 1;
+}
+// Bucket descriptors (device-side acceleration of the probe, built from the index arrays when a contig is loaded): 16 bytes per
+// hash bucket = offset of its first entry, min(n, 255), and -- when they fit -- the checksums of all its entries, so that a probe
+// is ONE random 16-byte read instead of a read of the offset table followed by reads of the checksum array.  A checksum has
+// 2 (k - 14) bits (k = 20: 12 bits, 7 of them fit; a 1.1-Gbp contig fills a bucket with 4 k-mers on average).  Larger buckets
+// keep going through the arrays.
+constexpr int DESC_WORDS = 4;
+CM_HD inline int desc_cbits(int kmer) { return 2 * (kmer - CM_WINDOW_SIZE); }
+CM_HD inline uint32_t desc_inline(int kmer) { return desc_cbits(kmer) > 0 ? (uint32_t)(88 / desc_cbits(kmer)) : 254u; }
+CM_HD inline int desc_value(uint32_t d1, uint32_t d2, uint32_t d3, uint32_t i, int cbits) {
+    const uint32_t sh = 8u + i * (uint32_t)cbits, w = sh >> 5, bit = sh & 31u;
+    const uint32_t lo = w == 0 ? d1 : (w == 1 ? d2 : d3), hi = w == 0 ? d2 : (w == 1 ? d3 : 0u);
+    const uint64_t two = ((uint64_t)hi << 32) | lo;
+    return (int)((uint32_t)(two >> bit) & ((1u << cbits) - 1u));
+}
+template <class CK> CM_HD inline void desc_pack(uint32_t b0, uint32_t n, const CK &cks /* cks(i) = checksum of entry b0 + i */, int kmer, uint32_t out[DESC_WORDS]) {
+    const int cbits = desc_cbits(kmer);
+    uint64_t lo = n < 255u ? n : 255u;      // bits 0..63 of the 96-bit field, hi = bits 64..95
+    uint32_t hi = 0;
+    if (n <= desc_inline(kmer) && cbits > 0)
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t sh = 8u + i * (uint32_t)cbits;
+            const uint64_t v = (uint64_t)(cks(i) & ((1u << cbits) - 1u));
+            if (sh < 64u) {
+                lo |= v << sh;
+                if (sh + (uint32_t)cbits > 64u) hi |= (uint32_t)(v >> (64u - sh));
+            } else hi |= (uint32_t)(v << (sh - 64u));
+        }
+    out[0] = b0;
+    out[1] = (uint32_t)lo;
+    out[2] = (uint32_t)(lo >> 32);
+    out[3] = hi;
+}
 CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
     Probe r{0u, 0u, 0u};
     // hashVal / checkSumVal without branches (a 4-way switch per base made k_seed scalar-ALU bound): a base is
@@ -215,31 +276,23 @@ CM_HD inline Probe seed_probe(const Core &c, const SV &s, int qpos) {
     }
     if (bad) return r;
     const int target = (int)(int16_t)cv;     // int16 quirk, src/match_read.cpp:77
+    if (c.desc) {
+        const g_u32 d = c.desc + (uint64_t)(uint32_t)hv * DESC_WORDS;
+        uint32_t w[DESC_WORDS];
+        __builtin_memcpy(w, (const CM_G uint8_t *)d, sizeof(w));     // one 16-byte load
+        const uint32_t n8 = w[1] & 0xffu;
+        if (n8 == 0) return r;
+        if (n8 <= desc_inline(c.P.kmer)) {
+            const int cbits = desc_cbits(c.P.kmer);
+            const uint32_t d1 = w[1], d2 = w[2], d3 = w[3];
+            probe_search([&](uint32_t i) { return cbits > 0 ? desc_value(d1, d2, d3, i, cbits) : 0; }, n8, target, w[0], r);
+            return r;
+        }
+    }
     const uint32_t b0 = c.X.bucket_off[hv], b1 = c.X.bucket_off[hv + 1];
     if (b1 == b0) return r;
     const g_u16 it = c.X.checksum + b0;
-    uint32_t lb = 1, ub = b1 - b0, mid;
-    while (lb < ub) {
-        mid = (lb + ub) / 2;
-        ++r.touches;
-        if (target <= (int)it[mid - 1]) ub = mid;
-        else lb = mid + 1;
-    }
-    ++r.touches;
-    if (ub < lb || target != (int)it[lb - 1]) return r;
-    const uint32_t LB = lb;
-    uint32_t UB = lb;
-    ub = b1 - b0;
-    while (lb < ub) {
-        mid = (lb + ub + 1) / 2;
-        ++r.touches;
-        if (target < (int)it[mid - 1]) ub = mid - 1;
-        else lb = mid;
-    }
-    ++r.touches;
-    if (target == (int)it[lb - 1]) UB = lb;
-    r.start = b0 + (LB - 1);
-    r.raw = UB - LB + 1;
+    probe_search([&](uint32_t i) { return (int)it[i]; }, b1 - b0, target, b0, r);
     return r;
 }
 

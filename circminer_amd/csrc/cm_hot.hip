@@ -927,7 +927,10 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
     return mr.type;
 }
 
-__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
+#ifndef CM_HEAVY_WAVES
+#define CM_HEAVY_WAVES CM_PAIR_WAVES
+#endif
+__global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
                                                          int str_cap, unsigned long long *dbg_rows, HRes *hres, unsigned int *next_pair) {
@@ -1043,6 +1046,17 @@ __global__ void __launch_bounds__(BLK) k_gather_records(const uint32_t *perm, co
 __global__ void k_err_clear(int *err, int mask) {
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAnd(err, ~mask);
 }
+// bucket descriptors of a loaded contig (cmc::desc_pack): one thread per hash bucket
+__global__ void __launch_bounds__(BLK) k_build_desc(const uint32_t *bucket_off, const uint16_t *checksum, uint64_t n_buckets, int kmer, uint32_t *desc) {
+    const uint64_t hv = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (hv >= n_buckets) return;
+    const uint32_t b0 = bucket_off[hv], n = bucket_off[hv + 1] - b0;
+    uint32_t out[cmc::DESC_WORDS];
+    cmc::desc_pack(b0, n, [&](uint32_t i) { return (uint32_t)checksum[b0 + i]; }, kmer, out);
+    uint4 v;
+    v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+    ((uint4 *)desc)[hv] = v;
+}
 __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
@@ -1057,6 +1071,7 @@ __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, i
 struct Slot {
     bool loaded = false, has_annot = false;
     uint64_t gen = 0;                    // bumped by every (un)load: work prepared against an older content of the slot is stale
+    uint32_t *d_desc = nullptr;          // bucket descriptors (cmc::desc_pack), one of idx_allocs; null when switched off
     bool chain_parallel_ok = false;      // see k_chain_heavy: no annotated hop longer than maxIntronLen
     cm_index_view X{};
     cmc::AnnotDev A{};
@@ -1258,6 +1273,7 @@ KCore make_core(const cm_ctx *c, const Slot &s) {
     k.P = c->P;
     k.X = s.X;
     k.A = s.A;
+    k.desc = s.d_desc;
     return k;
 }
 
@@ -1549,6 +1565,7 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     Slot &s = ctx->slots[slot];
     free_all(s.idx_allocs);
+    s.d_desc = nullptr;
     s.loaded = false;
     ++s.gen;
     const size_t nb = ((size_t)1 << (2 * CM_WINDOW_SIZE)) + 1;
@@ -1566,6 +1583,19 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     if ((rc = up(ctx, s.idx_allocs, iv->bucket_off, nb, &s.X.bucket_off))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->checksum, (size_t)iv->n_entries, &s.X.checksum))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->pos, (size_t)iv->n_entries, &s.X.pos))) return rc;
+    s.d_desc = nullptr;
+    static const bool use_desc = !(getenv("CM_SEED_DESC") && getenv("CM_SEED_DESC")[0] == '0');
+    if (use_desc) {          // 16 bytes per bucket (4 GiB per contig): a probe becomes one random read instead of two dependent ones
+        const uint64_t n_buckets = nb - 1;
+        uint32_t *d = nullptr;
+        if (hipMalloc((void **)&d, n_buckets * cmc::DESC_WORDS * sizeof(uint32_t)) == hipSuccess) {
+            s.idx_allocs.push_back(d);
+            hipLaunchKernelGGL(k_build_desc, dim3((unsigned)((n_buckets + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, s.X.bucket_off, s.X.checksum, n_buckets,
+                               ctx->P.kmer, d);
+            HIPCHK(ctx, hipGetLastError());
+            s.d_desc = d;
+        } else (void)hipGetLastError();      // not enough HBM: probes go through the arrays
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     s.loaded = true;
     return CM_OK;
@@ -1626,6 +1656,7 @@ int cm_unload_contig(cm_ctx *ctx, int slot) {
     free_all(ctx->slots[slot].idx_allocs);
     free_all(ctx->slots[slot].ann_allocs);
     ctx->slots[slot].loaded = ctx->slots[slot].has_annot = false;
+    ctx->slots[slot].d_desc = nullptr;
     ++ctx->slots[slot].gen;
     return CM_OK;
 }

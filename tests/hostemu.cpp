@@ -98,11 +98,31 @@ void chain_all(Emu &e, const uint8_t *active) {
 
 extern "C" {
 
+// bucket descriptors (cmc::desc_pack), built on request for ONE index view; every entry point below uses them for that view
+static std::vector<uint32_t> g_desc;
+static const void *g_desc_of = nullptr;
+int emu_build_desc(const cm_params *P, const cm_index_view *X) {
+    const uint64_t nb = (uint64_t)1 << (2 * CM_WINDOW_SIZE);
+    g_desc.assign((size_t)nb * cmc::DESC_WORDS, 0u);
+    for (uint64_t hv = 0; hv < nb; ++hv) {
+        const uint32_t b0 = X->bucket_off[hv], n = X->bucket_off[hv + 1] - b0;
+        cmc::desc_pack(b0, n, [&](uint32_t i) { return (uint32_t)X->checksum[b0 + i]; }, P->kmer, g_desc.data() + hv * cmc::DESC_WORDS);
+    }
+    g_desc_of = X->bucket_off;
+    return 0;
+}
+void emu_free_desc() {
+    std::vector<uint32_t>().swap(g_desc);
+    g_desc_of = nullptr;
+}
+static const uint32_t *desc_for(const cm_index_view *X) { return (g_desc_of && g_desc_of == X->bucket_off) ? g_desc.data() : nullptr; }
+
 int emu_seed_batch(const cm_params *P, const cm_index_view *X, const cm_reads *R, uint32_t n_slots, uint32_t *out_start, uint32_t *out_cnt,
                    uint32_t *out_raw) {
     Emu e;
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
+    e.core.desc = desc_for(X);
     memset(&e.core.A, 0, sizeof e.core.A);
     e.R = R;
     e.S = n_seeds_of(P, R);
@@ -120,6 +140,7 @@ int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_v
     Emu e;
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
+    e.core.desc = desc_for(X);
     cmc::build_annot_aos(*A, e.aos);
     e.core.A = cmc::to_dev(cmc::annot_dev_host(*A, e.aos));
     e.R = R;
@@ -144,6 +165,7 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
     Emu e;
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
+    e.core.desc = desc_for(X);
     cmc::build_annot_aos(*A, e.aos);
     e.core.A = cmc::to_dev(cmc::annot_dev_host(*A, e.aos));
     e.R = R;
@@ -202,6 +224,7 @@ uint32_t emu_probe(const cm_params *P, const cm_index_view *X, const uint8_t *se
     Core c{};
     c.P = *P;
     c.X = cmc::to_dev(*X);
+    c.desc = desc_for(X);
     const cmc::Probe pr = cmc::seed_probe(c, cmc::SV{seq, 0, 1, 0}, qpos);
     *start = pr.start;
     *touches = pr.touches;

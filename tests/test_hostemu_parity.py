@@ -382,3 +382,45 @@ def test_seed_touch_count(emu, ds_tiny):
             assert (raw, tc.value) == (want[0], want[2]) and (raw == 0 or st.value == want[1]), (p, mutate, raw, st.value, tc.value, want)
             seen_multi += raw >= 2
     assert seen_multi >= 100
+
+
+@pytest.mark.parametrize("kmer", [20, 22, 15])
+def test_bucket_descriptors(emu, tmp_path_factory, kmer):
+    """The device answers a k-mer probe from a 16-byte bucket descriptor (offset, count, the checksums of a small bucket packed at
+    2 (k - 14) bits each: cmc::desc_pack, built when a contig is loaded) instead of the offset table + checksum array.  Same
+    code on the CPU with descriptors built by the same packer: seed ranges, occurrence counts and search-touch counts equal the
+    array path's, and a whole mapping round equals the oracle's; k = 20 (12-bit checksums, 7 inline), k = 22 (16 bits, the int16
+    quirk, 5 inline) and k = 15 (2 bits, 44 inline)."""
+    from conftest import DataSet
+    ds = DataSet(tmp_path_factory.mktemp(f"desc{kmer}"), "tiny", 500, 61 + kmer, kmer=kmer)
+    P = cl.default_params(kmer=kmer)
+    iv, b = ds.hi.views[0], ds.batch
+    S = b.max_len() // kmer
+    a0, b0, c0 = (np.zeros(b.n * 4 * S, np.uint32) for _ in range(3))
+    assert emu.emu_seed_batch(C.byref(P), C.byref(iv), C.byref(b.c), S, a0.ctypes.data, b0.ctypes.data, c0.ctypes.data) == 0
+    emu.emu_probe.argtypes = [C.POINTER(cl.Params), C.POINTER(cl.IndexView), C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    emu.emu_probe.restype = C.c_uint32
+    g = ds.d.contigs[0]
+    rng = np.random.default_rng(kmer)
+    where = rng.integers(0, len(g) - kmer, 3000)
+
+    def probes():
+        out = []
+        for p in where:
+            st, tc = C.c_uint32(0), C.c_uint32(0)
+            raw = emu.emu_probe(C.byref(P), C.byref(iv), g[p:p + kmer].ctypes.data, 0, C.byref(st), C.byref(tc))
+            out.append((raw, st.value if raw else 0, tc.value))
+        return out
+
+    plain = probes()
+    emu.emu_build_desc.argtypes = [C.POINTER(cl.Params), C.POINTER(cl.IndexView)]
+    assert emu.emu_build_desc(C.byref(P), C.byref(iv)) == 0
+    try:
+        assert probes() == plain
+        a1, b1, c1 = (np.zeros_like(a0) for _ in range(3))
+        assert emu.emu_seed_batch(C.byref(P), C.byref(iv), C.byref(b.c), S, a1.ctypes.data, b1.ctypes.data, c1.ctypes.data) == 0
+        assert (b0 == b1).all() and (c0 == c1).all() and (a0[c0 > 0] == a1[c0 > 0]).all()
+        _emu_rounds(emu, ds, P)
+    finally:
+        emu.emu_free_desc()
+    assert sum(r[0] > 0 for r in plain) > 1000 and max(r[0] for r in plain) >= 3      # runs that cross the 32- and 64-bit word borders

@@ -365,7 +365,7 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
 __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, ReadsDev rd, uint64_t pair0, int S, const uint32_t *sstart, const uint32_t *scnt,
                                                     const unsigned long long *celloff, double *dp_score, int32_t *dp_prev, uint8_t *pool,
                                                     unsigned long long pool_bytes, unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain,
-                                                    int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm) {
+                                                    int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm, unsigned int *next_problem) {
     extern __shared__ uint32_t lds_words[];
     CM_L uint32_t *LP = (CM_L uint32_t *)lds_words;
     const int lane = threadIdx.x;
@@ -373,7 +373,9 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
     const int kmer = c.P.kmer;
     const uint32_t max_best = (uint32_t)c.P.max_chain_len;
     const unsigned int n_heavy = *n_perm;
-    for (unsigned int hidx = blockIdx.x; hidx < n_heavy; hidx += gridDim.x) {
+    // the list starts with the heaviest class; a wave takes the next problem from a shared cursor when it is done with its last
+    auto take = [&]() { return (unsigned int)__shfl((int)(lane == 0 ? atomicAdd(next_problem, 1u) : 0u), 0); };
+    for (unsigned int hidx = take(); hidx < n_heavy; hidx = take()) {
         const uint32_t r = perm[hidx];
         const uint64_t p = pair0 + (r >> 2);
         const int mate = (int)((r >> 1) & 1u);
@@ -1364,6 +1366,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
         const uint32_t n = b - a;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
         if (use_split) {          // the few long problems run on the second stream, concurrently with the bulk
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_cctr + 48, 0, sizeof(unsigned int), ctx->stream));       // spare word of the class counters: work cursor
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             {
@@ -1374,7 +1377,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
             static const size_t heavy_pad = getenv("CM_CHEAVY_LDS_PAD") ? (size_t)atoi(getenv("CM_CHEAVY_LDS_PAD")) : 0;     // occupancy experiment
             hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
                                ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, ctx->d_err,
-                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1);
+                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + 48);
             ++ctx->launches[6];
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));

@@ -73,10 +73,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         std::vector<uint64_t> sel;
         cm_fastq_batch batch;
     } res[2];
-    std::thread writer;
-    int writer_rc = CM_OK;
+    std::thread writer, parser;
+    int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
+        if (parser.joinable()) parser.join();
         if (writer.joinable()) writer.join();
         if (w_map) cm_writer_close(w_map);
         if (w_rem) cm_writer_close(w_rem);
@@ -163,7 +164,7 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     }
     MAP_TRY(cm_fastq_open(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, &fq), "cm_fastq_open");
 
-    // ---- batches: write k-1 (worker thread) | all rounds of k (device) | parse k+1 (this thread) ----
+    // ---- batches: write k-1 (worker thread) | all rounds of k (device, driven by this thread) | parse k+1 (worker thread) ----
     const double t1 = now();
     cm_fastq_batch cur, nxt;
     double write_s = 0.0;                                       // written by the writer thread, read after its join
@@ -175,22 +176,29 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     for (uint64_t k = 0; cur.reads.n_pairs; ++k) {
         const uint64_t n = cur.reads.n_pairs;
         Result &R = res[k & 1];
+        // cm_map_rounds keeps this thread busy for most of the device time (the chain stage reads two words back per round), so
+        // the next batch is tokenised on a thread of its own meanwhile (the parser keeps three batches alive: k - 1 being
+        // written, k on the device, k + 1 being parsed)
+        double parse_s = 0.0;
+        parser = std::thread([&]() {
+            const double tp = now();
+            parser_rc = cm_fastq_next(fq, batch_pairs, &nxt);
+            parse_s = now() - tp;
+        });
         double td = now();
         MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
         {
             std::vector<int> all(n_con);
             for (uint32_t c = 0; c < n_con; ++c) all[c] = (int)c;
-            MAP_TRY(cm_map_rounds(cm, all.data(), (int)n_con, 1), "cm_map_rounds");   // asynchronous; round r + 1 seeds while r pairs
+            MAP_TRY(cm_map_rounds(cm, all.data(), (int)n_con, 1), "cm_map_rounds");   // round r + 1 seeds while r pairs
         }
-        st.seconds_device += now() - td;
-        const double tp = now();
-        MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");
-        st.seconds_parse += now() - tp;
         R.state.resize(n);
         R.active.resize(n);
-        td = now();
         MAP_TRY(cm_reads_download(cm, R.state.data(), nullptr, R.active.data()), "cm_reads_download");
         st.seconds_device += now() - td;
+        parser.join();
+        st.seconds_parse += parse_s;
+        MAP_TRY(parser_rc, "cm_fastq_next");
         R.sel.clear();
         for (uint64_t i = 0; i < n; ++i) {
             if (R.active[i]) R.sel.push_back(i);

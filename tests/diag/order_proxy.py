@@ -70,3 +70,38 @@ for cols, nm in (([0, 1, 2, 3, 4, 5], 'linear model on residuals, gaps, chain-pa
     w, *_ = np.linalg.lstsq(X[:, cols], cost[li], rcond=None)
     pred = X[:, cols] @ w
     print('   %-70s %.3f   corr %.2f' % (nm + ':', fill(li[np.argsort(-pred, kind="stable")]), np.corrcoef(pred, cost[li])[0, 1]))
+
+# --- what k_pair_cls could compute itself: is each of the four residuals of the main orientation's best chains equal to the genome next to the chain?
+comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+first_r = ch['rpos'][:, :, 0, 0].astype(np.int64)
+last_r = np.take_along_axis(ch['rpos'][:, :, 0, :].astype(np.int64), np.maximum(clen - 1, 0)[:, :, None], 2)[:, :, 0]
+inex = np.zeros((N, 2, 2), bool)        # [pair, which of the two main problems, left/right]
+for side, xsel in ((0, fx), (1, bx)):
+    for p in li:
+        x = xsel[p]
+        if nc[p, x] <= 0: continue
+        mate, rc = x >> 1, x & 1
+        rd = (d.seq2 if mate else d.seq1)[p]
+        if rc: rd = comp[rd[::-1]]
+        q0, r0 = first_q[p, x], first_r[p, x]          # rpos is 1-based: genome[r0 - 1] aligns with rd[q0]
+        qe, re = lastq[p, x] + k, last_r[p, x] + k      # first base after the chain
+        if q0 > 0:
+            lo = r0 - 1 - q0
+            inex[p, side, 0] = lo < 0 or not np.array_equal(g[lo:lo + q0], rd[:q0])
+        if qe < L:
+            lo = re - 1
+            inex[p, side, 1] = lo + (L - qe) > len(g) or not np.array_equal(g[lo:lo + L - qe], rd[qe:])
+nin = inex.reshape(N, 4).sum(1)
+print('pairs by number of inexact residuals (genomic compare):', np.bincount(nin[li]).tolist(), ' corr(nin, real DPs) %.2f' % np.corrcoef(nin[li], ndp[li])[0, 1])
+inlen = (inex.reshape(N, 4) * res4).sum(1)       # bases in inexact residuals
+for name, key in (('inexact sides x 64 + total residual', nin * 64 + np.minimum(tot, 63)), ('bases in inexact residuals', inlen),
+                  ('inexact bases x 4 + total residual', inlen * 4 + tot), ('inexact bases x 4 + total + 30 x chain-pair cost', inlen * 4 + tot + 30 * pc)):
+    print('   sorted by %-50s %.3f   corr with cost %.2f' % (name + ':', fill(li[np.argsort(-key[li], kind="stable")]), np.corrcoef(key[li], cost[li])[0, 1]))
+X2 = np.stack([np.ones(len(li)), tot[li], mx[li], gap2[li], pc[li], (res4[li] > 0).sum(1), nin[li], inlen[li]], 1)
+w, *_ = np.linalg.lstsq(X2, cost[li], rcond=None)
+pred = X2 @ w
+print('   linear model incl. inexact sides / bases: %.3f  corr %.2f  weights %s' % (fill(li[np.argsort(-pred, kind="stable")]), np.corrcoef(pred, cost[li])[0, 1], np.round(w, 3).tolist()))
+q = np.digitize(pred, np.quantile(pred, np.linspace(0, 1, 17)[1:-1]))          # 16 levels of the model as one radix key
+print('   the same model quantised to 16 levels (one 4-bit radix pass), ties in input order: %.3f' % fill(li[np.argsort(-q, kind="stable")]))
+q8 = np.digitize(pred, np.quantile(pred, np.linspace(0, 1, 257)[1:-1]))
+print('   256 levels (two passes): %.3f' % fill(li[np.argsort(-q8, kind="stable")]))

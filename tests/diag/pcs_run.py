@@ -1,5 +1,5 @@
-"""Driver for a PC-sampling pass (rocprofv3 --pc-sampling-beta-enabled ...): a few mapping rounds of one batch.
-BATCH=mix|conc  PRESET  PAIRS  CM_LIB (a -gline-tables-only build: DIAG_FLAGS=-gline-tables-only DIAG_NAME=pcs bash tests/diag/build_diag.sh)"""
+"""Driver for the PMC passes of pmc_mix.sh: a few mapping rounds of one batch on chr21.
+BATCH=mix|conc|same|rep64|rest  PRESET  PAIRS  REPS  CM_LIB (a variant build)"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

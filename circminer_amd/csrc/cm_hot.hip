@@ -1975,6 +1975,14 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
 int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final) {
     if (!ctx || (n_rounds > 0 && !slots) || n_rounds < 0) return CM_EINVAL;
     int rc;
+    // a failed stage leaves earlier pair stages in flight: wait for them, so that the caller may reuse or free the batch buffers
+    auto bail = [&](int e) {
+        (void)hipStreamSynchronize(ctx->stream_p);
+        (void)hipStreamSynchronize(ctx->stream_p2);
+        ctx->pair_pending[0] = ctx->pair_pending[1] = false;
+        ctx->pre_ready = ctx->pre_launched = false;
+        return e;
+    };
     for (int r = 0; r < n_rounds; ++r)
         if ((rc = check_slot(ctx, slots[r], true))) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
@@ -2011,17 +2019,17 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
                     ctx->pair_pending[b] = false;
                 }
-                if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return rc;
+                if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return bail(rc);
                 static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
                 if (exact_flags && r > 0 && ctx->pair_pending[b ^ 1]) {       // item - 1 = the same tile's round r - 1
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
                     ctx->pair_pending[b ^ 1] = false;
                 }
-                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, exact_flags ? act_chain : act_prep, rb))) return rc;
+                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, exact_flags ? act_chain : act_prep, rb))) return bail(rc);
                 HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
             }
             const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
-            if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return rc;
+            if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return bail(rc);
             static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: rounds back to back
             if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
         }
@@ -2050,8 +2058,8 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
             ctx->pair_pending[b] = false;
         }
         const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
-        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones))) return rc;
-        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, round_bufs(ctx, b)))) return rc;
+        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones))) return bail(rc);
+        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, round_bufs(ctx, b)))) return bail(rc);
         HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         ctx->pre_launched = true;
         ctx->pre_slot = slots[0];

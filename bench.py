@@ -6,7 +6,8 @@
 
 Default workload = the configuration the metric is quoted on (BASELINE.json configs[2], scaled to one step): an hg38-sized
 synthetic genome (24 chromosomes with hg38's lengths, 3.09 Gbp -> three packed contigs, all resident in HBM, three mapping
-rounds), k = 20, batches of 1 M 2x150 bp pairs.
+rounds), k = 20, batches of 2^21 2x150 bp pairs = two launch tiles of 2^20 (with two tiles the library walks them round by
+round, so a tile's seeding sees the flags its previous pair stage wrote: DESIGN.md 5.25).
 
 A "step" is one batch through the whole hot path:
   * its reads come from (page-locked) host memory: cm_reads_stage copies batch k+1 over PCIe on a copy stream while batch
@@ -150,7 +151,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hg38like", choices=sorted(WORKLOAD_NOTE))
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per batch (= per step and GPU)")
+    ap.add_argument("--pairs", type=int, default=1 << 21, help="pairs per batch (= per step and GPU); the library maps tiles of <= 2^20 pairs")
     ap.add_argument("--seed", type=int, default=38)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: CPU rehearsal of the launch, tests only)")
@@ -343,7 +344,7 @@ def main():
         try:
             with open(args.traffic) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("pairs") == args.pairs:
+            if tj.get("workload") == args.workload and tj.get("pairs") == min(args.pairs, 1 << 20):      # pairs per launch (tile)
                 traffic = tj.get("bytes_per_launch", {}).get(KERNELS[dom])
                 traffic_src = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/traffic.json), not this run"
         except Exception:

@@ -1100,6 +1100,7 @@ struct cm_ctx {
     bool pre_ready = false;                   // ... which cm_reads_swap has made the current one
     int pre_slot = -1, pre_b = 0;
     uint64_t pre_gen = 0, pre_n = 0;
+    uint32_t pre_nt = 0;                      // pairs of the prefetched item (the staged batch's first tile)
     uint8_t *d_ones = nullptr;                // all-active flags of a fresh batch
     uint64_t ones_cap = 0;
     unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
@@ -1991,62 +1992,78 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
     uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
-    // Was this batch's first round prepared while the previous batch was in its last pair stage (see the end of this function)?
+    // The work items: (tile, round).  One tile per batch: its rounds in order.  Several tiles: ROUND-major -- every tile through
+    // round r, then every tile through round r + 1 -- so that between the pair stage of (tile, r) and the seeding of (tile, r + 1)
+    // lies the work of the other tiles: the flags that pair stage wrote are final when the seeding starts, and seeds / chains are
+    // computed for exactly the pairs still active (with one tile the seeding of round r + 1 runs UNDER the pair stage of round r
+    // and has to take the flags from before it, a superset: 20 % more seeding and chaining on the hg38-like bench).
+    struct Item { uint64_t p0; uint32_t nt; int r; };
+    std::vector<Item> items;
+    const uint64_t n_tiles = (ctx->n_pairs + ctx->tile - 1) / ctx->tile;
+    static const bool tile_major_env = getenv("CM_TILE_MAJOR") && getenv("CM_TILE_MAJOR")[0] == '1';      // diagnostic: the round-2 order
+    const bool round_major = n_tiles >= 2 && !tile_major_env;
+    auto tile_nt = [&](uint64_t t) { return (uint32_t)((ctx->n_pairs - t * ctx->tile < ctx->tile) ? ctx->n_pairs - t * ctx->tile : ctx->tile); };
+    if (round_major) {
+        for (int r = 0; r < n_rounds; ++r)
+            for (uint64_t t = 0; t < n_tiles; ++t) items.push_back(Item{t * ctx->tile, tile_nt(t), r});
+    } else {
+        for (uint64_t t = 0; t < n_tiles; ++t)
+            for (int r = 0; r < n_rounds; ++r) items.push_back(Item{t * ctx->tile, tile_nt(t), r});
+    }
+    const int n_items = (int)items.size();
+    // Was this batch's first item prepared while the previous batch was in its last pair stage (see the end of this function)?
     const bool use_pre = ctx->pre_ready && slots[0] == ctx->pre_slot && ctx->slots[slots[0]].gen == ctx->pre_gen && ctx->n_pairs == ctx->pre_n &&
-                         ctx->n_pairs <= ctx->tile && (ctx->item_base & 1) == ctx->pre_b;
-    ctx->pre_ready = ctx->pre_launched = false;            // the rounds below reuse both sets of chain records
+                         items[0].nt == ctx->pre_nt && (ctx->item_base & 1) == ctx->pre_b;
+    ctx->pre_ready = ctx->pre_launched = false;            // the items below reuse both sets of chain records
     if (use_pre) ++ctx->launches[7];
     const ReadsDev rd_cur = current_reads(ctx);
-    int item = 0;
-    for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
-        const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        for (int r = 0; r < n_rounds; ++r, ++item) {
-            const int b = (ctx->item_base + item) & 1;
-            const Slot &sl = ctx->slots[slots[r]];
-            const KCore core = make_core(ctx, sl);
-            const RoundBufs rb = round_bufs(ctx, b);
-            // Seeds and chains of round r depend on the reads and the contig only; the flags merely skip pairs that are retired.
-            // While the pair stage of round r - 1 is still writing A[r & 1], this round's seeding reads the flags from before
-            // round r - 1 (a superset: pairs retired by round r - 1 get chains nobody looks at).
-            const uint8_t *act_prep = (r == 0) ? A[0] : A[(r - 1) & 1];
-            // CM_CHAIN_EXACT=1 (diagnostic): the chain kernels wait for the pair stage of round r - 1 and use its output flags
-            // A[r & 1], i.e. skip what it retired (23 % / 47 % of the pairs in rounds 2 / 3 of the hg38-like bench: chain kernels
-            // 8.4 -> 6.7 ms per step).  Measured slower overall (25.1 vs 24.0 ms): the wait removes what overlap the chain
-            // kernels had with the tail of that pair stage.
-            const uint8_t *act_chain = A[r & 1];
-            if (!(use_pre && item == 0)) {                                    // else: set b holds this round's chains, ev_prep[b] is recorded
-                if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
-                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
-                    ctx->pair_pending[b] = false;
-                }
-                if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return bail(rc);
-                static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
-                if (exact_flags && r > 0 && ctx->pair_pending[b ^ 1]) {       // item - 1 = the same tile's round r - 1
-                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
-                    ctx->pair_pending[b ^ 1] = false;
-                }
-                if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, exact_flags ? act_chain : act_prep, rb))) return bail(rc);
-                HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
+    for (int i = 0; i < n_items; ++i) {
+        const uint64_t p0 = items[i].p0;
+        const uint32_t nt = items[i].nt;
+        const int r = items[i].r, b = (ctx->item_base + i) & 1;
+        const Slot &sl = ctx->slots[slots[r]];
+        const KCore core = make_core(ctx, sl);
+        const RoundBufs rb = round_bufs(ctx, b);
+        // Seeds and chains of round r depend on the reads and the contig only; the flags merely skip pairs that are retired.
+        // Round-major: A[r & 1], what the pair stage of (tile, r - 1) wrote -- item i - n_tiles, complete before item i - 2, for
+        // which this item waits anyway (it reuses its chain records).  One tile: the pair stage of round r - 1 is still writing
+        // A[r & 1], so the flags from before it (pairs it retires get chains nobody looks at).
+        const uint8_t *act_prep = round_major ? A[r & 1] : ((r == 0) ? A[0] : A[(r - 1) & 1]);
+        if (!(use_pre && i == 0)) {                                       // else: set b holds this item's chains, ev_prep[b] is recorded
+            if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+                ctx->pair_pending[b] = false;
             }
-            const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
-            if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return bail(rc);
-            static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: rounds back to back
-            if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+            if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return bail(rc);
+            // CM_CHAIN_EXACT=1 (diagnostic, one tile): the chain kernels wait for the pair stage of round r - 1 and use its output
+            // flags (chain kernels 8.4 -> 6.7 ms per step, step 24.0 -> 25.1 ms: the wait costs more than the work it saves)
+            static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
+            const bool wait_exact = exact_flags && !round_major && r > 0;
+            if (wait_exact && ctx->pair_pending[b ^ 1]) {                 // item - 1 = the same tile's round r - 1
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
+                ctx->pair_pending[b ^ 1] = false;
+            }
+            if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, wait_exact ? A[r & 1] : act_prep, rb))) return bail(rc);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         }
+        const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
+        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return bail(rc);
+        static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
+        if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
     }
-    ctx->item_base = (ctx->item_base + item) & 1;
-    // Cross-batch prefetch.  A batch's first round cannot hide behind one of its own pair stages, and its last pair stage has no
-    // later round of its own to cover.  So when this call ends the batch and the next one is already staged (cm_reads_stage),
-    // that batch's first round against slots[0] is seeded and chained now, from the staging buffers (every pair of a fresh batch
-    // is active), into the set of chain records the running pair stage does not read.  cm_reads_swap keeps the result;
-    // the next cm_map_rounds uses it if it starts with the same slot, still holding the same contig.  Conditions: one tile, and
-    // the staged batch fits the workspace as it is sized now (nothing may be reallocated under the kernels in flight).
+    ctx->item_base = (ctx->item_base + n_items) & 1;
+    // Cross-batch prefetch.  A batch's first item cannot hide behind one of its own pair stages, and its last pair stage has no
+    // later item of its own to cover.  So when this call ends the batch and the next one is already staged (cm_reads_stage),
+    // that batch's first item (first tile, slots[0]) is seeded and chained now, from the staging buffers (every pair of a fresh
+    // batch is active), into the set of chain records the running pair stage does not read.  cm_reads_swap keeps the result;
+    // the next cm_map_rounds uses it if it starts with the same slot, still holding the same contig.  Condition: the staged
+    // batch fits the workspace as it is sized now (nothing may be reallocated under the kernels in flight).
     static const bool prefetch_on = !(getenv("CM_PREFETCH") && getenv("CM_PREFETCH")[0] == '0');
-    if (prefetch_on && last_is_final && ctx->staged && ctx->st_n_pairs <= ctx->n_pairs && ctx->n_pairs <= ctx->tile && ctx->st_max_len <= ctx->max_len) {
+    if (prefetch_on && last_is_final && ctx->staged && ctx->st_n_pairs <= ctx->n_pairs && ctx->st_max_len <= ctx->max_len) {
         const int b = ctx->item_base;
         const Slot &sl = ctx->slots[slots[0]];
         const KCore core = make_core(ctx, sl);
-        const uint32_t nt = (uint32_t)ctx->st_n_pairs;
+        const uint32_t nt = (uint32_t)(ctx->st_n_pairs < ctx->tile ? ctx->st_n_pairs : ctx->tile);     // = that batch's first tile (prepare_resident)
         if (ctx->ones_cap < ctx->st_n_pairs) {
             HIPCHK(ctx, ensure(ctx, ctx->d_ones, ctx->n_pairs));
             HIPCHK(ctx, hipMemsetAsync(ctx->d_ones, 1, ctx->n_pairs, ctx->stream));
@@ -2065,6 +2082,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
         ctx->pre_slot = slots[0];
         ctx->pre_gen = sl.gen;
         ctx->pre_b = b;
+        ctx->pre_nt = nt;
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p));

@@ -206,9 +206,11 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round);
  * Results are those of n_rounds cm_map_round calls.  What differs is the schedule: seeds and chains of a round depend on the
  * reads and the contig only (the carried MatchedRead enters in the pair stage), so round r + 1 is seeded and chained on the
  * main streams while the pair stage of round r still runs on a second pair of streams; chain buffers and active flags are
- * double-buffered.  Asynchronous like cm_map_round.
+ * double-buffered.  Asynchronous like cm_map_round.  A batch of more than 2^20 pairs is mapped in tiles, walked round by round
+ * (every tile through round r, then every tile through round r + 1), so a tile's seeding sees the flags its previous pair stage
+ * wrote and only pairs still active are seeded and chained.
  * Across batches: when last_is_final is set and a batch is staged (cm_reads_stage) that fits the workspace of the resident
- * one, its first round against slots[0] is seeded and chained under this batch's last pair stage; after cm_reads_swap the next
+ * one, its first tile's first round against slots[0] is seeded and chained under this batch's last pair stage; after cm_reads_swap the next
  * cm_map_rounds takes that work over if its slots[0] is the same slot, still holding the same contig and annotation
  * (otherwise it is discarded and redone: results never depend on it). */
 int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final);

@@ -582,11 +582,15 @@ def test_extension_memo_limit_is_reported(ds_tiny, tmp_path):
     hp.close()
 
 
-def test_cross_batch_prefetch_is_used_and_discarded_correctly(ds_tiny2r, ds_dirty):
-    """cm_map_rounds seeds / chains the staged batch's first round under the resident batch's last pair stage.  Every batch
-    equals the oracle whether that work is taken over (same first slot, same contig: launches[7] counts it) or has to be
-    discarded (slot reloaded in between, another first slot, a call that is not the batch's last, a staged batch that does
-    not fit the resident workspace)."""
+@pytest.mark.parametrize("tile", [None, "300"])
+def test_cross_batch_prefetch_is_used_and_discarded_correctly(ds_tiny2r, ds_dirty, monkeypatch, tile):
+    """cm_map_rounds seeds / chains the staged batch's first item (first tile, first round) under the resident batch's last pair
+    stage.  Every batch equals the oracle whether that work is taken over (same first slot, same contig: launches[7] counts it)
+    or has to be discarded (slot reloaded in between, another first slot, a call that is not the batch's last, a staged batch
+    that does not fit the resident workspace).  tile = 300: two tiles per 600-pair batch, walked round by round (a tile's
+    seeding then uses the flags its previous pair stage wrote)."""
+    if tile:
+        monkeypatch.setenv("CM_TILE_PAIRS", tile)
     ds = ds_tiny2r
     P = cl.default_params(kmer=ds.kmer)
     hp = cl.HotPath(P)

@@ -82,6 +82,13 @@ for k in range(n_sets):
         if not ((cat0 == cat1).all() and (act0 == act1).all() and st0.tobytes() == st1.tobytes()):
             print("MISMATCH", seed, preset, mix, kw, read_len, "round", ci, conftest.first_diff(st0, st1), flush=True)
             sys.exit(1)
+    if GPU:          # and all rounds in one call (pipelined; several tiles per batch are walked round-major: CM_TILE_PAIRS)
+        hp.reset()
+        hp.map_rounds(list(range(ds.hi.n_contigs)))
+        st2, cat2, act2 = hp.download()
+        if not ((cat0 == cat2).all() and (act0 == act2).all() and st0.tobytes() == st2.tobytes()):
+            print("MISMATCH (map_rounds)", seed, preset, mix, kw, read_len, conftest.first_diff(st0, st2), flush=True)
+            sys.exit(1)
     print(f"seed {seed} {preset}{' dirty' if dirty else ''} mix {mix} {kw} len {read_len}: ok, types {np.bincount(st0['type'], minlength=14).tolist()} ({time.time() - t:.0f}s)", flush=True)
     if hp is not None:
         hp.close()

@@ -18,6 +18,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -917,9 +919,12 @@ struct Fail {
 
 }  // namespace
 
-extern "C" int cm_circ_call(const cm_params *P, int32_t window_size, uint32_t n_contigs, const cm_index_view *contigs, const cm_annot_view *annots,
-                            const cm_chr_info *chrs, uint32_t n_chr, const cm_fastq_batch *sorted, const char *candidates_path,
-                            const char *report_path, cm_circ_stats *stats) {
+// ProcessCirc::do_process over the sorted remain pairs.  Pairs are independent of one another (the per-gene regional tables are a
+// cache, dropped once the sorted input has moved past the gene), so runs of pairs on one contig are cut into chunks that
+// worker threads take in turn, each with a Caller of its own; rows and calls are put together in chunk order, i.e. input order.
+static int circ_call_mt(const cm_params *P, int32_t window_size, uint32_t n_contigs, const cm_index_view *contigs, const cm_annot_view *annots,
+                        const cm_chr_info *chrs, uint32_t n_chr, const cm_fastq_batch *sorted, const char *candidates_path,
+                        const char *report_path, cm_circ_stats *stats, int n_threads) {
     if (!P || !contigs || !annots || !chrs || !sorted || !candidates_path || !report_path) return CM_EINVAL;
     const int ws = window_size > 0 ? window_size : 8;
     if (ws > 12) return CM_EINVAL;
@@ -928,38 +933,66 @@ extern "C" int cm_circ_call(const cm_params *P, int32_t window_size, uint32_t n_
     if (!fc) return CM_EINVAL;
     const uint64_t n = sorted->reads.n_pairs;
     const cm_mapped_read *states = sorted->prior;
-    std::vector<Call> calls;
-    uint64_t n_rows = 0;
-    Caller *cur = nullptr;
-    int cur_contig = -1;
-    int rc = CM_OK;
-    auto flush = [&]() {
-        if (!cur) return;
-        if (cur->err_) rc = CM_ELIMIT;
-        fwrite(cur->candidates.data(), 1, cur->candidates.size(), fc);
-        n_rows += (uint64_t)std::count(cur->candidates.begin(), cur->candidates.end(), '\n');
-        calls.insert(calls.end(), cur->calls.begin(), cur->calls.end());
-        delete cur;
-        cur = nullptr;
-    };
-    std::vector<uint8_t> rc1, rc2;
+    // eligible pairs, in input order; a chunk = consecutive eligible pairs of one contig (load_genome + refresh_hash_table_list
+    // happen at contig changes in the reference)
+    std::vector<uint64_t> todo;
     for (uint64_t i = 0; i < n && states; ++i) {
         const cm_mapped_read &st = states[i];
         if (st.type != CM_CHIBSJ && st.type != CM_CHI2BSJ) continue;
         if (st.contig_num < 0 || (uint32_t)st.contig_num >= n_contigs || st.chr_id < 0 || (uint32_t)st.chr_id >= n_chr) continue;
-        if (st.contig_num != cur_contig) {                          // load_genome + refresh_hash_table_list
-            flush();
-            cur_contig = st.contig_num;
-            cur = new Caller(*P, contigs[cur_contig], annots[cur_contig], ws, chrs);
-        }
-        const uint8_t *p1 = sorted->reads.seq1 + sorted->reads.off1[i], *p2 = sorted->reads.seq2 + sorted->reads.off2[i];
-        const uint32_t l1 = (uint32_t)(sorted->reads.off1[i + 1] - sorted->reads.off1[i]), l2 = (uint32_t)(sorted->reads.off2[i + 1] - sorted->reads.off2[i]);
-        reverse_complement(p1, l1, rc1);
-        reverse_complement(p2, l2, rc2);
-        const Seq fwd[2] = {Seq{p1, l1}, Seq{p2, l2}}, rev[2] = {Seq{rc1.data(), l1}, Seq{rc2.data(), l2}};
-        cur->process(fwd, rev, st, chrs[st.chr_id].start_pos, i, sorted->names1 + sorted->name_off1[i]);
+        todo.push_back(i);
     }
-    flush();
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("CM_CIRC_THREADS")) T = atoi(e);
+    T = T < 1 ? 1 : (T > 64 ? 64 : T);
+    const size_t chunk_len = std::max<size_t>(256, todo.size() / (size_t)(T * 8) + 1);
+    struct Chunk { size_t a, b; std::string rows; std::vector<Call> calls; int err = 0; };
+    std::vector<Chunk> chunks;
+    for (size_t a = 0; a < todo.size();) {
+        size_t b = a;
+        const int con = states[todo[a]].contig_num;
+        while (b < todo.size() && b - a < chunk_len && states[todo[b]].contig_num == con) ++b;
+        chunks.push_back(Chunk{a, b, {}, {}, 0});
+        a = b;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        std::vector<uint8_t> rc1, rc2;
+        for (size_t c = next.fetch_add(1); c < chunks.size(); c = next.fetch_add(1)) {
+            Chunk &ck = chunks[c];
+            const int con = states[todo[ck.a]].contig_num;
+            Caller cur(*P, contigs[con], annots[con], ws, chrs);
+            for (size_t x = ck.a; x < ck.b; ++x) {
+                const uint64_t i = todo[x];
+                const cm_mapped_read &st = states[i];
+                const uint8_t *p1 = sorted->reads.seq1 + sorted->reads.off1[i], *p2 = sorted->reads.seq2 + sorted->reads.off2[i];
+                const uint32_t l1 = (uint32_t)(sorted->reads.off1[i + 1] - sorted->reads.off1[i]), l2 = (uint32_t)(sorted->reads.off2[i + 1] - sorted->reads.off2[i]);
+                reverse_complement(p1, l1, rc1);
+                reverse_complement(p2, l2, rc2);
+                const Seq fwd[2] = {Seq{p1, l1}, Seq{p2, l2}}, rev[2] = {Seq{rc1.data(), l1}, Seq{rc2.data(), l2}};
+                cur.process(fwd, rev, st, chrs[st.chr_id].start_pos, i, sorted->names1 + sorted->name_off1[i]);
+            }
+            ck.rows.swap(cur.candidates);
+            ck.calls.swap(cur.calls);
+            ck.err = cur.err_;
+        }
+    };
+    {
+        const int nt = (int)std::min<size_t>((size_t)T, std::max<size_t>(chunks.size(), 1));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
+    std::vector<Call> calls;
+    uint64_t n_rows = 0;
+    int rc = CM_OK;
+    for (Chunk &ck : chunks) {
+        if (ck.err) rc = CM_ELIMIT;
+        fwrite(ck.rows.data(), 1, ck.rows.size(), fc);
+        n_rows += (uint64_t)std::count(ck.rows.begin(), ck.rows.end(), '\n');
+        calls.insert(calls.end(), ck.calls.begin(), ck.calls.end());
+    }
     fclose(fc);
     std::vector<cm_circ_res> res(calls.size());
     for (size_t i = 0; i < calls.size(); ++i) {
@@ -977,6 +1010,12 @@ extern "C" int cm_circ_call(const cm_params *P, int32_t window_size, uint32_t n_
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
+}
+
+extern "C" int cm_circ_call(const cm_params *P, int32_t window_size, uint32_t n_contigs, const cm_index_view *contigs, const cm_annot_view *annots,
+                            const cm_chr_info *chrs, uint32_t n_chr, const cm_fastq_batch *sorted, const char *candidates_path,
+                            const char *report_path, cm_circ_stats *stats) {
+    return circ_call_mt(P, window_size, n_contigs, contigs, annots, chrs, n_chr, sorted, candidates_path, report_path, stats, 0);
 }
 
 extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *err, uint64_t err_cap) {
@@ -1041,7 +1080,8 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
     cm_fastq_batch b;
     S2_TRY(cm_fastq_next(fq, ~0ull >> 2, &b), "cm_fastq_next");
     const std::string cand = out + ".candidates.pam", rep = out + ".circ_report";
-    rc = cm_circ_call(&P, a->window_size, (uint32_t)views.size(), views.data(), annots.data(), chrs, n_chr, &b, cand.c_str(), rep.c_str(), stats);
+    rc = circ_call_mt(&P, a->window_size, (uint32_t)views.size(), views.data(), annots.data(), chrs, n_chr, &b, cand.c_str(), rep.c_str(), stats,
+                      a->n_threads);
     if (rc != CM_OK) rc = fail(rc, "cm_circ_call failed (%d)", rc);
     cleanup();
     return rc;

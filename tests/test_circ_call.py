@@ -109,3 +109,19 @@ def test_stage2_empty_and_unannotated(built, tmp_path):
     stt = cl.circ_call(P, hi, d.chr_table, b, prefix + ".candidates.pam", prefix + ".circ_report")
     assert stt.pairs == 1 and stt.candidate_rows == 0 and open(prefix + ".circ_report").read() == ""
     rd.close()
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "13"])
+def test_stage2_does_not_depend_on_the_thread_count(built, tmp_path, monkeypatch, threads):
+    """cm_circ_call cuts the sorted pairs into chunks that worker threads take in turn (a Caller and a table cache each); rows and
+    calls are assembled in input order, so the files are the same bytes for any number of threads (and equal the oracle's)."""
+    monkeypatch.setenv("CM_CIRC_THREADS", threads)
+    d, gtf, (hi, ohi), P, prefix, r1, r2 = _case(tmp_path, "tiny2r", 4000, 23)
+    s1, s2 = cl.sort_remain(r1), cl.sort_remain(r2)
+    want_c, want_r = oracle_stage2(tmp_path, ohi, d, P, gnu_sort(r1), gnu_sort(r2))
+    rd = cl.FastqReader(s1, s2, d.chr_table, P.max_ed)
+    b = rd.next_batch(1 << 30)
+    cl.circ_call(P, hi, d.chr_table, b, prefix + ".candidates.pam", prefix + ".circ_report")
+    rd.close()
+    assert open(prefix + ".candidates.pam", "rb").read() == want_c and open(prefix + ".circ_report", "rb").read() == want_r
+    assert want_c.count(b"\n") > 500            # more rows than one chunk holds: several chunks per contig

@@ -425,7 +425,8 @@ int cm_circ_report(const cm_circ_res *res, uint64_t n, const char *report_path);
  * rescue_overlapping_bsj :1488-1552) over records that are already in the order of the sorted remain files: `sorted` is one
  * batch from cm_fastq_next on <out>_<R>_remain_R{1,2}.fastq.srt (its `prior` = the MatchedRead each pair carries in its header).
  * Writes <out>.candidates.pam rows (print_split_mapping :1670-1708 + type) to candidates_path and the <out>.circ_report rows
- * (report_events) to report_path.  window_size 0 = 8 (circ_detect, src/circminer.cpp:347-352). */
+ * (report_events) to report_path.  window_size 0 = 8 (circ_detect, src/circminer.cpp:347-352).  Pairs are called on all host
+ * cores (CM_CIRC_THREADS overrides; cm_circ_run uses its n_threads); the files do not depend on the number of threads. */
 typedef struct cm_circ_stats {
     uint64_t pairs, candidate_rows, calls;
     double seconds;

@@ -18,6 +18,9 @@
 #include <stdint.h>
 
 #include "circminer_hot.h"
+#if defined(CM_STAGE2_HOST)
+#include <vector>
+#endif
 
 #if defined(__HIPCC__)
 #define CM_HD __host__ __device__
@@ -1220,34 +1223,42 @@ CM_HD inline int local_alignment_side(const Core &c, const DpMem &sm, const SV &
 inline int local_alignment_sc_edit(const Core &c, const LBuf &s, int n, const LBuf &t, int m, int &sc_len, int &indel, int &align_score) {
     const int w = c.P.band, BIG = DPTINF;
     const bool banded = !(w < 0 || n <= 2 * w || m <= w);
-    const int W = m + 1;
-    int *dp = new int[(size_t)(n + 1) * (size_t)W];
-    auto in_band = [&](int i, int j) { return !banded || (i - j <= w && j - i <= w); };
-    for (int i = 0; i <= n; ++i)
-        for (int j = 0; j <= m; ++j) {
+    // Banded: only the cells with |i - j| <= w are ever finite (everything else is BIG in the reference's matrix), so only they are
+    // kept: row i holds columns i - w .. i + w at slots 0 .. 2w.  Not banded (a few rows or columns): the whole matrix.
+    const int W = banded ? 2 * w + 1 : m + 1;
+    static thread_local std::vector<int> cells;
+    cells.resize((size_t)(n + 1) * (size_t)W);
+    int *dp = cells.data();
+    auto at = [&](int i, int j) -> int {                       // dp[i][j]; BIG outside the band
+        if (!banded) return dp[(size_t)i * W + j];
+        const int k = j - i + w;
+        return (k < 0 || k >= W) ? BIG : dp[(size_t)i * W + k];
+    };
+    for (int i = 0; i <= n; ++i) {
+        const int j0 = banded ? cmax(0, i - w) : 0, j1 = banded ? cmin(m, i + w) : m;
+        for (int j = j0; j <= j1; ++j) {
             int v;
-            if (!in_band(i, j)) v = BIG;
-            else if (i == 0) v = j;
+            if (i == 0) v = j;
             else if (j == 0) v = i;
             else {
-                const int d = dp[(size_t)(i - 1) * W + (j - 1)] + ldiff(s.get(i - 1), t.get(j - 1));
-                const int u = dp[(size_t)(i - 1) * W + j] + 1, l = dp[(size_t)i * W + (j - 1)] + 1;
+                const int d = at(i - 1, j - 1) + ldiff(s.get(i - 1), t.get(j - 1));
+                const int u = at(i - 1, j) + 1, l = at(i, j - 1) + 1;
                 v = cmin(d, cmin(u, l));
                 if (v > BIG) v = BIG;
             }
-            dp[(size_t)i * W + j] = v;
+            dp[(size_t)i * W + (banded ? j - i + w : j)] = v;
         }
+    }
     const int max_sclen = cmin(c.P.max_sc, m);
     Cand best{c.P.max_ed + 1, c.P.max_sc + 1, w + 1, -(c.P.max_sc + 1) - 2 * (c.P.max_ed + 1)};
     for (int j = m; j >= m - max_sclen; --j)
         for (int i = cmax(0, j - w); i <= cmin(j + w, n); ++i) {
-            const int v = dp[(size_t)i * W + j];
+            const int v = at(i, j);
             if (v <= c.P.max_ed) {
                 const Cand x{v, m - j, j - i, -(m - j) - 2 * v};
                 if (cand_less(x, best)) best = x;
             }
         }
-    delete[] dp;
     if (m <= c.P.max_ed) {
         const Cand x{m, 0, 0, -2 * m};
         if (cand_less(x, best)) best = x;

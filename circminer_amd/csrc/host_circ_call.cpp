@@ -22,6 +22,19 @@
 #include <thread>
 #include <vector>
 
+#if defined(CM_S2_PROF)      // diagnostic build only: where one_split / two_splits spend their time (tests/diag/s2_prof.py)
+#include <atomic>
+static std::atomic<unsigned long long> g_s2_ns[8];
+struct S2Tm {
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit S2Tm(int kk) : k(kk), t0(std::chrono::steady_clock::now()) {}
+    ~S2Tm() { g_s2_ns[k] += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#define S2_TIME(k) S2Tm s2tm_##k(k)
+#else
+#define S2_TIME(k) ((void)0)
+#endif
 #include "circminer_hot.h"
 
 #define CM_STAGE2_HOST 1
@@ -103,6 +116,7 @@ public:
 
     // call_circ (src/process_circ.cpp:334-358); st in chromosome coordinates, shift = start of its chromosome in the contig
     void process(const Seq fwd[2], const Seq rc[2], const cm_mapped_read &st, uint32_t shift, uint64_t rec, const char *name) {
+        S2_TIME(5);
         rem_ = full_ = s1_ = s2_ = Seq{};
         rec_ = rec;
         name_ = name;
@@ -171,6 +185,7 @@ private:
     const Table &table_for(uint32_t gene) {
         auto it = tables_.find(gene);
         if (it != tables_.end()) return it->second;
+        S2_TIME(0);
         Table t;
         const uint32_t gs = av_.gene_start[gene], ge = av_.gene_end[gene];
         std::string g;
@@ -215,6 +230,7 @@ private:
     // (as the reference does).  Improvements are logged in order and replayed best score first, at most max_chain_len per score.
     struct Seed { const uint32_t *hit; uint32_t n; int32_t qpos; };
     void chains_of(uint32_t qs, uint32_t qe, const Table &tab, const Seq &seq, uint32_t gene_start, std::vector<WideChain> &out) {
+        S2_TIME(1);
         out.clear();
         const int span = (int)qe - (int)qs + 1;
         if (span < ws_ || !tab.off) return;
@@ -467,6 +483,7 @@ private:
     // the read is cut after `cut` bases: the left part must end at end_bp walking left, the right part start at beg_bp walking
     // right, both along `tids`; the two bases at the cut are compared directly (split_realignment, 6-argument form, :1343-1392)
     int realign_at(uint32_t cut, uint32_t beg_bp, uint32_t end_bp, const Seq &s, const std::vector<uint32_t> &tids) {
+        S2_TIME(2);
         const int lim = P().max_ed;
         if (cut == 0 || cut >= s.n) return lim + 1;
         const int e_last = base_equals(end_bp, s.at(cut - 1)) ? 0 : 1, e_first = base_equals(beg_bp, s.at(cut)) ? 0 : 1;
@@ -615,6 +632,7 @@ private:
     }
     // single split: which of the mates is the split one, and in which read order its two pieces come (check_split_map, :892-921)
     int judge_single(k::MM &m1, k::MM &m2, k::MM &piece, bool r1_split, Breakpoint &bp) {
+        S2_TIME(4);
         k::MM &split = r1_split ? m1 : m2, &whole = r1_split ? m2 : m1;
         const int ed = k::mm_ed(split) + k::mm_ed(piece);
         const int v = (split.qspos < piece.qspos) ? judge_three(whole, split, piece, bp) : judge_three(whole, piece, split, bp);
@@ -784,6 +802,7 @@ private:
     }
     // exact coordinates of the unmapped part along one chain (find_exact_coord, :739-789); true when it ends up concordant
     bool place_piece(k::MM &m1, k::MM &m2, k::MM &piece, int dir, uint32_t qs, int todo, int rlen, const WideChain &c) {
+        S2_TIME(3);
         span_of_chain(c, qs, todo, dir, piece);
         const uint32_t q0 = qs - 1;
         k::overlap_to_spos(core_, m1);
@@ -1002,6 +1021,10 @@ static int circ_call_mt(const cm_params *P, int32_t window_size, uint32_t n_cont
     }
     const int rr = cm_circ_report(res.data(), res.size(), report_path);
     if (rr != CM_OK) return rr;
+#if defined(CM_S2_PROF)
+    fprintf(stderr, "[s2 prof] ms: table build %.1f, chains_of %.1f, realign_at %.1f (inside judge), place_piece %.1f, judge_single %.1f, process total %.1f\n",
+            g_s2_ns[0] / 1e6, g_s2_ns[1] / 1e6, g_s2_ns[2] / 1e6, g_s2_ns[3] / 1e6, g_s2_ns[4] / 1e6, g_s2_ns[5] / 1e6);
+#endif
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->pairs = n;

@@ -67,9 +67,13 @@ def _compare_all_rounds(d, gtf, P, n_pairs, streamed):
     return st1
 
 
-def test_hg38like_three_rounds(hg38):
+@pytest.mark.parametrize("tile", [None, "524288"])
+def test_hg38like_three_rounds(hg38, monkeypatch, tile):
     """configs[2]: k = 20, defaults, 1 M pairs through all three rounds; every pair's final state, active flag and
-    category equal to the oracle's."""
+    category equal to the oracle's.  tile = 524288: two tiles per batch, walked round by round as the bench's 2^21-pair batches
+    are (a tile's seeding uses the flags its previous pair stage wrote)."""
+    if tile:
+        monkeypatch.setenv("CM_TILE_PAIRS", tile)
     d, gtf = hg38
     st = _compare_all_rounds(d, gtf, cl.default_params(), N_PAIRS, streamed=True)
     m = d.src[:N_PAIRS] == 0

@@ -1085,7 +1085,7 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
     for (;;) {
         cm_index_view iv;
         int loaded = 0;
-        S2_TRY(cm_host_next_contig(idx, a->n_threads > 0 ? a->n_threads : 1, &iv, &loaded), "cm_host_next_contig");
+        S2_TRY(cm_host_next_contig_genome(idx, &iv, &loaded), "cm_host_next_contig_genome");      // the sequence only: stage 2 never probes the k-mer table
         if (!loaded) break;
         views.push_back(iv);
     }

@@ -361,7 +361,7 @@ int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kme
 // (pac2char_whole_contig, src/match_read.cpp:301-332) and the table in the flattened layout of
 // cm_index_view.  Returns CM_OK and *loaded = 1, or *loaded = 0 after the last contig.
 // The view (including its genome) is released with cm_host_free_loaded_contig.
-int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded) {
+static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded, bool genome_only) {
     if (!x || !out || !loaded) return CM_EINVAL;
     *loaded = 0;
     if (x->done) return CM_OK;
@@ -391,8 +391,10 @@ int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int
     }
     const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
     std::vector<uint32_t> hvs, cnts;
-    hvs.reserve(nbuckets);
-    cnts.reserve(nbuckets);
+    if (!genome_only) {
+        hvs.reserve(nbuckets);
+        cnts.reserve(nbuckets);
+    }
     std::vector<uint8_t> buf;
     uint64_t hv = 0, mem = 0;
     for (uint32_t i = 0; i < nbuckets;) {
@@ -417,8 +419,10 @@ int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int
             idx += (size_t)a;
             hv += d;
             if (hv >= nb) { free(g); return CM_EINVAL; }
-            hvs.push_back((uint32_t)hv);
-            cnts.push_back(cn);
+            if (!genome_only) {
+                hvs.push_back((uint32_t)hv);
+                cnts.push_back(cn);
+            }
             mem += (uint64_t)cn + 1;
             ++i;
         }
@@ -426,7 +430,19 @@ int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int
     const int kmer = x->window + x->checksum_len;
     const int contig_num = atoi(name) - 1;            // contigNum of the mapping loop, src/circminer.cpp:266-267
     int rc = CM_OK;
-    if (x->full) {
+    if (genome_only) {                                   // the table is stepped over, not decoded (stage 2 needs the sequence only)
+        if (x->full) {
+            uint32_t memsz = 0;
+            if (!get(f, memsz) || memsz != mem || fseeko(f, (off_t)memsz * (off_t)sizeof(Entry), SEEK_CUR) != 0) {
+                free(g);
+                return CM_EINVAL;
+            }
+        }
+        memset(out, 0, sizeof *out);
+        out->contig_num = contig_num;
+        out->ref_len = n;
+        out->genome = g;
+    } else if (x->full) {
         uint32_t memsz = 0;
         if (!get(f, memsz) || memsz != mem) {
             free(g);
@@ -484,6 +500,9 @@ int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int
     *loaded = 1;
     return CM_OK;
 }
+
+int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded) { return next_contig(x, n_threads, out, loaded, false); }
+int cm_host_next_contig_genome(cm_index_file *x, cm_index_view *out, int *loaded) { return next_contig(x, 1, out, loaded, true); }
 
 void cm_host_free_loaded_contig(cm_index_view *iv) {
     if (!iv) return;

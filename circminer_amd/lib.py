@@ -202,6 +202,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_host_write_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int, C.c_int]),
         "cm_host_open_index": (C.c_int, [C.c_char_p, pp(vp), pp(C.c_int32), pp(C.c_int32), pp(C.c_uint32)]),
         "cm_host_next_contig": (C.c_int, [vp, C.c_int, pp(IndexView), pp(C.c_int)]),
+        "cm_host_next_contig_genome": (C.c_int, [vp, pp(IndexView), pp(C.c_int)]),
         "cm_host_free_loaded_contig": (None, [pp(IndexView)]),
         "cm_host_close_index": (None, [vp]),
         "cm_fastq_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, C.c_int32, pp(vp)]),
@@ -237,7 +238,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
-                    "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_free_loaded_contig",
+                    "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_next_contig_genome", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
                     "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_flush", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
@@ -329,9 +330,10 @@ class IndexFile:
     """Iterates the packed contigs of a stock index file as IndexView objects (one mapping round each).
     The view handed out is valid until the next iteration step / close()."""
 
-    def __init__(self, path: str, n_threads: int = 8):
+    def __init__(self, path: str, n_threads: int = 8, genome_only: bool = False):
         self.L = load()
         self.h = C.c_void_p()
+        self.genome_only = genome_only          # cm_host_next_contig_genome: the k-mer tables are stepped over (what stage 2 does)
         kmer, full, nrec = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
         rc = self.L.cm_host_open_index(path.encode(), C.byref(self.h), C.byref(kmer), C.byref(full), C.byref(nrec))
         if rc != 0:
@@ -350,7 +352,10 @@ class IndexFile:
     def __next__(self) -> IndexView:
         self._drop()
         iv, loaded = IndexView(), C.c_int(0)
-        rc = self.L.cm_host_next_contig(self.h, self.n_threads, C.byref(iv), C.byref(loaded))
+        if self.genome_only:
+            rc = self.L.cm_host_next_contig_genome(self.h, C.byref(iv), C.byref(loaded))
+        else:
+            rc = self.L.cm_host_next_contig(self.h, self.n_threads, C.byref(iv), C.byref(loaded))
         if rc != 0:
             raise RuntimeError(f"cm_host_next_contig failed ({rc})")
         if not loaded.value:

@@ -327,6 +327,9 @@ typedef struct cm_index_file cm_index_file;
 int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kmer, int32_t *is_full,
                        uint32_t *n_records);
 int cm_host_next_contig(cm_index_file *f, int n_threads, cm_index_view *out, int *loaded);
+/* The same record with its k-mer table stepped over: only genome / ref_len / contig_num of *out are set (ProcessCirc::load_genome,
+ * src/process_circ.cpp:1659-1680: loadCompressedRefGenome, the sequence alone); stage 2 uses this. */
+int cm_host_next_contig_genome(cm_index_file *f, cm_index_view *out, int *loaded);
 void cm_host_free_loaded_contig(cm_index_view *iv);
 void cm_host_close_index(cm_index_file *f);
 

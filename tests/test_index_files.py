@@ -264,6 +264,25 @@ def test_compact_index_rebuilds_the_same_table(L, genome_files):
         assert x["genome"] == y["genome"] and (x["off"] == y["off"]).all() and (x["cs"] == y["cs"]).all() and (x["pos"] == y["pos"]).all()
 
 
+def test_genome_only_records(L, genome_files):
+    """cm_host_next_contig_genome (what stage 2 loads: ProcessCirc::load_genome reads the sequence alone) steps over the k-mer
+    table of every record, full or compact index, and hands out the same genomes in the same order."""
+    full, compact = str(genome_files["dir"] / "fg.index"), str(genome_files["dir"] / "cg.index")
+    assert L.cm_host_write_index(genome_files["packed"].encode(), full.encode(), 20, 0, 2) == 0
+    assert L.cm_host_write_index(genome_files["packed"].encode(), compact.encode(), 20, 1, 2) == 0
+    want = _load_all(L, full)[3]
+    for path in (full, compact):
+        got = []
+        f = cl.IndexFile(path, genome_only=True)
+        for iv in f:
+            assert not iv.bucket_off and not iv.checksum and not iv.pos and iv.n_entries == 0
+            got.append((iv.contig_num, C.string_at(iv.genome, iv.ref_len)))
+        f.close()
+        assert len(got) == len(want) >= 2
+        for (cn, g), w in zip(got, want):
+            assert g == w["genome"] and cn == w["contig"]
+
+
 def test_reader_rejects_garbage(L, tmp_path):
     p = tmp_path / "bad.index"
     p.write_bytes(b"\x07\x0e\x06" + b"\0" * 64)

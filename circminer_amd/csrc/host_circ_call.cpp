@@ -1069,6 +1069,12 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
             return rc;                                         \
         }                                                      \
     } while (0)
+    const bool trace = getenv("CM_CIRC_TRACE") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[circ] %s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count());
+        tp = std::chrono::steady_clock::now();
+    };
     // ProcessCirc ctor: sort both remain files (sort_fq); do_process: index info, packed genome, GTF
     char r1[4096], r2[4096];
     snprintf(r1, sizeof r1, "%s_%d_remain_R1.fastq", out.c_str(), a->last_round);
@@ -1076,6 +1082,7 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
     const std::string s1 = std::string(r1) + ".srt", s2 = std::string(r2) + ".srt";
     S2_TRY(cm_sort_remain(r1, s1.c_str()), "cm_sort_remain (R1)");
     S2_TRY(cm_sort_remain(r2, s2.c_str()), "cm_sort_remain (R2)");
+    lap("sort remain files");
     S2_TRY(cm_host_read_index_info(a->index_info_path, &chrs, &n_chr), "cm_host_read_index_info");
     int32_t kmer = 0, full = 0;
     uint32_t n_rec = 0;
@@ -1089,6 +1096,7 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
         if (!loaded) break;
         views.push_back(iv);
     }
+    lap("genome from the index file");
     std::vector<uint32_t> clen;
     for (auto &v : views) clen.push_back(v.ref_len);
     annots.resize(views.size());
@@ -1099,14 +1107,18 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
         cleanup();
         return rc;
     }
+    lap("annotation");
     S2_TRY(cm_fastq_open(s1.c_str(), s2.c_str(), chrs, n_chr, P.max_ed, &fq), "cm_fastq_open (sorted remain files)");
     cm_fastq_batch b;
     S2_TRY(cm_fastq_next(fq, ~0ull >> 2, &b), "cm_fastq_next");
+    lap("parse sorted remain files");
     const std::string cand = out + ".candidates.pam", rep = out + ".circ_report";
     rc = circ_call_mt(&P, a->window_size, (uint32_t)views.size(), views.data(), annots.data(), chrs, n_chr, &b, cand.c_str(), rep.c_str(), stats,
                       a->n_threads);
     if (rc != CM_OK) rc = fail(rc, "cm_circ_call failed (%d)", rc);
+    lap("calling + report");
     cleanup();
+    lap("cleanup");
     return rc;
 #undef S2_TRY
 }

@@ -13,6 +13,7 @@
 // Deliberately defined where the reference has undefined behaviour: names shorter than 2 characters are not
 // inspected for the "/x" suffix, header lines with more than 23 tokens are treated like fresh reads.
 #include <unistd.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -463,7 +464,16 @@ int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_ou
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
     const int half = nt > 1 ? nt / 2 : 1;
     // ~ 2 x (read length + name) + 8 per record; the estimate only sizes the first read(), more is read on demand
-    const size_t hint = (size_t)std::min<uint64_t>(max_pairs, 1ull << 22) * 360 + (1u << 20);
+    size_t hint = (size_t)std::min<uint64_t>(max_pairs, 1ull << 22) * 360 + (1u << 20);
+    {   // never more than what is left of the larger file (a caller asking for "everything" must not cost a 1.5-GB buffer)
+        struct stat sa, sb;
+        if (f->s1.plain && f->s2.plain && fstat(fileno(f->s1.plain), &sa) == 0 && fstat(fileno(f->s2.plain), &sb) == 0) {
+            const uint64_t left1 = (uint64_t)sa.st_size > f->s1.file_pos ? (uint64_t)sa.st_size - f->s1.file_pos : 0;
+            const uint64_t left2 = (uint64_t)sb.st_size > f->s2.file_pos ? (uint64_t)sb.st_size - f->s2.file_pos : 0;
+            const uint64_t left = std::max(left1, left2) + (1u << 16);
+            if (left < hint) hint = (size_t)left;
+        }
+    }
     size_t a1 = 0, a2 = 0;
     const bool trace = getenv("CM_FASTQ_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -382,7 +383,23 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     if (nw && fread(packed.data(), 8, nw, f) != nw) return CM_EINVAL;
     uint8_t *g = (uint8_t *)malloc((size_t)n + 1);
     if (!g) return CM_ENOMEM;
-    for (uint32_t i = 0; i < n; ++i) g[i] = (uint8_t)"ACGTNNNN"[(packed[i / 21] >> (60 - 3 * (i % 21))) & 7u];
+    {   // 21 bases per 64-bit word, first base in the top bits; word ranges decoded side by side
+        auto decode = [&](uint32_t w0, uint32_t w1) {
+            for (uint32_t wd = w0; wd < w1; ++wd) {
+                const uint64_t x = packed[wd];
+                const uint32_t base = wd * 21u, cnt = n - base < 21u ? n - base : 21u;
+                for (uint32_t j = 0; j < cnt; ++j) g[base + j] = (uint8_t)"ACGTNNNN"[(x >> (60 - 3 * j)) & 7u];
+            }
+        };
+        int T = n_threads > 0 ? n_threads : 1;
+        if (genome_only) T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (nw < (1u << 20)) T = 1;
+        if (T > 32) T = 32;
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(decode, (uint32_t)((uint64_t)nw * t / T), (uint32_t)((uint64_t)nw * (t + 1) / T));
+        decode(0, (uint32_t)((uint64_t)nw / T));
+        for (auto &t : th) t.join();
+    }
     g[n] = 0;
     uint32_t nbuckets = 0;
     if (!get(f, nbuckets)) {

@@ -1080,8 +1080,14 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
     snprintf(r1, sizeof r1, "%s_%d_remain_R1.fastq", out.c_str(), a->last_round);
     snprintf(r2, sizeof r2, "%s_%d_remain_R2.fastq", out.c_str(), a->last_round);
     const std::string s1 = std::string(r1) + ".srt", s2 = std::string(r2) + ".srt";
-    S2_TRY(cm_sort_remain(r1, s1.c_str()), "cm_sort_remain (R1)");
-    S2_TRY(cm_sort_remain(r2, s2.c_str()), "cm_sort_remain (R2)");
+    {   // the two files are sorted side by side
+        int rc2 = CM_OK;
+        std::thread t2([&]() { rc2 = cm_sort_remain(r2, s2.c_str()); });
+        const int rc1 = cm_sort_remain(r1, s1.c_str());
+        t2.join();
+        S2_TRY(rc1, "cm_sort_remain (R1)");
+        S2_TRY(rc2, "cm_sort_remain (R2)");
+    }
     lap("sort remain files");
     S2_TRY(cm_host_read_index_info(a->index_info_path, &chrs, &n_chr), "cm_host_read_index_info");
     int32_t kmer = 0, full = 0;

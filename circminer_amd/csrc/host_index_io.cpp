@@ -489,7 +489,35 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(g);
             return ok ? CM_ENOMEM : CM_EINVAL;
         }
-        for (uint64_t h = 0; h < nb; ++h) boff[h + 1] += boff[h];
+        {   // inclusive prefix sum of the 4^14 bucket counts: per-thread blocks, block totals, then the offsets added back
+            const int T = std::max(1, std::min(n_threads, 32));
+            std::vector<uint64_t> tot((size_t)T + 1, 0);
+            auto blk = [&](int t, uint64_t &lo, uint64_t &hi) { lo = 1 + nb * (uint64_t)t / (uint64_t)T; hi = 1 + nb * (uint64_t)(t + 1) / (uint64_t)T; };
+            auto pass1 = [&](int t) {
+                uint64_t lo, hi, run = 0;
+                blk(t, lo, hi);
+                for (uint64_t h = lo; h < hi; ++h) {
+                    run += boff[h];
+                    boff[h] = (uint32_t)run;
+                }
+                tot[(size_t)t + 1] = run;
+            };
+            auto pass2 = [&](int t) {
+                uint64_t lo, hi;
+                blk(t, lo, hi);
+                const uint32_t add = (uint32_t)tot[(size_t)t];
+                if (add)
+                    for (uint64_t h = lo; h < hi; ++h) boff[h] += add;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(pass1, t);
+            pass1(0);
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) tot[(size_t)t + 1] += tot[(size_t)t];
+            th.clear();
+            for (int t = 1; t < T; ++t) th.emplace_back(pass2, t);
+            for (auto &x : th) x.join();
+        }
         cur = 0;
         for (size_t b = 0; b < hvs.size(); ++b) {
             const uint32_t c = (uint32_t)tab[cur].info, w = boff[hvs[b]];

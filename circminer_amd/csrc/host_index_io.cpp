@@ -30,6 +30,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -364,6 +365,12 @@ int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kme
 // The view (including its genome) is released with cm_host_free_loaded_contig.
 static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded, bool genome_only) {
     if (!x || !out || !loaded) return CM_EINVAL;
+    const bool trace = getenv("CM_INDEX_TRACE") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[index] %s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count());
+        tp = std::chrono::steady_clock::now();
+    };
     *loaded = 0;
     if (x->done) return CM_OK;
     FILE *f = x->f;
@@ -401,6 +408,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         for (auto &t : th) t.join();
     }
     g[n] = 0;
+    lap("sequence read + decoded");
     uint32_t nbuckets = 0;
     if (!get(f, nbuckets)) {
         free(g);
@@ -444,6 +452,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             ++i;
         }
     }
+    lap("bucket headers decoded");
     const int kmer = x->window + x->checksum_len;
     const int contig_num = atoi(name) - 1;            // contigNum of the mapping loop, src/circminer.cpp:266-267
     int rc = CM_OK;
@@ -470,15 +479,50 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(g);
             return CM_EINVAL;
         }
+        lap("table read");
         uint32_t *boff = (uint32_t *)calloc(nb + 1, sizeof(uint32_t));
         uint64_t total = 0, cur = 0;
         bool ok = boff != nullptr;
-        for (size_t b = 0; b < hvs.size() && ok; ++b) {
-            const int32_t c = tab[cur].info;
-            ok = c >= 0 && (uint32_t)c <= cnts[b];
-            boff[hvs[b] + 1] = ok ? (uint32_t)c : 0u;
-            total += ok ? (uint32_t)c : 0u;
-            cur += (uint64_t)cnts[b] + 1;
+        // the non-empty buckets in T ranges: where each range starts in the table (one serial pass over the counts), then the
+        // ranges side by side
+        const int TT = std::max(1, std::min(n_threads, 32));
+        std::vector<uint64_t> start((size_t)TT + 1, 0);
+        {
+            uint64_t run = 0;
+            int t = 0;
+            for (size_t b = 0; b < hvs.size(); ++b) {
+                while (t < TT && b == hvs.size() * (size_t)t / (size_t)TT) start[(size_t)t++] = run;
+                run += (uint64_t)cnts[b] + 1;
+            }
+            while (t <= TT) start[(size_t)t++] = run;
+        }
+        auto over_ranges = [&](auto &&body) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < TT; ++t) th.emplace_back(body, t);
+            body(0);
+            for (auto &x : th) x.join();
+        };
+        if (ok) {
+            std::vector<uint64_t> sum((size_t)TT, 0);
+            std::vector<uint8_t> bad((size_t)TT, 0);
+            over_ranges([&](int t) {
+                uint64_t c0 = start[(size_t)t], s = 0;
+                for (size_t b = hvs.size() * (size_t)t / (size_t)TT, e = hvs.size() * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
+                    const int32_t c = tab[c0].info;
+                    if (c < 0 || (uint32_t)c > cnts[b]) {
+                        bad[(size_t)t] = 1;
+                        return;
+                    }
+                    boff[hvs[b] + 1] = (uint32_t)c;
+                    s += (uint32_t)c;
+                    c0 += (uint64_t)cnts[b] + 1;
+                }
+                sum[(size_t)t] = s;
+            });
+            for (int t = 0; t < TT; ++t) {
+                total += sum[(size_t)t];
+                ok = ok && !bad[(size_t)t];
+            }
         }
         uint16_t *cs = (uint16_t *)malloc((total ? total : 1) * sizeof(uint16_t));
         uint32_t *ps = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
@@ -489,6 +533,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(g);
             return ok ? CM_ENOMEM : CM_EINVAL;
         }
+        lap("counts placed");
         {   // inclusive prefix sum of the 4^14 bucket counts: per-thread blocks, block totals, then the offsets added back
             const int T = std::max(1, std::min(n_threads, 32));
             std::vector<uint64_t> tot((size_t)T + 1, 0);
@@ -518,15 +563,19 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             for (int t = 1; t < T; ++t) th.emplace_back(pass2, t);
             for (auto &x : th) x.join();
         }
-        cur = 0;
-        for (size_t b = 0; b < hvs.size(); ++b) {
-            const uint32_t c = (uint32_t)tab[cur].info, w = boff[hvs[b]];
-            for (uint32_t e = 0; e < c; ++e) {
-                cs[w + e] = tab[cur + 1 + e].checksum;
-                ps[w + e] = (uint32_t)tab[cur + 1 + e].info;
+        over_ranges([&](int t) {
+            uint64_t c0 = start[(size_t)t];
+            for (size_t b = hvs.size() * (size_t)t / (size_t)TT, e = hvs.size() * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
+                const uint32_t c = (uint32_t)tab[c0].info, w = boff[hvs[b]];
+                for (uint32_t k = 0; k < c; ++k) {
+                    cs[w + k] = tab[c0 + 1 + k].checksum;
+                    ps[w + k] = (uint32_t)tab[c0 + 1 + k].info;
+                }
+                c0 += (uint64_t)cnts[b] + 1;
             }
-            cur += (uint64_t)cnts[b] + 1;
-        }
+        });
+        (void)cur;
+        lap("prefix sum + entries scattered");
         out->contig_num = contig_num;
         out->ref_len = n;
         out->genome = g;

@@ -15,6 +15,10 @@ int cm_load_annotation(cm_ctx *, int, const cm_annot_view *) { return CM_ENODEV;
 int cm_unload_contig(cm_ctx *, int) { return CM_ENODEV; }
 int cm_reads_upload(cm_ctx *, const cm_reads *, const cm_mapped_read *) { return CM_ENODEV; }
 int cm_map_round(cm_ctx *, int, int) { return CM_ENODEV; }
+int cm_map_rounds(cm_ctx *, const int *, int, int) { return CM_ENODEV; }
+int cm_reads_stage(cm_ctx *, const cm_reads *, const cm_mapped_read *) { return CM_ENODEV; }
+int cm_reads_swap(cm_ctx *) { return CM_ENODEV; }
+int cm_debug_lane_clk(cm_ctx *, unsigned long long *) { return CM_ENODEV; }
 int cm_sync(cm_ctx *) { return CM_ENODEV; }
 int cm_reads_reset(cm_ctx *) { return CM_ENODEV; }
 int cm_collect_active(cm_ctx *, uint64_t, uint64_t *, cm_mapped_read *, uint64_t *) { return CM_ENODEV; }
@@ -35,8 +39,8 @@ CPP
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -I "$ROOT/include" -I "$ROOT/circminer_amd/csrc" \
     "$OUT/asan_stubs.cpp" "$ROOT/circminer_amd/csrc/host_index.cpp" "$ROOT/circminer_amd/csrc/host_annot.cpp" \
     "$ROOT/circminer_amd/csrc/host_index_io.cpp" "$ROOT/circminer_amd/csrc/host_fastq.cpp" "$ROOT/circminer_amd/csrc/host_mapping.cpp" \
-    "$ROOT/circminer_amd/csrc/host_circ.cpp" -o "$OUT/libcmhost_asan.so" -lpthread -lz
+    "$ROOT/circminer_amd/csrc/host_circ.cpp" "$ROOT/circminer_amd/csrc/host_circ_call.cpp" -o "$OUT/libcmhost_asan.so" -lpthread -lz
 cd "$ROOT"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 CM_LIB="$OUT/libcmhost_asan.so" \
-    python -m pytest tests/test_index_files.py tests/test_fastq_io.py tests/test_host_builders.py tests/test_circ_stage2.py -x -q "$@"
+    python -m pytest tests/test_index_files.py tests/test_fastq_io.py tests/test_host_builders.py tests/test_circ_stage2.py tests/test_circ_call.py -x -q "$@"

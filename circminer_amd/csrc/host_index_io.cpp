@@ -31,6 +31,8 @@
 #include <string>
 #include <thread>
 #include <chrono>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -474,8 +476,12 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(g);
             return CM_EINVAL;
         }
-        std::vector<Entry> tab(memsz);
-        if (memsz && fread(tab.data(), sizeof(Entry), memsz, f) != memsz) {
+        std::unique_ptr<Entry[]> tab(new (std::nothrow) Entry[(size_t)memsz + 1]);      // not cleared: fread fills it
+        if (!tab) {
+            free(g);
+            return CM_ENOMEM;
+        }
+        if (memsz && fread(tab.get(), sizeof(Entry), memsz, f) != memsz) {
             free(g);
             return CM_EINVAL;
         }

@@ -22,31 +22,35 @@ KERNEL_EXPORTS = ['cm_create', 'cm_destroy', 'cm_last_error', 'cm_load_contig', 
 VARIANTS = (("k16", []), ("k24", ["-DCM_MAX_CHAIN_FRAGS=24"]))
 
 
-def needs_build() -> bool:
-    if not os.path.exists(OUT):
+def needs_build(out: str = OUT) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, tag: str = "", flags=()) -> str:
+    """tag / flags: a second library libcmhot_<tag>.so compiled with extra -D flags (test builds, e.g. a 2-entry extension
+    memo that sends many pairs through the re-run launch); the product library has neither."""
+    OUT = os.path.join(CSRC, f"libcmhot_{tag}.so") if tag else globals()["OUT"]
+    if not force and not needs_build(OUT):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("CM_EXTRA_FLAGS", "").split()
+    extra = os.environ.get("CM_EXTRA_FLAGS", "").split() + list(flags)
+    sfx = ("_" + tag) if tag else ""
     objs = []
     jobs = []
     for s in SOURCES:
         base = [hipcc, "-c", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *extra, "-I", INC, "-I", CSRC]
         if s.endswith(".hip"):
             arch = ["--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] if verbose else ["--offload-arch=gfx950"]
-            for tag, flags in VARIANTS:
-                o = os.path.join(CSRC, s.rsplit(".", 1)[0] + "_" + tag + ".o")
-                ren = [f"-D{n}={n}_{tag}" for n in KERNEL_EXPORTS + ["cmc"]]      # cmc: the kernel bodies' namespace (their structs differ in size)
-                jobs.append((s + " [" + tag + "]", [base[0]] + arch + base[1:] + flags + ren + [os.path.join(CSRC, s), "-o", o]))
+            for vtag, vflags in VARIANTS:
+                o = os.path.join(CSRC, s.rsplit(".", 1)[0] + "_" + vtag + sfx + ".o")
+                ren = [f"-D{n}={n}_{vtag}" for n in KERNEL_EXPORTS + ["cmc"]]      # cmc: the kernel bodies' namespace (their structs differ in size)
+                jobs.append((s + " [" + vtag + "]", [base[0]] + arch + base[1:] + vflags + ren + [os.path.join(CSRC, s), "-o", o]))
                 objs.append(o)
         else:
-            o = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
+            o = os.path.join(CSRC, s.rsplit(".", 1)[0] + sfx + ".o")
             jobs.append((s, [base[0], "-x", "c++"] + base[1:] + [os.path.join(CSRC, s), "-o", o]))   # host-only sources: plain C++
             objs.append(o)
     procs = [(name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for name, cmd in jobs]   # in parallel

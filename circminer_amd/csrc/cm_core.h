@@ -143,6 +143,8 @@ constexpr int MAX_BAND = 8;                 // bandWidth supported by the privat
 constexpr int MAX_TID = 64;                 // |common_tid| kept in registers / scratch per mate pair (larger sets: TidList)
 #if defined(CM_STAGE2_HOST)
 constexpr int MEMO_N = 512;                 // host (stage 2): room for every exon piece of every common transcript
+#elif defined(CM_MEMO_N)
+constexpr int MEMO_N = CM_MEMO_N;           // test builds (tests/test_gpu_parity.py: a tiny table sends many pairs through the re-run launch)
 #else
 constexpr int MEMO_N = 8;                   // memoised exon alignments per extend call
 #endif
@@ -694,6 +696,9 @@ CM_HD inline int chain_kbest(const Core &c, int seq_len, int n_seeds, const uint
 // alignment (A14, A15)
 // ------------------------------------------------------------------------------------------
 struct AlignRes { uint32_t pos; int ed, sclen, indel, qcovlen, rcovlen, score; };
+struct MemoKey { uint32_t rspos, rlen, qspos, qlen; };
+struct MemoSpill { MemoKey k; AlignRes v; };     // one overflow entry of the extension memo, in global memory (see Memo)
+typedef CM_G MemoSpill *g_spill;
 CM_HD inline AlignRes ar_init(uint32_t p) { return AlignRes{p, 0, 0, 0, 0, 0, -INF_I}; }
 CM_HD inline void ar_set(AlignRes &a, uint32_t p, int e, int s, int i, int qc, int scr) {
     a.pos = p; a.ed = e; a.sclen = s; a.indel = i; a.qcovlen = qc; a.rcovlen = qc - i; a.score = scr;
@@ -1177,13 +1182,13 @@ __device__ inline void cm_tick(Tick *tk, int id) {
 #else
 #define CM_TICK(sm_, id) ((void)0)
 #endif
-struct DpMem { LBuf a, b; g_err err; Tick *tk; };
+struct DpMem { LBuf a, b; g_err err; Tick *tk; g_spill spill; int spill_cap; };
 #elif defined(CM_STAGE2_HOST)
 #define CM_TICK(sm_, id) ((void)0)
-struct DpMem { LBuf a, b; g_err err; bool edit; };      // edit: EditDistAlignment instead of DropAlignment (ProcessCirc, src/process_circ.cpp:25)
+struct DpMem { LBuf a, b; g_err err; bool edit; g_spill spill; int spill_cap; };      // edit: EditDistAlignment instead of DropAlignment (ProcessCirc, src/process_circ.cpp:25)
 #else
 #define CM_TICK(sm_, id) ((void)0)
-struct DpMem { LBuf a, b; g_err err; };
+struct DpMem { LBuf a, b; g_err err; g_spill spill; int spill_cap; };   // spill: see Memo (null in the first pass of a pair)
 #endif
 CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
     if (n <= sm.a.cap && m <= sm.b.cap && n >= 0 && m >= 0) return true;
@@ -1685,29 +1690,42 @@ CM_HD inline bool is_left_chain(const CH &a, const CH &b, int read_length) {
 // ------------------------------------------------------------------------------------------
 // extension (A11-A13, A19)
 // ------------------------------------------------------------------------------------------
-struct MemoKey { uint32_t rspos, rlen, qspos, qlen; };
 struct Memo {
     MemoKey k[MEMO_N];
     AlignRes v[MEMO_N];
     int n;
     int flags;          // bit 0: an insert was dropped (table full); bit 1: an end piece shorter than its query was seen
+    g_spill sp;         // entries MEMO_N .. MEMO_N + sp_cap - 1 (the exact re-run of a pair whose memo overflowed); null otherwise
+    int sp_cap;
 };
+CM_HD inline bool memo_key_eq(const MemoKey &a, const MemoKey &k) { return a.rspos == k.rspos && a.rlen == k.rlen && a.qspos == k.qspos && a.qlen == k.qlen; }
 CM_HD inline int memo_find(const Memo &m, const MemoKey &k) {
-    for (int i = 0; i < m.n; ++i)
-        if (m.k[i].rspos == k.rspos && m.k[i].rlen == k.rlen && m.k[i].qspos == k.qspos && m.k[i].qlen == k.qlen) return i;
+    const int np = m.n < MEMO_N ? m.n : MEMO_N;
+    for (int i = 0; i < np; ++i)
+        if (memo_key_eq(m.k[i], k)) return i;
+    for (int i = MEMO_N; i < m.n; ++i) {
+        const MemoKey a = m.sp[i - MEMO_N].k;
+        if (memo_key_eq(a, k)) return i;
+    }
     return -1;
 }
+CM_HD inline AlignRes memo_get(const Memo &m, int i) { return i < MEMO_N ? m.v[i] : m.sp[i - MEMO_N].v; }
 // std::map::insert semantics (no overwrite).  The reference's memo (std::map<AllCoord, AlignRes>, src/extend.cpp:299,375) is a
 // pure cache -- same key, same computation -- EXCEPT when a "middle" piece and an "end" piece share a key, where it serves the
 // first-inserted kind to both.  A middle key has rlen < qlen; an end key has rlen = min(remaining window, exon) >= qlen unless
 // the indels of the pieces before it sum to less than -band (rlen = qlen + band + sum(indel)).  So a full table that stops
 // memoising (recomputing instead) is exact unless BOTH happen in one extend call: an insert was dropped and an end piece with
-// rlen < qlen was seen.  extend_side reports that combination as ERR_MEMO (CM_ELIMIT) instead of returning a result that
-// may differ from the reference's.
+// rlen < qlen was seen.  extend_side flags that combination (ERR_MEMO) instead of returning a result that may differ from the
+// reference's; the pair kernels then leave the pair untouched and map it again with a spill area behind the table (m.sp:
+// entries MEMO_N .. in global memory, cm_hot.hip RetryArgs), so no pair fails a batch for the size of this table.
 CM_HD inline void memo_put(Memo &m, const MemoKey &k, const AlignRes &v) {      // callers have just looked k up and missed
     if (m.n < MEMO_N) {
         m.k[m.n] = k;
         m.v[m.n] = v;
+        ++m.n;
+    } else if (m.n - MEMO_N < m.sp_cap) {
+        m.sp[m.n - MEMO_N].k = k;
+        m.sp[m.n - MEMO_N].v = v;
         ++m.n;
     } else m.flags |= 1;
 }
@@ -1752,7 +1770,7 @@ struct Ext {
         CM_TICK(sm, 20);
         const int f = memo_find(memo, key);
         if (f >= 0) {
-            const AlignRes &r = memo.v[f];
+            const AlignRes r = memo_get(memo, f);
             if (curr.ed + r.ed > ed_th) return false;
             ar_update(curr, r.ed, r.sclen, r.pos, r.indel, r.qcovlen, r.score);
             ar_side(c, best, curr, right);
@@ -1772,7 +1790,7 @@ struct Ext {
         if (key.rlen < key.qlen) memo.flags |= 2;
         const int f = memo_find(memo, key);
         if (f >= 0) {
-            const AlignRes &r = memo.v[f];
+            const AlignRes r = memo_get(memo, f);
             if ((curr.ed + r.ed > ed_th) || (r.sclen > c.P.max_sc) || (r.qcovlen - r.sclen < r.sclen)) return;
             ar_update(curr, r.ed, r.sclen, r.pos, r.indel, r.qcovlen, r.score);
             ar_by_score(best, curr, right);
@@ -1902,6 +1920,8 @@ struct Ext {
         Memo memo;
         memo.n = 0;
         memo.flags = 0;
+        memo.sp = sm.spill;
+        memo.sp_cap = sm.spill ? sm.spill_cap : 0;
         int it_ind = -1, it_seg = -1;
         CM_TICK(sm, 22);
         if (tl.n > 0) it_seg = overlap_ind(c, pos, it_ind);
@@ -1913,7 +1933,11 @@ struct Ext {
         };
         for (int i = 0; i < tl.n; ++i) along(tl.t[i]);
         if (tl.more) common_tids_from(c, tl.s, tl.r, MAX_TID, along);
+#if defined(CM_MEMO_STRICT)          // test builds: every dropped insert sends the pair to the re-run launch
+        if (memo.flags & 1) flag_err(sm.err, ERR_MEMO);
+#else
         if (memo.flags == 3) flag_err(sm.err, ERR_MEMO);
+#endif
         int min_ed = best.ed, sclen_best = best.sclen;
         CM_TICK(sm, 11);
         if (min_ed <= ed_th) {

@@ -101,6 +101,6 @@ int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) { return ctx ? GO(cm
 int cm_prof_enable(cm_ctx *ctx, int on) { return ctx ? GO(cm_prof_enable, on) : CM_EINVAL; }
 int cm_prof_reset(cm_ctx *ctx) { return ctx ? GO(cm_prof_reset) : CM_EINVAL; }
 int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) { return ctx ? GO(cm_prof_get, ms, launches) : CM_EINVAL; }
-int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]) { return ctx ? GO(cm_prof_counters, c) : CM_EINVAL; }
+int cm_prof_counters(cm_ctx *ctx, uint64_t c[8]) { return ctx ? GO(cm_prof_counters, c) : CM_EINVAL; }
 
 }  // extern "C"

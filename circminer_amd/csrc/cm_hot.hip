@@ -195,13 +195,28 @@ __global__ void __launch_bounds__(BLK_CHAIN, CM_CHAIN_WAVES) k_chain(KCore kc, R
     resid[r] = (uint16_t)rs;
 }
 
+// The reference has no per-pair capacity limits inside maxReadLength (its extension memo is an unbounded std::map,
+// src/extend.cpp:299,375); the device keeps 8 memo entries per extend call in registers / scratch.  A pair that would need more
+// (and could observe the difference, cm_core.h memo_put) is not allowed to fail the batch: both pair kernels leave it untouched,
+// append it to `list`, and a second launch of k_pair over that list -- queued behind them unconditionally, it reads `count` on
+// the device -- maps it with a spill area of `spill_cap` more entries per lane in global memory and longer DP staging buffers.
+struct RetryArgs {
+    uint32_t *pair_err;          // one word per pair of the tile, all zero between launches
+    uint32_t *list;              // pairs (tile-relative) to re-run
+    unsigned int *count;
+    cmc::MemoSpill *spill;       // re-run only
+    int spill_cap;
+    int first;                   // 1: first pass (record, skip, queue)   0: the re-run
+};
+
 #ifndef CM_PAIR_WAVES
 #define CM_PAIR_WAVES 4       // waves per SIMD the pair kernels are compiled for (128 VGPRs; LDS: 2 x lbuf_bytes x 64 per wave)
 #endif
 __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
                                                    const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
                                                    int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
-                                                   const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk) {
+                                                   const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk,
+                                                   RetryArgs ra) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
@@ -216,10 +231,14 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
     tick.wave_on = 1;
     for (int i = threadIdx.x; i < 65; i += BLK_PAIR) tick_w[i] = i == 0 ? tick.last : 0ull;
     __syncthreads();
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
+    cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
+    cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
+    if (ra.spill) {          // the exact re-run of the pairs the first pass gave up on: a memo that holds every exon piece
+        sm.spill = (cmc::g_spill)(ra.spill + ((size_t)blockIdx.x * BLK_PAIR + threadIdx.x) * (size_t)ra.spill_cap);
+        sm.spill_cap = ra.spill_cap;
+    }
     const Core c = cmc::to_core(kc);
     // persistent grid: the launch places every workgroup at once (gridDim <= resident capacity), so the dispatcher is free
     // for the kernels of the next round that other streams run at the same time.  A wave takes the next 64 pairs of the list
@@ -243,15 +262,32 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
         hh[x] = high[r];
     }
     cm_mapped_read mr = state[p];
-    const int st = cmc::process_read(c, sm, (cmc::g_u8)(rd.seq1 + a0), (int)(a1 - a0), (cmc::g_u8)(rd.seq2 + b0), (int)(b1 - b0), sets, hh, mr, (cmc::g_err)err);
-    uint8_t act = 1;
-    cmc::finish_round(c, st, is_last, (int)(a1 - a0), (int)(b1 - b0), mr, act);
-    state[p] = mr;
-    active[p] = act;
-    cat[p] = st;
-    {   // pair-rounds counter: one atomic per wave
-        const unsigned long long m = __ballot(1);
-        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(&counters[3], (unsigned long long)__popcll(m));
+    // First pass: a device-capacity limit hit by this pair (cmc::ERR_MEMO / ERR_BAND) is recorded in the pair's own word; such
+    // a pair keeps its inputs (nothing is written) and is queued for the re-run.  Re-run (ra.first == 0): limits go to the
+    // launch-wide word and fail the call -- with the spill memo and the longer staging buffers none is known to be reachable.
+    int *perr = ra.first ? (int *)(ra.pair_err + t) : err;
+    sm.err = (cmc::g_err)perr;
+    const int st = cmc::process_read(c, sm, (cmc::g_u8)(rd.seq1 + a0), (int)(a1 - a0), (cmc::g_u8)(rd.seq2 + b0), (int)(b1 - b0), sets, hh, mr, (cmc::g_err)perr);
+    bool keep = true;
+    if (ra.first) {
+        if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            ra.list[atomicAdd(ra.count, 1u)] = t;
+            keep = false;
+        }
+    } else ra.pair_err[t] = 0u;
+    if (keep) {
+        uint8_t act = 1;
+        cmc::finish_round(c, st, is_last, (int)(a1 - a0), (int)(b1 - b0), mr, act);
+        state[p] = mr;
+        active[p] = act;
+        cat[p] = st;
+    }
+    {   // pair-rounds counter: one atomic per wave (a pair left to the re-run is counted there)
+        const unsigned long long m = __ballot(1), mk = __ballot(keep);
+        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1 && mk) {
+            atomicAdd(&counters[3], (unsigned long long)__popcll(mk));
+            if (!ra.first) atomicAdd(&counters[4], (unsigned long long)__popcll(mk));       // pairs mapped by the re-run launch
+        }
     }
 #if defined(CM_DIAG)
     CM_TICK(sm, 13);
@@ -623,6 +659,11 @@ constexpr int CHAIN_LIGHT_CLS = 12;     // chaining classes below this are light
 constexpr int CLS_T = 1024;            // threads per block = 16 waves
 constexpr int N_CLS = 16;                // classes a sort can use (pairs: 0..13 light + 15 heavy; chaining: 0..11 light + 12..15 heavy)
 constexpr int CTR_SUM = 16, CTR_BASE = 32, CTR_WORDS = 64;
+constexpr int CTR_NEXT = 48;             // spare words of the pair stage's class counters: work cursors of k_pair / k_pair_heavy, then the
+constexpr int CTR_RETRY = 50;            // re-run list's length and the re-run launch's cursor (RetryArgs)
+constexpr unsigned HEAVY_GRID_MAX = 4096;   // d_hres holds the task outcomes + scratch of this many k_pair_heavy blocks
+constexpr int RETRY_GRID = 8;            // blocks of the re-run launch of k_pair (pairs beyond the first pass's capacity: a handful per run, if any)
+constexpr int RETRY_SPILL = 2040;        // + MEMO_N in registers: 2048 memoised exon pieces per extend call
 __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], unsigned int &rank_in_wave, int lane, int wave) {
     // wcnt[w][c] = number of lanes of wave w with class c; rank_in_wave = rank of this lane among its class in its wave
     rank_in_wave = 0;
@@ -935,7 +976,8 @@ __device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainS
 __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
-                                                         int str_cap, unsigned long long *dbg_rows, HRes *hres, unsigned int *next_pair) {
+                                                         int str_cap, unsigned long long *dbg_rows, HRes *hres, unsigned int *next_pair,
+                                                         RetryArgs ra) {
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_L uint8_t *base = (CM_L uint8_t *)lds_words;
@@ -950,9 +992,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
     tick.last = wall_clock64();
     for (int i = threadIdx.x; i < 65; i += BLK_PAIR) tick_w[i] = i == 0 ? tick.last : 0ull;
     __syncthreads();
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
+    cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err, &tick};
 #else
-    const cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
+    cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
     CM_L uint8_t *q = base + lds_stage_bytes;
     HeavyLds H;
@@ -983,6 +1025,8 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
         }
         cm_mapped_read mr = state[p];
         int st = -1;
+        int *perr = (int *)(ra.pair_err + t);        // capacity limits of this pair (see RetryArgs): every lane of the wave flags the same word
+        sm.err = (cmc::g_err)perr;
         const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
         if (n1 + n2 <= 0) {             // unreachable for a pair classified heavy; kept for completeness
             st = ((hh[0] + hh[1] > 0) && (hh[2] + hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
@@ -999,20 +1043,25 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
             const bool first = lhs >= rhs;
             for (int attempt = 0; attempt < 2 && st < 0; ++attempt) {
                 int a;
-                if ((attempt == 0) == first) a = mates_wave(c, sm, sets[0], r1f, sets[3], r2b, mr, true, (cmc::g_err)err, H, lane);
-                else a = mates_wave(c, sm, sets[2], r2f, sets[1], r1b, mr, false, (cmc::g_err)err, H, lane);
+                if ((attempt == 0) == first) a = mates_wave(c, sm, sets[0], r1f, sets[3], r2b, mr, true, (cmc::g_err)perr, H, lane);
+                else a = mates_wave(c, sm, sets[2], r2f, sets[1], r1b, mr, false, (cmc::g_err)perr, H, lane);
                 if (c.P.scan_level == 0 && a == CM_CONCRD) st = CM_CONCRD;
                 __syncthreads();
             }
             if (st < 0) st = __shfl(mr.type, 0);
         }
+        __threadfence();
         if (lane == 0) {
-            uint8_t act = 1;
-            cmc::finish_round(c, st, is_last, len1, len2, mr, act);
-            state[p] = mr;
-            active[p] = act;
-            cat[p] = st;
-            atomicAdd(&counters[3], 1ull);
+            if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ra.list[atomicAdd(ra.count, 1u)] = t;          // left as it was; the re-run launch of k_pair maps it (one lane, exact)
+            } else {
+                uint8_t act = 1;
+                cmc::finish_round(c, st, is_last, len1, len2, mr, act);
+                state[p] = mr;
+                active[p] = act;
+                cat[p] = st;
+                atomicAdd(&counters[3], 1ull);
+            }
         }
         __syncthreads();
         CM_TICK(sm, 13);
@@ -1158,6 +1207,8 @@ struct cm_ctx {
     unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
     uint32_t *d_hlist = nullptr;
     HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
+    uint32_t *d_pair_err = nullptr, *d_retry_list = nullptr;      // per-pair capacity flags of a tile (zero between launches), pairs to re-run (RetryArgs)
+    cmc::MemoSpill *d_spill = nullptr;                            // RETRY_GRID x 64 lanes x RETRY_SPILL overflow entries of the extension memo
     uint8_t *d_pool = nullptr;
     unsigned long long pool_bytes = 0;
     unsigned long long *d_pool_cursor = nullptr;
@@ -1229,6 +1280,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
+    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
@@ -1506,13 +1558,13 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     }
     if (hipMalloc((void **)&ctx->d_pool_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault) != hipSuccess) {
         delete ctx;
         return CM_ENOMEM;
     }
     (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);
-    (void)hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
     if (getenv("CM_ONE_STREAM")) {           // diagnostic: no concurrency between the light and the heavy kernels
         (void)hipStreamDestroy(ctx->stream2);
         ctx->stream2 = ctx->stream;
@@ -1737,7 +1789,14 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
-    HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)4096 * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)HEAVY_GRID_MAX * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
+    {
+        const uint32_t *before = ctx->d_pair_err;
+        HIPCHK(ctx, ensure(ctx, ctx->d_pair_err, (size_t)tile * 4));
+        if (ctx->d_pair_err != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_err, 0, (size_t)tile * 4, ctx->stream_p));   // the kernels keep it zero
+    }
+    HIPCHK(ctx, ensure(ctx, ctx->d_retry_list, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_spill, (size_t)RETRY_GRID * BLK_PAIR * RETRY_SPILL * sizeof(cmc::MemoSpill)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_sub, (size_t)tile));
@@ -1903,8 +1962,11 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         if (want > lds_bytes && want <= 60 * 1024) lds_bytes = want;
     }
     const size_t lds_heavy = lds_bytes + 64 * sizeof(int);
-    if (lds_heavy > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // the re-run launch of k_pair (RetryArgs): staging buffers for strings of any length a read of this batch can produce
+    const int cap2 = std::min(((2 * ctx->max_len + 64 + 7) / 8) * 8, 1016);      // 1016: 64 KB of LDS per wave
+    const size_t lds2 = (size_t)2 * lbuf_bytes(cap2) * BLK_PAIR;
+    if (lds_heavy > 48 * 1024 || lds2 > 48 * 1024) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_bytes, lds2)));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_heavy));
     }
     {
@@ -1933,8 +1995,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                            ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
     }
-    constexpr int CTR_NEXT = 48;      // spare words of the class counters: the pair kernels' work cursors (light, heavy)
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), sp));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 4 * sizeof(unsigned int), sp));     // both cursors, re-run count + cursor
+    const RetryArgs ra1{ctx->d_pair_err, ctx->d_retry_list, ctx->d_cls_ctr + CTR_RETRY, nullptr, 0, 1};
     // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
     // behind it.
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
@@ -1947,12 +2009,12 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         static const unsigned heavy_div = getenv("CM_HEAVY_DIV") ? (unsigned)atoi(getenv("CM_HEAVY_DIV")) : 2u;      // tuning knob
         const unsigned heavy_cap = cap / (heavy_div ? heavy_div : 2u);
         static const unsigned heavy_fix = getenv("CM_HEAVY_GRID") ? (unsigned)atoi(getenv("CM_HEAVY_GRID")) : 0u;    // tuning knob
-        const unsigned heavy_lim = heavy_fix ? heavy_fix : heavy_cap;
+        const unsigned heavy_lim = std::min(heavy_fix ? heavy_fix : heavy_cap, HEAVY_GRID_MAX);     // d_hres is sized for HEAVY_GRID_MAX blocks
         const unsigned heavy_grid = nt < heavy_lim ? (nt ? nt : 1u) : heavy_lim;
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
                            ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres,
-                           ctx->d_cls_ctr + CTR_NEXT + 1);
+                           ctx->d_cls_ctr + CTR_NEXT + 1, ra1);
         ++ctx->launches[4];
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join_p, sp2));
@@ -1963,9 +2025,16 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = light_fix ? light_fix : 256u * 4u * slots_per_simd;   // light takes the slots heavy leaves: full cap
         hipLaunchKernelGGL(k_pair, dim3(want < cap ? want : cap), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, ctx->d_perm,
-                           ctx->d_cls_ctr + CTR_SUM, ctx->d_cls_ctr + CTR_NEXT);
+                           ctx->d_cls_ctr + CTR_SUM, ctx->d_cls_ctr + CTR_NEXT, ra1);
         HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
         ++ctx->launches[2];
+        // the re-run of whatever the two kernels queued (usually nothing: the launch reads the count on the device and ends):
+        // the same kernel over the re-run list, one pair per lane, memo spill area, staging buffers for strings of any length a
+        // read of this batch can produce.  It ends before ev_pair[b] frees this item's chain records.
+        const RetryArgs ra2{ctx->d_pair_err, ctx->d_retry_list, ctx->d_cls_ctr + CTR_RETRY, ctx->d_spill, RETRY_SPILL, 0};
+        hipLaunchKernelGGL(k_pair, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
+                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,
+                           (const uint32_t *)ctx->d_retry_list, (const unsigned int *)(ctx->d_cls_ctr + CTR_RETRY), ctx->d_cls_ctr + CTR_RETRY + 1, ra2);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp));
     ctx->pair_pending[b] = true;
@@ -2333,7 +2402,7 @@ int cm_prof_reset(cm_ctx *ctx) {
         ctx->ms[i] = 0;
         ctx->launches[i] = 0;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CM_OK;
 }
@@ -2356,13 +2425,13 @@ int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) {
     return CM_OK;
 }
 
-int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]) {
+int cm_prof_counters(cm_ctx *ctx, uint64_t c[8]) {
     if (!ctx || !c) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 4; ++i) c[i] = h[i];
+    for (int i = 0; i < 8; ++i) c[i] = h[i];
     return CM_OK;
 }
 

@@ -209,3 +209,33 @@ extern "C" void cm_host_free_index(cm_index_view *iv) {
     iv->pos = nullptr;
     iv->n_entries = 0;
 }
+
+extern "C" int cm_host_index_stats(const cm_index_view *iv, int32_t seed_lim, int n_threads, uint64_t out[4]) {
+    if (!iv || !out || !iv->bucket_off || (iv->n_entries && !iv->checksum)) return CM_EINVAL;
+    const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
+    const int nt = std::max(1, std::min(n_threads, 64));
+    std::vector<uint64_t> part((size_t)nt * 4, 0);
+    const uint32_t *off = iv->bucket_off;
+    const uint16_t *cs = iv->checksum;
+    run_threads(nt, [&](int t) {
+        uint64_t *p = part.data() + (size_t)t * 4;
+        const uint64_t h0 = nb * (uint64_t)t / nt, h1 = nb * (uint64_t)(t + 1) / nt;
+        for (uint64_t h = h0; h < h1; ++h) {
+            for (uint32_t i = off[h], e = off[h + 1]; i < e;) {           // runs of equal checksum inside a bucket = one k-mer
+                uint32_t j = i + 1;
+                while (j < e && cs[j] == cs[i]) ++j;
+                const uint64_t m = j - i;
+                p[0] += m;
+                if (m > 1) p[1] += m;
+                if (m > (uint64_t)std::max(seed_lim, 0)) p[2] += m;
+                ++p[3];
+                i = j;
+            }
+        }
+    });
+    for (int k = 0; k < 4; ++k) {
+        out[k] = 0;
+        for (int t = 0; t < nt; ++t) out[k] += part[(size_t)t * 4 + k];
+    }
+    return CM_OK;
+}

@@ -193,6 +193,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_prof_counters": (C.c_int, [vp, pp(C.c_uint64)]),
         "cm_host_build_index": (C.c_int, [u8p, C.c_uint32, C.c_int32, C.c_int32, C.c_int, pp(IndexView)]),
         "cm_host_free_index": (None, [pp(IndexView)]),
+        "cm_host_index_stats": (C.c_int, [pp(IndexView), C.c_int32, C.c_int, pp(C.c_uint64)]),
         "cm_host_build_annotation": (C.c_int, [C.c_char_p, pp(ChrInfo), C.c_uint32, u32p, C.c_uint32, C.c_int32,
                                                pp(AnnotView)]),
         "cm_host_free_annotation": (None, [pp(AnnotView), C.c_uint32]),
@@ -236,7 +237,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_map_rounds", "cm_reads_download", "cm_map_batch",
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
-                    "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_build_annotation",
+                    "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_index_stats", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_next_contig_genome", "cm_host_free_loaded_contig",
                     "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
@@ -282,6 +283,18 @@ class HostIndex:
             raise RuntimeError(f"cm_host_build_annotation failed: {rc}")
         self.chr_table = list(chr_table)
         self.n_contigs = n_con
+
+    def hit_stats(self, seed_lim=500, n_threads=8):
+        """Per contig (indexed positions, positions whose k-mer occurs more than once, positions whose k-mer occurs more than
+        seed_lim times, distinct k-mers): the repeat content a probe of this index sees (cm_host_index_stats)."""
+        res = []
+        for iv in self.views:
+            o = (C.c_uint64 * 4)()
+            rc = self.L.cm_host_index_stats(C.byref(iv), seed_lim, n_threads, o)
+            if rc != 0:
+                raise RuntimeError(f"cm_host_index_stats failed: {rc}")
+            res.append(tuple(int(x) for x in o))
+        return res
 
     def save_index(self, index_dir):
         """Raw dumps of the flattened index arrays (bucket offsets, checksums, positions) of every contig."""
@@ -678,7 +691,7 @@ class HotPath:
         ms = (C.c_double * 8)()
         n = (C.c_uint64 * 8)()
         self._chk(self.L.cm_prof_get(self.h, ms, n), "cm_prof_get")
-        cnt = (C.c_uint64 * 4)()
+        cnt = (C.c_uint64 * 8)()
         self._chk(self.L.cm_prof_counters(self.h, cnt), "cm_prof_counters")
         return list(ms), list(n), list(cnt)
 

@@ -88,6 +88,69 @@ def make_genome(rng, chr_lens, n_families=6, fam_len=300, fam_copies=40, fam_div
     return seqs
 
 
+# Repeat content of the dense hg38-like preset ("repeat families tuned so ~10 % of 20-mers have > 1 hit and ~1 %
+# exceed seedLim"), in terms of what a probe of ONE packed contig's index sees (a round maps against one contig of ~1.03 Gbp,
+# a third of the genome, and seedLim applies to that contig's hit list, src/match_read.cpp:231).  Tiers: (families, (len_lo,
+# len_hi), (copies_lo, copies_hi) genome-wide, log-uniform, divergence of a copy from its consensus).
+#   "alu": two 300-bp families of 132 000 copies at 4 % -- ~44 000 copies per contig: the consensus 20-mers (44 % of a copy's
+#          positions) return ~18 000 hits each, far beyond seedLim = 500; the one-mismatch variants ~250 hits (multi-hit, kept);
+#   "dup": low-copy families (6 .. 900 copies genome-wide, 0.5 - 3 kbp, 2 %): the bulk of the multi-hit 20-mers, 2 .. 300 hits.
+# Measured on the built indexes (cm_host_index_stats, printed by bench.py in config.workload and asserted within +-30 % of the
+# targets in tests/test_gpu_hg38like.py).
+DENSE_TIERS = (
+    dict(name="alu", families=2, length=(300, 300), copies=(132_000, 132_000), div=0.04),
+    dict(name="dup", families=1200, length=(500, 3000), copies=(6, 900), div=0.02),
+)
+
+
+def scale_tiers(tiers, frac):
+    """The same repeat content per Mbp on a genome that is `frac` of hg38's size and packs into ONE contig (the copy numbers
+    a probe sees are per contig: a third of the genome-wide ones)."""
+    if frac > 0.9:
+        return tiers
+    out = []
+    for t in tiers:
+        t = dict(t)
+        t["families"] = max(1, int(round(t["families"] * (frac * 3 if t["name"] == "dup" else 1))))
+        t["copies"] = tuple(max(2, int(round(c / 3 * min(1.0, frac * 3)))) if t["name"] == "alu" else max(2, int(round(c / 3))) for c in t["copies"])
+        out.append(t)
+    return out
+
+
+def make_genome_tiers(rng, chr_lens, tiers=DENSE_TIERS, n_runs=2):
+    """Uniform ACGT chromosomes with repeat families of a spread of copy numbers / lengths / divergences planted at positions
+    drawn over the whole genome (later copies overwrite earlier ones where they overlap), plus a few N runs."""
+    seqs = [_ACGT[rng.integers(0, 4, L)] for L in chr_lens]
+    starts = np.concatenate([[0], np.cumsum(chr_lens)]).astype(np.int64)
+    total = int(starts[-1])
+    for tier in tiers:
+        for _ in range(tier["families"]):
+            flen = int(rng.integers(tier["length"][0], tier["length"][1] + 1))
+            lo, hi = tier["copies"]
+            ncopy = int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+            cons = _ACGT[rng.integers(0, 4, flen)]
+            g = rng.integers(0, total, ncopy)
+            ci = np.searchsorted(starts, g, side="right") - 1
+            p = g - starts[ci]
+            lens = np.asarray(chr_lens, dtype=np.int64)[ci]
+            ok = (p >= 1000) & (p + flen + 1000 < lens)
+            ci, p = ci[ok], p[ok]
+            mat = np.tile(cons, (len(p), 1))
+            m = rng.random(mat.shape) < tier["div"]
+            mat[m] = _ACGT[rng.integers(0, 4, int(m.sum()))]
+            ar = np.arange(flen)
+            for c in np.unique(ci):
+                sel = ci == c
+                seqs[c][p[sel][:, None] + ar] = mat[sel]
+    for s in seqs:
+        L = len(s)
+        if L > 6000:
+            for _ in range(n_runs):
+                p = int(rng.integers(L // 4, 3 * L // 4))
+                s[p:p + int(rng.integers(20, 200))] = ord("N")
+    return seqs
+
+
 def pack_genome(chr_names, chr_seqs, contig_size):
     """GenomePacker::pack_genome (reference src/genome.cpp:96-145)."""
     contigs: List[List[np.ndarray]] = []
@@ -108,7 +171,10 @@ def pack_genome(chr_names, chr_seqs, contig_size):
     return [np.concatenate(c) for c in contigs], table
 
 
-def make_genes(rng, chr_lens, genes_per_mbp=12.0, max_intron=20000, min_margin=2000):
+def make_genes(rng, chr_lens, genes_per_mbp=12.0, max_intron=20000, min_margin=2000, spread=False):
+    """spread: gaps drawn so that the mean gene-to-gene distance is 1e6 / genes_per_mbp, i.e. the genes cover the whole
+    chromosome (the plain presets draw shorter gaps and stop at the gene count, which leaves the far end of a long
+    chromosome empty)."""
     genes: List[Gene] = []
     gcount = 0
     for ci, L in enumerate(chr_lens):
@@ -120,7 +186,10 @@ def make_genes(rng, chr_lens, genes_per_mbp=12.0, max_intron=20000, min_margin=2
             in_len = np.minimum(rng.integers(200, max_intron + 1, n_ex - 1),
                                 (rng.pareto(1.5, n_ex - 1) * 400 + 200).astype(np.int64))
             span = int(ex_len.sum() + in_len.sum())
-            gap = int(rng.integers(500, max(501, int(1e6 / genes_per_mbp) - span // 2)))
+            if spread:
+                gap = int(rng.integers(500, max(501, 2 * (int(1e6 / genes_per_mbp) - span) - 500)))
+            else:
+                gap = int(rng.integers(500, max(501, int(1e6 / genes_per_mbp) - span // 2)))
             start = pos + gap
             if start + span + min_margin >= L:
                 break
@@ -338,7 +407,16 @@ def make_reads(rng, chr_seqs, genes, n_pairs, read_len=150, frag_lo=260, frag_hi
     return seq1, seq2, src, t_chr, t_lo, t_hi
 
 
+HG38_CHR_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+                 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+                 50818468, 156040895, 57227415]
+# presets whose repeats come from make_genome_tiers (DENSE_TIERS) and whose genes are spread over the chromosomes
+DENSE = {"hg38like", "contig1g_dense"}
+
 PRESETS = {
+    # The preset SURVEY.md 8(d) specifies for BASELINE.json configs[2..4]: hg38's chromosome lengths (3.09 Gbp -> three packed
+    # contigs), ~60 000 genes of 1 - 3 isoforms (19.4 / Mbp), tiered repeat families (DENSE_TIERS).  fam_copies is unused here.
+    "hg38like": (HG38_CHR_LENS, 19.4, 1_100_000_000, 0),
     # name: (chromosome lengths, genes/Mbp, contig size cap, copies per repeat family)
     "tiny": ([120_000, 90_000], 60.0, 1_100_000_000, 6),
     "tiny2r": ([120_000, 90_000], 60.0, 150_000, 6),           # two packed contigs -> two rounds
@@ -350,9 +428,10 @@ PRESETS = {
     # one full-size packed contig (hg38 chr1-5 lengths, 1.06 Gbp): the scale of one round of configs[2..4]
     # hg38 primary chromosome lengths (1-22, X, Y; 3.09 Gbp) -> three packed contigs of <= 1.1 Gbp = three rounds: the layout of
     # BASELINE.json configs[2..4].  ~25 GB of index + genome in HBM, ~40 GB of host memory while one contig's index is built.
-    "hg38like": ([248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+    "hg38like_sparse": ([248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
                   135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
                   50818468, 156040895, 57227415], 5.5, 1_100_000_000, 100000),
+    "contig1g_dense": ([248_000_000, 242_000_000, 198_000_000, 190_000_000, 181_000_000], 19.4, 1_100_000_000, 0),
     "contig1g": ([248_000_000, 242_000_000, 198_000_000, 190_000_000, 181_000_000], 5.5, 1_100_000_000, 40000),
 }
 
@@ -366,9 +445,10 @@ def generate(preset="tiny", n_pairs=2000, seed=21, read_len=150, mix=(0.70, 0.25
     gpm = genes_per_mbp or p_gpm
     cs = contig_size or p_cs
     names = [f"chr{i + 1}" for i in range(len(chr_lens))]
-    seqs = make_genome(rng, chr_lens, fam_copies=fam_copies)
+    dense = preset in DENSE
+    seqs = make_genome_tiers(rng, chr_lens, scale_tiers(DENSE_TIERS, sum(chr_lens) / sum(HG38_CHR_LENS))) if dense else make_genome(rng, chr_lens, fam_copies=fam_copies)
     contigs, table = pack_genome(names, seqs, cs)
-    genes = make_genes(rng, chr_lens, genes_per_mbp=gpm)
+    genes = make_genes(rng, chr_lens, genes_per_mbp=gpm, spread=dense)
     if preset == "variety":
         genes = add_variety(rng, genes, chr_lens)
     gtf = gtf_text(genes, names)

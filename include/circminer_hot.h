@@ -278,8 +278,10 @@ int cm_prof_enable(cm_ctx *ctx, int on);
 int cm_prof_reset(cm_ctx *ctx);
 int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]);
 /* Algorithmic byte counters of SURVEY §8(d) accumulated by the kernels since cm_prof_reset():
- * [0]=probes [1]=binary-search touches [2]=hits consumed (cnt<=seedLim) [3]=pair-rounds. */
-int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]);
+ * [0]=probes [1]=binary-search touches [2]=hits consumed (cnt<=seedLim) [3]=pair-rounds; [4]=pair-rounds that needed the re-run
+ * launch (a device capacity the reference does not have, e.g. more than 8 memoised exon pieces in one extension: mapped again
+ * with room for 2048, results identical); [5..7] reserved (0). */
+int cm_prof_counters(cm_ctx *ctx, uint64_t c[8]);
 
 /* ---------------- host-side builders (stay on host; north_star "index build ... on host") ---- */
 /* In-memory equivalent of generateHashTableOnDisk for one contig
@@ -287,6 +289,11 @@ int cm_prof_counters(cm_ctx *ctx, uint64_t c[4]);
 int cm_host_build_index(const uint8_t *genome, uint32_t ref_len, int32_t kmer, int32_t contig_num,
                         int n_threads, cm_index_view *out);
 void cm_host_free_index(cm_index_view *iv);
+/* Hit multiplicity of an index: over all indexed k-mer positions of the contig, how many share their k-mer with at least one
+ * other position (out[1]) and with more than seed_lim - 1 others, i.e. a probe of that k-mer returns more than seed_lim hits and
+ * the seed is dropped (src/match_read.cpp:231,259-263) (out[2]); out[0] = indexed positions, out[3] = distinct k-mers.  The two
+ * fractions out[1] / out[0] and out[2] / out[0] characterise a workload's repeat content. */
+int cm_host_index_stats(const cm_index_view *iv, int32_t seed_lim, int n_threads, uint64_t out[4]);
 
 /* GTF -> flattened annotation for every packed contig (GTFParser::load_gtf,
  * src/gene_annotation.cpp:191-399).  chromosome table = rows of .index.info

@@ -104,7 +104,7 @@ def map_all_rounds_mt(params, host_index, batch, n_threads=None, p1=None):
     import threading
     L = load()
     n = batch.n if p1 is None else min(int(p1), batch.n)
-    T = max(1, min(n_threads or os.cpu_count() or 1, 64))
+    T = max(1, n_threads or os.cpu_count() or 1)
     st, act = default_state(params, batch.n)
     cat = np.full(max(batch.n, 1), -1, dtype=np.int32)
 

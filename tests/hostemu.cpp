@@ -160,9 +160,18 @@ static uint32_t *g_pair_dps = nullptr;      // number of real DPs (cmc::stage ca
 void emu_set_cost_out(double *out) { g_pair_ns = out; }
 void emu_set_dp_out(uint32_t *out) { g_pair_dps = out; }
 
+// spill_cap > 0: the extension memo gets that many overflow entries behind its MEMO_N (what the device's re-run launch of
+// k_pair does for a pair whose first pass flagged ERR_MEMO, cm_hot.hip RetryArgs)
+int emu_map_round_spill(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last, cm_mapped_read *state,
+                        uint8_t *active, int32_t *category, int spill_cap);
 int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last, cm_mapped_read *state,
                   uint8_t *active, int32_t *category) {
+    return emu_map_round_spill(P, X, A, R, is_last, state, active, category, 0);
+}
+int emu_map_round_spill(const cm_params *P, const cm_index_view *X, const cm_annot_view *A, const cm_reads *R, int is_last, cm_mapped_read *state,
+                        uint8_t *active, int32_t *category, int spill_cap) {
     Emu e;
+    std::vector<cmc::MemoSpill> spill((size_t)(spill_cap > 0 ? spill_cap : 0));
     e.core.P = *P;
     e.core.X = cmc::to_dev(*X);
     e.core.desc = desc_for(X);
@@ -186,7 +195,11 @@ int emu_map_round(const cm_params *P, const cm_index_view *X, const cm_annot_vie
         }
         const int l1 = (int)(R->off1[p + 1] - R->off1[p]), l2 = (int)(R->off2[p + 1] - R->off2[p]);
         uint8_t bufa[1024], bufb[1024];
-        const cmc::DpMem sm{cmc::LBuf{bufa, 1024}, cmc::LBuf{bufb, 1024}, &e.err};
+        cmc::DpMem sm{cmc::LBuf{bufa, 1024}, cmc::LBuf{bufb, 1024}, &e.err};
+        if (spill_cap > 0) {
+            sm.spill = spill.data();
+            sm.spill_cap = spill_cap;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         const unsigned long long dp0 = cm_stats[8];
         const int st = cmc::process_read(e.core, sm, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);

@@ -36,6 +36,27 @@ def remain_files_from_states(tmp, d, P, states, active, rounds, out="o"):
     return prefix, r1, r2
 
 
+def remain_files_of_active(tmp, d, P, states, active, rounds, out="o"):
+    """The same two files, written from the active pairs alone (the others never reach a remain file): for batches too large
+    to push through Python text I/O as a whole.  Names carry the pair's index in the batch."""
+    keep = np.nonzero(active)[0]
+
+    class _Sub:
+        seq1, seq2 = d.seq1[keep], d.seq2[keep]
+
+    p1, p2 = write_fastq_pair(tmp, _Sub, len(keep), prefix=out + "_in", name=lambda i: f"pair{keep[i]}")
+    rd = cl.FastqReader(p1, p2, d.chr_table, P.max_ed)
+    b = rd.next_batch(len(keep) + 10)
+    prefix = os.path.join(str(tmp), out)
+    r1, r2 = f"{prefix}_{rounds}_remain_R1.fastq", f"{prefix}_{rounds}_remain_R2.fastq"
+    w = cl.RecordWriter(r1, r2, d.chr_table)
+    if b is not None:
+        w.write_remain(b, np.ascontiguousarray(states[keep]))
+    w.close()
+    rd.close()
+    return prefix, r1, r2
+
+
 def gnu_sort(path):
     """ProcessCirc::sort_fq's pipeline itself (C locale)."""
     env = dict(os.environ, LC_ALL="C")

@@ -559,27 +559,73 @@ def test_reads_of_21_seeds_take_the_wide_build(ds_long, ds_tiny2r):
         hp.upload(cl.ReadBatch(np.full((2, 380), ord("A"), np.uint8), np.full((2, 380), ord("C"), np.uint8)))
 
 
-def test_extension_memo_limit_is_reported(ds_tiny, tmp_path):
+def test_extension_memo_limit_is_recovered(ds_tiny, tmp_path, monkeypatch):
     """The three cases of test_hostemu_parity.test_extension_memo_limit on the device: a full memo alone and a short end piece
-    alone equal the oracle; both in one extend call end the batch with CM_ELIMIT, and the context maps the next batch."""
+    alone equal the oracle in the first pass; both in one extend call make the pair kernels leave the pair untouched and queue
+    it for the re-run launch (spill area behind the 8 memo entries): all three equal the oracle, no CM_ELIMIT -- the reference's
+    memo is an unbounded std::map (src/extend.cpp:299,375), one pair must not fail a batch.  The same pair inside a batch of
+    ordinary pairs, in the light and (CM_HEAVY_COST=0: every pair) the heavy kernel."""
     from test_hostemu_parity import tiny_exon_case
+    from conftest import _Shim
     P = cl.default_params(max_ed=6)
     _run_all_rounds(tiny_exon_case(tmp_path, 10, 0), P)
     _run_all_rounds(tiny_exon_case(tmp_path, 6, 4), P)
     both = tiny_exon_case(tmp_path, 10, 4)
+    _run_all_rounds(both, P)
+    # that pair (several copies) among 300 ordinary pairs drawn from the same contig
+    from circminer_amd import synth
+    chrom = both.d.contigs[0]
+    rng = np.random.default_rng(4)
+    st = rng.integers(100, len(chrom) - 600, 300)
+    ar = np.arange(150)
+    g1 = chrom[st[:, None] + ar]
+    g2 = synth.revcomp(chrom[(st + 200)[:, None] + ar])
+    s1 = np.concatenate([g1, np.repeat(both.batch.seq1.reshape(1, -1), 5, 0)])
+    s2 = np.concatenate([g2, np.repeat(both.batch.seq2.reshape(1, -1), 5, 0)])
+    order = rng.permutation(len(s1))
+    mixed = _Shim(both, cl.ReadBatch(s1[order], s2[order]))
+    st_mixed = _run_all_rounds(mixed, P)
+    assert (st_mixed["type"] == 0).sum() >= 295
+    monkeypatch.setenv("CM_HEAVY_COST", "0")
+    _run_all_rounds(mixed, P)
+
+
+def test_rerun_launch_under_a_two_entry_memo(tmp_path):
+    """A second build of the library with a 2-entry extension memo that flags every dropped insert (-DCM_MEMO_N=2
+    -DCM_MEMO_STRICT): a large share of the spliced pairs now goes through the re-run launch of k_pair (spill area in global
+    memory, pairs skipped by both pair kernels, nothing written in the first pass).  The parity suites of this file that map
+    whole data sets through all rounds must still equal the oracle bit for bit.  Runs them in ONE child process (the library
+    is chosen at import time through CM_LIB)."""
+    import subprocess
+    import sys
+    from circminer_amd import _build
+    so = _build.build(tag="memo2", flags=["-DCM_MEMO_N=2", "-DCM_MEMO_STRICT"])
+    env = dict(os.environ, CM_LIB=so, CM_EXPECT_RERUNS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "test_map_round_parity or test_variety or test_dirty or test_rounds_in_one_call or test_extension_memo_limit_is_recovered "
+                        "or test_reruns_are_counted"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_reruns_are_counted(ds_small):
+    """cm_prof_counters [4] counts the pair-rounds the re-run launch mapped: zero for the product
+    build on ordinary data, many under the 2-entry strict test build (CM_EXPECT_RERUNS, see the test above)."""
+    P = cl.default_params()
     hp = cl.HotPath(P)
-    hp.upload(both.batch)
-    hp.load_contig(0, both.hi.views[0], both.hi.annots[0])
-    hp.map_round(0, True)                                 # asynchronous: the flag surfaces at the next synchronising call
-    with pytest.raises(RuntimeError, match="memo"):
-        hp.download()
-    hp.upload(ds_tiny.batch)                              # reported once; the next batch starts clean
-    hp.load_contig(0, ds_tiny.hi.views[0], ds_tiny.hi.annots[0])
-    st0, act0 = op.default_state(P, ds_tiny.batch.n)
-    op.map_round(P, ds_tiny.ohi.views[0], ds_tiny.ohi.annots[0], ds_tiny.batch, True, st0, act0)
+    hp.prof(True)
+    hp.load_contig(0, ds_small.hi.views[0], ds_small.hi.annots[0])
+    hp.upload(ds_small.batch)
     hp.map_round(0, True)
-    assert hp.download()[0].tobytes() == st0.tobytes()
+    hp.sync()
+    reruns = hp.prof_get()[2][4]
     hp.close()
+    if os.environ.get("CM_EXPECT_RERUNS"):
+        assert reruns > 100, reruns
+    else:
+        assert reruns == 0
 
 
 @pytest.mark.parametrize("tile", [None, "300"])

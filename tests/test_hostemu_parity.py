@@ -306,6 +306,16 @@ def test_extension_memo_limit(emu, tmp_path):
     rc = emu.emu_map_round(C.byref(P), C.byref(both.hi.views[0]), C.byref(both.hi.annots[0]), C.byref(both.batch.c), 1, st1.ctypes.data,
                            act1.ctypes.data, cat1.ctypes.data)
     assert rc == 16                                       # cmc::ERR_MEMO and nothing else
+    # ... which on the device queues the pair for the re-run with a spill area behind the 8 entries (cm_hot.hip RetryArgs): exact
+    emu.emu_map_round_spill.argtypes = emu.emu_map_round.argtypes + [C.c_int]
+    for cap in (3, 2040):                                 # 3: the spill area fills up too -> still flagged; 2040: the device's size
+        st2, act2 = op.default_state(P, 1)
+        rc = emu.emu_map_round_spill(C.byref(P), C.byref(both.hi.views[0]), C.byref(both.hi.annots[0]), C.byref(both.batch.c), 1, st2.ctypes.data,
+                                     act2.ctypes.data, cat1.ctypes.data, cap)
+        assert rc == (16 if cap == 3 else 0)
+    st0, act0 = op.default_state(P, 1)
+    cat0 = op.map_round(P, both.ohi.views[0], both.ohi.annots[0], both.batch, True, st0, act0)
+    assert st2.tobytes() == st0.tobytes() and (act2 == act0).all() and cat1[0] == cat0[0]
 
 
 def test_seed_touch_count(emu, ds_tiny):

@@ -94,12 +94,14 @@ def make_genome(rng, chr_lens, n_families=6, fam_len=300, fam_copies=40, fam_div
 # len_hi), (copies_lo, copies_hi) genome-wide, log-uniform, divergence of a copy from its consensus).
 #   "alu": two 300-bp families of 132 000 copies at 4 % -- ~44 000 copies per contig: the consensus 20-mers (44 % of a copy's
 #          positions) return ~18 000 hits each, far beyond seedLim = 500; the one-mismatch variants ~250 hits (multi-hit, kept);
-#   "dup": low-copy families (6 .. 900 copies genome-wide, 0.5 - 3 kbp, 2 %): the bulk of the multi-hit 20-mers, 2 .. 300 hits.
+#   "dup": low-copy families (6 .. 900 copies genome-wide, 0.5 - 3 kbp, 2 %): the bulk of the multi-hit 20-mers, 2 .. 300 hits per
+#          contig, copy numbers drawn so that every octave of multiplicity holds the same share of the genome (a uniform or
+#          log-uniform draw per FAMILY would put two thirds of the multi-hit positions beyond 100 hits).
 # Measured on the built indexes (cm_host_index_stats, printed by bench.py in config.workload and asserted within +-30 % of the
 # targets in tests/test_gpu_hg38like.py).
 DENSE_TIERS = (
     dict(name="alu", families=2, length=(300, 300), copies=(132_000, 132_000), div=0.04),
-    dict(name="dup", families=1200, length=(500, 3000), copies=(6, 900), div=0.02),
+    dict(name="dup", families=7100, length=(500, 3000), copies=(6, 900), div=0.02, spread="positions"),
 )
 
 
@@ -127,7 +129,12 @@ def make_genome_tiers(rng, chr_lens, tiers=DENSE_TIERS, n_runs=2):
         for _ in range(tier["families"]):
             flen = int(rng.integers(tier["length"][0], tier["length"][1] + 1))
             lo, hi = tier["copies"]
-            ncopy = int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+            if tier.get("spread") == "positions" and hi > lo:
+                # family density ~ 1 / c^2: every octave of copy number (2-4, 4-8, ... copies) then covers the same number of
+                # genome positions -- a multi-hit 20-mer is as likely to have 2-4 hits as 128-256
+                ncopy = int(round(1.0 / (1.0 / lo - rng.random() * (1.0 / lo - 1.0 / hi))))
+            else:
+                ncopy = int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
             cons = _ACGT[rng.integers(0, 4, flen)]
             g = rng.integers(0, total, ncopy)
             ci = np.searchsorted(starts, g, side="right") - 1

@@ -130,7 +130,9 @@ def test_hg38like_three_rounds(hg38, monkeypatch, tmp_path, tile):
     st, res = _compare_all_rounds(d, gtf, P, N_PAIRS, streamed=True, stage2=s2)
     if res:
         rows, n_planted, n_pass = res
-        assert n_planted >= 0.99 * len(rows) and n_pass >= 0.99 * len(rows) and all(r[4] == "STC" for r in rows)
+        # every reported circle is a planted back-splice at its exact coordinates; "Pass" = the junction consensus of the
+        # supporting reads equals the reference (most circles have one supporting read here, and reads carry 0.4 % substitutions)
+        assert n_planted == len(rows) and n_pass >= 0.95 * len(rows) and all(r[4] == "STC" for r in rows)
         assert len(rows) >= 0.5 * int((d.src[:N_PAIRS] == 2).sum())
     m = d.src[:N_PAIRS] == 0
     assert (st["type"][m] == cl.CAT["CONCRD"]).mean() > 0.9

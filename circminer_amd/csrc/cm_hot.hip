@@ -395,15 +395,29 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
     return n;
 }
 
+// back-tracking state of one heavy problem (LDS): the candidates of the current score, their chains as (cell, slot) lists, the
+// non-first fragments of every chain emitted so far (the reference's `repeats` set, src/chain.cpp:248,274-276)
+struct HeavyBackTrack {
+    uint32_t base[cmc::MAX_SEEDS + 1];
+    uint32_t cand[CM_BESTCHAINLIM + 2];
+    uint16_t cidx[CM_BESTCHAINLIM][CM_MAX_CHAIN_FRAGS];
+    uint8_t cbl[CM_BESTCHAINLIM][CM_MAX_CHAIN_FRAGS];
+    uint8_t clen[CM_BESTCHAINLIM + 2];
+    uint8_t emit[CM_BESTCHAINLIM + 2];
+    uint32_t rep[CM_BESTCHAINLIM * (CM_MAX_CHAIN_FRAGS - 1)];
+};
+
 #ifndef CM_CHEAVY_WAVES
 #define CM_CHEAVY_WAVES 3      // waves per SIMD k_chain_heavy is compiled for (158 VGPRs as it stands)
 #endif
 __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, ReadsDev rd, uint64_t pair0, int S, const uint32_t *sstart, const uint32_t *scnt,
                                                     const unsigned long long *celloff, double *dp_score, int32_t *dp_prev, uint8_t *pool,
                                                     unsigned long long pool_bytes, unsigned long long *pool_cursor, cm_chain *chains, int32_t *nchain,
-                                                    int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm, unsigned int *next_problem) {
+                                                    int *err, uint16_t *resid, const uint32_t *perm, const unsigned int *n_perm, unsigned int *next_problem,
+                                                    unsigned long long *counters) {
     extern __shared__ uint32_t lds_words[];
     CM_L uint32_t *LP = (CM_L uint32_t *)lds_words;
+    __shared__ HeavyBackTrack BT;
     const int lane = threadIdx.x;
     const Core c = cmc::to_core(kc_);
     const int kmer = c.P.kmer;
@@ -416,6 +430,9 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
         const uint64_t p = pair0 + (r >> 2);
         const int mate = (int)((r >> 1) & 1u);
         const int len = (int)(mate ? rd.off2[p + 1] - rd.off2[p] : rd.off1[p + 1] - rd.off1[p]);
+#if defined(CM_CHAIN_DIAG)      // wave time per phase (100 MHz ticks) into counters[5..7]: load + init, DP, back-tracking
+        const unsigned long long dg0 = wall_clock64();
+#endif
         uint32_t st[cmc::MAX_SEEDS], cn[cmc::MAX_SEEDS], base[cmc::MAX_SEEDS + 1];
         int kc = S;
         for (int s = 0; s < S; ++s) {
@@ -437,6 +454,9 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
         }
         __threadfence_block();
         __syncthreads();
+#if defined(CM_CHAIN_DIAG)
+        const unsigned long long dg1 = wall_clock64();
+#endif
         HeavyChainCtx H{&c, LP, base, cn, kc, len, dps, dpp};
         CM_G cmc::Event *ev = nullptr;
         uint32_t n_ev = 0, cap_ev = 0;
@@ -487,11 +507,21 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
             __threadfence_block();
             __syncthreads();
         }
-        // ---- back-tracking (src/chain.cpp:242-298), lane 0 emits; searches are wave-parallel
+        // ---- back-tracking (src/chain.cpp:242-298), wave-parallel.  The reference walks the scores downwards; per score it takes
+        // the first <= maxChainLen logged cells in insertion order, skips one whose start is a non-first fragment of a chain
+        // already emitted (only below the best score), and emits the others until maxChainLen chains are out.  Here, per score:
+        // (1) the candidates are picked out of the log with ballots, (2) every candidate's chain is walked by its own lane
+        // (dependent loads of the back pointers: 30 walks overlap instead of queueing on lane 0), (3) the skip rule runs over
+        // the candidates in order against the emitted fragments kept in LDS, (4) the emitted chains are written by all lanes.
         CM_G cm_chain *out = (CM_G cm_chain *)(chains + (uint64_t)r * CM_BESTCHAINLIM);
         uint32_t best_count = 0;
+        int first_q0 = 0, first_qlast = 0;            // of chain 0 (for the residual key below)
+        if (lane <= kc) BT.base[lane] = base[lane];   // base[] by a lane-varying slot: from LDS
         __threadfence_block();
         __syncthreads();
+#if defined(CM_CHAIN_DIAG)
+        const unsigned long long dg2 = wall_clock64();
+#endif
         if (n_ev > 0) {
             double best_score = -1.0;
             for (uint32_t q = lane; q < n_ev; q += 64) best_score = ev[q].score > best_score ? ev[q].score : best_score;
@@ -501,62 +531,26 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
             }
             double cur = best_score;
             bool have = true;
+            uint32_t n_rep = 0;
             while (have && best_count < max_best) {
-                uint32_t in_group = 0;
-                bool stop_group = false;
-                for (uint32_t q0 = 0; q0 < n_ev && !stop_group && best_count < max_best; q0 += 64) {
-                    const uint32_t q = q0 + lane;
-                    const bool hit = q < n_ev && ev[q].score == cur;
-                    unsigned long long m = __ballot(hit);
-                    while (m && !stop_group && best_count < max_best) {
-                        const int l = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        if (in_group >= max_best) {
-                            stop_group = true;
-                            break;
-                        }
-                        ++in_group;
-                        const uint32_t cell = ev[q0 + l].cell;             // uniform
-                        int bl = (int)(cell >> 16);
-                        uint32_t bi = cell & 0xffffu;
-                        const uint32_t spos = LP[base[bl] + bi];
-                        bool rep = false;
-                        if (cur < best_score) {                            // repeats: non-first fragments already emitted
-                            for (uint32_t a = 0; a < best_count && !rep; ++a) {
-                                const uint32_t cl = out[a].chain_len;
-                                const bool mine2 = (uint32_t)lane >= 1u && (uint32_t)lane < cl && out[a].rpos[lane] == spos;
-                                rep = __ballot(mine2) != 0ull;
-                            }
-                        }
-                        if (rep) continue;
-                        if (lane == 0) {
-                            CM_G cm_chain &ch = out[best_count];
-                            uint32_t n = 0;
-                            while (true) {
-                                ch.rpos[n] = LP[base[bl] + bi];
-                                ch.qpos[n] = bl * kmer;
-                                ++n;
-                                const int32_t pv = dpp[base[bl] + bi];
-                                if (pv < 0) break;
-                                bl = (int)((uint32_t)pv >> 16);
-                                bi = (uint32_t)pv & 0xffffu;
-                            }
-                            ch.score = (float)cur;
-                            ch.chain_len = n;
-                        }
-                        ++best_count;
-                        __threadfence_block();
-                        __syncthreads();
-                    }
-                }
-                // next lower score
+                // (1) + next lower score, one pass over the log
+                uint32_t n_c = 0;
                 double nxt = -1.0;
                 bool hv = false;
-                for (uint32_t q = lane; q < n_ev; q += 64) {
-                    const double v = ev[q].score;
-                    if (v < cur && (!hv || v > nxt)) {
+                for (uint32_t q0 = 0; q0 < n_ev; q0 += 64) {
+                    const uint32_t q = q0 + lane;
+                    const double v = q < n_ev ? ev[q].score : 0.0;
+                    const bool hit = q < n_ev && v == cur;
+                    if (q < n_ev && v < cur && (!hv || v > nxt)) {
                         nxt = v;
                         hv = true;
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (m && n_c < max_best) {
+                        const uint32_t rank = n_c + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (hit && rank < max_best) BT.cand[rank] = ev[q].cell;
+                        n_c += (uint32_t)__popcll(m);
+                        if (n_c > max_best) n_c = max_best;
                     }
                 }
                 for (int o = 32; o >= 1; o >>= 1) {
@@ -567,29 +561,95 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
                         hv = true;
                     }
                 }
+                __syncthreads();
+                // (2) one lane per candidate walks its chain
+                if ((uint32_t)lane < n_c) {
+                    const uint32_t cell = BT.cand[lane];
+                    uint32_t bl = cell >> 16, bi = cell & 0xffffu, n = 0;
+                    while (true) {
+                        const uint32_t x = BT.base[bl] + bi;
+                        BT.cidx[lane][n] = (uint16_t)x;
+                        BT.cbl[lane][n] = (uint8_t)bl;
+                        ++n;
+                        const int32_t pv = dpp[x];
+                        if (pv < 0 || n >= (uint32_t)CM_MAX_CHAIN_FRAGS) break;
+                        bl = (uint32_t)pv >> 16;
+                        bi = (uint32_t)pv & 0xffffu;
+                    }
+                    BT.clen[lane] = (uint8_t)n;
+                }
+                __syncthreads();
+                // (3) the skip rule, candidates in order
+                const uint32_t first = best_count;
+                uint32_t n_emit = 0;
+                for (uint32_t a = 0; a < n_c && best_count < max_best; ++a) {
+                    if (cur < best_score) {
+                        const uint32_t spos = LP[BT.cidx[a][0]];
+                        bool mine = false;
+                        for (uint32_t x = lane; x < n_rep; x += 64) mine = mine || BT.rep[x] == spos;
+                        if (__ballot(mine) != 0ull) continue;
+                    }
+                    const uint32_t cl = BT.clen[a];
+                    if (lane == 0) BT.emit[n_emit] = (uint8_t)a;
+                    if ((uint32_t)lane >= 1u && (uint32_t)lane < cl) BT.rep[n_rep + lane - 1] = LP[BT.cidx[a][lane]];
+                    if (best_count == 0) {
+                        first_q0 = (int)BT.cbl[a][0] * kmer;
+                        first_qlast = (int)BT.cbl[a][cl - 1] * kmer;
+                    }
+                    n_rep += cl - 1;
+                    ++n_emit;
+                    ++best_count;
+                    __syncthreads();
+                }
+                __syncthreads();
+                // (4) write the chains emitted for this score
+                for (uint32_t x = lane; x < n_emit * (uint32_t)CM_MAX_CHAIN_FRAGS; x += 64) {
+                    const uint32_t k = x / (uint32_t)CM_MAX_CHAIN_FRAGS, f = x % (uint32_t)CM_MAX_CHAIN_FRAGS;
+                    const uint32_t a = BT.emit[k];
+                    if (f < BT.clen[a]) {
+                        CM_G cm_chain &ch = out[first + k];
+                        ch.rpos[f] = LP[BT.cidx[a][f]];
+                        ch.qpos[f] = (int32_t)BT.cbl[a][f] * kmer;
+                    }
+                }
+                if ((uint32_t)lane < n_emit) {
+                    CM_G cm_chain &ch = out[first + lane];
+                    ch.score = (float)cur;
+                    ch.chain_len = BT.clen[BT.emit[lane]];
+                }
+                __syncthreads();
                 have = hv;
                 cur = nxt;
             }
         }
-        if (best_count == 0 && lane == 0) {          // singletons
+        if (best_count == 0) {          // singletons (lane 0 emits; every lane keeps the count)
             for (int ii = kc - 1; ii >= 0; --ii)
                 for (uint32_t i = 0; i < cn[ii]; ++i) {
                     if (best_count >= max_best) break;
-                    CM_G cm_chain &ch = out[best_count++];
-                    ch.rpos[0] = LP[base[ii] + i];
-                    ch.qpos[0] = ii * kmer;
-                    ch.score = (float)dps[base[ii] + i];
-                    ch.chain_len = 1;
+                    if (best_count == 0) first_q0 = first_qlast = ii * kmer;
+                    if (lane == 0) {
+                        CM_G cm_chain &ch = out[best_count];
+                        ch.rpos[0] = LP[base[ii] + i];
+                        ch.qpos[0] = ii * kmer;
+                        ch.score = (float)dps[base[ii] + i];
+                        ch.chain_len = 1;
+                    }
+                    ++best_count;
                 }
         }
-        best_count = __shfl(best_count, 0);
         __threadfence_block();
         __syncthreads();
         if (lane == 0) {
             nchain[r] = (int32_t)best_count;
             int rs = 0;
-            if (best_count > 0) rs = pack_resid(out[0].qpos[0], len - (out[0].qpos[out[0].chain_len - 1] + kmer));
+            if (best_count > 0) rs = pack_resid(first_q0, len - (first_qlast + kmer));
             resid[r] = (uint16_t)rs;
+#if defined(CM_CHAIN_DIAG)
+            const unsigned long long dg3 = wall_clock64();
+            atomicAdd(&counters[5], dg1 - dg0);
+            atomicAdd(&counters[6], dg2 - dg1);
+            atomicAdd(&counters[7], dg3 - dg2);
+#endif
         }
         __syncthreads();
     }
@@ -1430,7 +1490,7 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
             static const size_t heavy_pad = getenv("CM_CHEAVY_LDS_PAD") ? (size_t)atoi(getenv("CM_CHEAVY_LDS_PAD")) : 0;     // occupancy experiment
             hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
                                ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, ctx->d_err,
-                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + 48);
+                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + 48, ctx->d_counters);
             ++ctx->launches[6];
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));

@@ -2102,21 +2102,11 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     return CM_OK;
 }
 
-int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final) {
-    if (!ctx || (n_rounds > 0 && !slots) || n_rounds < 0) return CM_EINVAL;
+// The rounds of cm_map_rounds; any failure (a HIP call, a stage) returns from here and is cleaned up by the caller below.
+// *rounds_done counts the rounds whose pair stage was issued for every tile (the flags arrays have swapped roles that often).
+static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final, int *items_done, int *rounds_done) {
     int rc;
-    // a failed stage leaves earlier pair stages in flight: wait for them, so that the caller may reuse or free the batch buffers
-    auto bail = [&](int e) {
-        (void)hipStreamSynchronize(ctx->stream_p);
-        (void)hipStreamSynchronize(ctx->stream_p2);
-        ctx->pair_pending[0] = ctx->pair_pending[1] = false;
-        ctx->pre_ready = ctx->pre_launched = false;
-        return e;
-    };
-    for (int r = 0; r < n_rounds; ++r)
-        if ((rc = check_slot(ctx, slots[r], true))) return rc;
-    HIPCHK(ctx, hipSetDevice(ctx->P.device));
-    if (ctx->n_pairs == 0 || n_rounds == 0) return CM_OK;
+    auto bail = [&](int e) { return e; };
     // everything queued on the main stream so far (uploads, resets, collects of the previous batch) comes first
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
@@ -2140,6 +2130,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
             for (int r = 0; r < n_rounds; ++r) items.push_back(Item{t * ctx->tile, tile_nt(t), r});
     }
     const int n_items = (int)items.size();
+    std::vector<int> tiles_of_round((size_t)n_rounds, 0);
     // Was this batch's first item prepared while the previous batch was in its last pair stage (see the end of this function)?
     const bool use_pre = ctx->pre_ready && slots[0] == ctx->pre_slot && ctx->slots[slots[0]].gen == ctx->pre_gen && ctx->n_pairs == ctx->pre_n &&
                          items[0].nt == ctx->pre_nt && (ctx->item_base & 1) == ctx->pre_b;
@@ -2177,10 +2168,13 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
         }
         const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
         if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return bail(rc);
+        ++*items_done;
+        if (++tiles_of_round[(size_t)r] == (int)n_tiles) ++*rounds_done;
         static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
         if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
     }
     ctx->item_base = (ctx->item_base + n_items) & 1;
+    *items_done = 0;                                   // accounted for
     // Cross-batch prefetch.  A batch's first item cannot hide behind one of its own pair stages, and its last pair stage has no
     // later item of its own to cover.  So when this call ends the batch and the next one is already staged (cm_reads_stage),
     // that batch's first item (first tile, slots[0]) is seeded and chained now, from the staging buffers (every pair of a fresh
@@ -2218,7 +2212,33 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;                     // covered by the wait above
     if (n_rounds & 1) std::swap(ctx->d_active, ctx->d_active_b);             // the current flags are in the other array now
+    *rounds_done = 0;                                  // accounted for
     return CM_OK;
+}
+
+int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final) {
+    if (!ctx || (n_rounds > 0 && !slots) || n_rounds < 0) return CM_EINVAL;
+    int rc;
+    for (int r = 0; r < n_rounds; ++r)
+        if ((rc = check_slot(ctx, slots[r], true))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    if (ctx->n_pairs == 0 || n_rounds == 0) return CM_OK;
+    int items_done = 0, rounds_done = 0;
+    rc = map_rounds_issue(ctx, slots, n_rounds, last_is_final, &items_done, &rounds_done);
+    if (rc == CM_OK) return rc;
+    // One exit for every failure inside: nothing of this call may still be running when the caller frees or reuses the batch
+    // buffers, and the bookkeeping must describe what was actually issued -- the chain-record set parity (item_base), the
+    // flags array that holds the latest flags (one swap per completed round), no prepared first item, no pending pair stage.
+    // The states of the batch are unspecified after a failed call (upload or reset before mapping again).
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream_p);
+    (void)hipStreamSynchronize(ctx->stream_p2);
+    ctx->item_base = (ctx->item_base + items_done) & 1;
+    if (rounds_done & 1) std::swap(ctx->d_active, ctx->d_active_b);
+    ctx->pair_pending[0] = ctx->pair_pending[1] = false;
+    ctx->pre_ready = ctx->pre_launched = false;
+    return rc;
 }
 
 int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) { return cm_map_rounds(ctx, &slot, 1, is_last_round); }

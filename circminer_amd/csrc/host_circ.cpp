@@ -230,11 +230,12 @@ extern "C" int cm_sort_remain(const char *in_path, const char *out_path) {
     for (Rec &r : recs) {
         for (char &c : r.pasted)
             if (c == '\t') c = '\n';                    // tr "\t" "\n"
-        fwrite(r.pasted.data(), 1, r.pasted.size(), out);
-        fputc('\n', out);
+        if (fwrite(r.pasted.data(), 1, r.pasted.size(), out) != r.pasted.size() || fputc('\n', out) == EOF) {
+            fclose(out);
+            return CM_EIO;
+        }
     }
-    fclose(out);
-    return CM_OK;
+    return fclose(out) == 0 ? CM_OK : CM_EIO;
 }
 
 extern "C" int cm_circ_report(const cm_circ_res *res, uint64_t n, const char *report_path) {
@@ -270,6 +271,6 @@ extern "C" int cm_circ_report(const cm_circ_res *res, uint64_t n, const char *re
         }
     }
     report_group(f, group);
-    fclose(f);
-    return CM_OK;
+    const bool bad = ferror(f) != 0;
+    return (fclose(f) == 0 && !bad) ? CM_OK : CM_EIO;
 }

@@ -1006,13 +1006,14 @@ static int circ_call_mt(const cm_params *P, int32_t window_size, uint32_t n_cont
     std::vector<Call> calls;
     uint64_t n_rows = 0;
     int rc = CM_OK;
+    bool io_bad = false;
     for (Chunk &ck : chunks) {
         if (ck.err) rc = CM_ELIMIT;
-        fwrite(ck.rows.data(), 1, ck.rows.size(), fc);
+        if (fwrite(ck.rows.data(), 1, ck.rows.size(), fc) != ck.rows.size()) io_bad = true;      // full disk: not a silent short file
         n_rows += (uint64_t)std::count(ck.rows.begin(), ck.rows.end(), '\n');
         calls.insert(calls.end(), ck.calls.begin(), ck.calls.end());
     }
-    fclose(fc);
+    if (fclose(fc) != 0 || io_bad) return CM_EIO;
     std::vector<cm_circ_res> res(calls.size());
     for (size_t i = 0; i < calls.size(); ++i) {
         const Call &c = calls[i];

@@ -12,12 +12,14 @@
 // batch goes to cm_reads_upload without another copy; with cm_host_alloc'ed staging the copy is one DMA.
 // Deliberately defined where the reference has undefined behaviour: names shorter than 2 characters are not
 // inspected for the "/x" suffix, header lines with more than 23 tokens are treated like fresh reads.
+#include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -53,19 +55,30 @@ struct Stream {
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
+    bool io_error = false;                   // a read failed (not: reached the end): the batch in flight is CM_EIO, not a short file
     bool open(const char *path) {
-        FILE *t = fopen(path, "rb");
-        if (!t) return false;
+        const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return false;
+        struct stat sb;
         unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, t);
-        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {          // gzip: one inflate stream, the record-by-record path
-            fclose(t);
-            gz = gzopen(path, "r");
-            if (!gz) return false;
+        // Only a regular file can be sniffed and read with pread(); a FIFO, a process substitution or /dev/stdin goes to zlib on
+        // the same descriptor, which reads plain and gzip streams alike (what the reference's gzopen / gzread does for every
+        // input, src/fastq_parser.cpp:60,85).
+        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+        const bool gzip = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (!regular || gzip) {                                           // one (inflate) stream, the record-by-record path
+            gz = gzdopen(fd, "r");
+            if (!gz) {
+                ::close(fd);
+                return false;
+            }
             gzbuffer(gz, 1u << 20);
         } else {
-            rewind(t);
-            plain = t;
+            plain = fdopen(fd, "rb");
+            if (!plain) {
+                ::close(fd);
+                return false;
+            }
         }
         buf.resize(BLOCK);
         return true;
@@ -80,17 +93,27 @@ struct Stream {
     int read_threads = 1;
     int read_some(char *dst, size_t cap) {
         if (cap > (1u << 30)) cap = 1u << 30;
-        if (!plain) return gzread(gz, dst, (unsigned)cap);
+        if (!plain) {
+            const int r = gzread(gz, dst, (unsigned)cap);
+            if (r < 0) io_error = true;
+            return r;
+        }
         // page-cache -> buffer copies are what a read() of a hot file is: several pread()s side by side
         const int fd = fileno(plain);
         const int nt = (read_threads > 1 && cap >= (8u << 20)) ? read_threads : 1;
         std::vector<long> got((size_t)nt, 0);
+        std::vector<char> failed((size_t)nt, 0);
         auto piece = [&](int t) {
             const size_t a = cap * (size_t)t / (size_t)nt, b = cap * (size_t)(t + 1) / (size_t)nt;
             size_t done = 0;
             while (a + done < b) {
                 const ssize_t r = pread(fd, dst + a + done, b - a - done, (off_t)(file_pos + a + done));
-                if (r <= 0) break;
+                if (r < 0) {                       // an I/O error is not the end of the file
+                    if (errno == EINTR) continue;
+                    failed[(size_t)t] = 1;
+                    break;
+                }
+                if (r == 0) break;
                 done += (size_t)r;
             }
             got[(size_t)t] = (long)done;
@@ -101,6 +124,11 @@ struct Stream {
             for (int t = 0; t < nt; ++t) th.emplace_back(piece, t);
             for (auto &x : th) x.join();
         }
+        for (int t = 0; t < nt; ++t)
+            if (failed[(size_t)t]) {
+                io_error = true;
+                return -1;
+            }
         size_t total = 0;
         for (int t = 0; t < nt; ++t) {              // contiguous prefix that was actually read (a short piece means end of file)
             const size_t want = cap * (size_t)(t + 1) / (size_t)nt - cap * (size_t)t / (size_t)nt;
@@ -290,9 +318,8 @@ void state_from_header(const cm_fastq *f, int nt, const char *const *tok, const 
 int parse_record(cm_fastq *f, Stream &s, Side &side, bool want_state, cm_mapped_read *st, bool *carried) {
     const char *p;
     size_t len;
-    if (!s.line(p, len)) return 0;
-    if (len == 0 && s.eof && s.pos >= s.end) return 0;
-    if (len == 0 || p[0] != '@') return -1;                       // has_next asserts the '@'
+    if (!s.line(p, len)) return s.io_error ? -1 : 0;
+    if (len == 0 || p[0] != '@') return -1;                       // has_next asserts the '@' (fastq_parser.h:64-65): blank lines at the end are malformed too
     const char *tok[FQCOMMENTCNT + 1];
     size_t tl[FQCOMMENTCNT + 1];
     const int nt = split_header(p, len, tok, tl);
@@ -337,7 +364,7 @@ template <class F> void par_for(int nt, size_t n, F f) {       // f(thread, begi
 
 // makes sure s.buf[s.pos .. s.end) holds at least `want` complete records (or everything up to end of input); nl = offsets
 // (relative to s.pos) of the line ends of those bytes.  Returns the number of complete records available.
-size_t fill_and_index(Stream &s, std::vector<size_t> &nl, size_t want, size_t bytes_hint, int nt) {
+size_t fill_and_index(Stream &s, std::vector<size_t> &nl, size_t want, size_t bytes_hint, int nt, size_t *tail_lines) {
     s.read_threads = nt;
     if (s.pos > 0) {                                              // drop what the previous batch consumed
         memmove(s.buf.data(), s.buf.data() + s.pos, s.end - s.pos);
@@ -366,6 +393,7 @@ size_t fill_and_index(Stream &s, std::vector<size_t> &nl, size_t want, size_t by
         }
         size_t lines = nl.size();
         if (s.eof && s.end > 0 && (nl.empty() || nl.back() != s.end - 1)) ++lines;     // last line without a newline
+        if (tail_lines) *tail_lines = s.eof ? lines % 4 : 0;                           // lines behind the last whole record of the input
         if (lines / 4 >= want || s.eof) return lines / 4;
         // more input: room for the rest of the estimate (at least one block)
         size_t need = std::max<size_t>(BLOCK, bytes_hint > s.end ? bytes_hint - s.end : BLOCK);
@@ -458,7 +486,7 @@ bool build_side(cm_fastq *f, Stream &s, const std::vector<size_t> &nl, size_t n,
 }
 
 // cm_fastq_next for two plain-text files; *n_out pairs
-int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_out) {
+int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_out, uint64_t *n2_out) {
     int nt = f->n_threads > 0 ? f->n_threads : (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("CM_FASTQ_THREADS")) nt = atoi(e);
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
@@ -474,31 +502,32 @@ int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_ou
             if (left < hint) hint = (size_t)left;
         }
     }
-    size_t a1 = 0, a2 = 0;
+    size_t a1 = 0, a2 = 0, tail1 = 0, tail2 = 0;
     const bool trace = getenv("CM_FASTQ_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     {   // the two files are filled and indexed side by side
-        std::thread t2([&]() { a2 = fill_and_index(f->s2, f->nl2, (size_t)max_pairs, hint, half); });
-        a1 = fill_and_index(f->s1, f->nl1, (size_t)max_pairs, hint, half);
+        std::thread t2([&]() { a2 = fill_and_index(f->s2, f->nl2, (size_t)max_pairs, hint, half, &tail2); });
+        a1 = fill_and_index(f->s1, f->nl1, (size_t)max_pairs, hint, half, &tail1);
         t2.join();
     }
+    if (f->s1.io_error || f->s2.io_error) return CM_EIO;
     if (a2 < a1 && a2 < max_pairs) return CM_EINVAL;                  // R2 ends before R1
     const size_t n = (size_t)std::min<uint64_t>(a1, max_pairs);      // R1 decides; surplus R2 records at the end of input are ignored
+    // R2 records beyond R1's last (only at the end of the input) are parsed too, as the record-by-record parser does, and cut
+    // off by the caller: a malformed one among them is an error there, so it is one here
+    const size_t n2 = (size_t)std::min<uint64_t>(a2, max_pairs);
     *n_out = n;
-    if (n == 0) {
-        // a trailing partial record is malformed input unless the stream is simply empty
-        if (f->s1.eof && f->s1.end > f->s1.pos) {
-            size_t k = f->s1.pos;
-            while (k < f->s1.end && f->s1.buf[k] == '\n') ++k;
-            if (k < f->s1.end) return CM_EINVAL;
-        }
-        return CM_OK;
-    }
+    *n2_out = n2;
+    // The same verdicts, in the same call, as the record-by-record parser (gzip / pipe input): what follows the last whole
+    // record -- a partial record, blank lines -- is malformed input (the reference asserts the '@', fastq_parser.h:64-65), and it
+    // is reported by the call that would have parsed it, i.e. unless this batch is full without it.
+    if ((tail1 != 0 && a1 < max_pairs) || (tail2 != 0 && a2 < max_pairs)) return CM_EINVAL;
+    if (n == 0 && n2 == 0) return CM_OK;
     bool ok1 = true, ok2 = true, any = false;
     const auto t_mid = std::chrono::steady_clock::now();
     {
-        std::thread t2([&]() { ok2 = build_side(f, f->s2, f->nl2, n, G.b, nullptr, nullptr, half); });
-        ok1 = build_side(f, f->s1, f->nl1, n, G.a, &G.prior, &any, half);
+        std::thread t2([&]() { ok2 = n2 == 0 || build_side(f, f->s2, f->nl2, n2, G.b, nullptr, nullptr, half); });
+        ok1 = n == 0 || build_side(f, f->s1, f->nl1, n, G.a, &G.prior, &any, half);
         t2.join();
     }
     if (!ok1 || !ok2) return CM_EINVAL;
@@ -598,16 +627,16 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     G.b.clear();
     G.prior.clear();
     f->any_prior = false;
-    uint64_t n_fast = 0;
+    uint64_t n_fast = 0, n2_fast = 0;
     const bool fast = f->s1.plain && f->s2.plain && !getenv("CM_FASTQ_SERIAL");
     if (fast) {
-        const int rc = next_plain(f, max_pairs, G, &n_fast);
+        const int rc = next_plain(f, max_pairs, G, &n_fast, &n2_fast);
         if (rc != CM_OK) return rc;
     }
     // The two files are independent streams until the records are paired up: R2 is parsed (and, for .gz input, inflated)
     // on a second thread while this one does R1 and its carried state.  The reference does both inside one lock-protected
     // serial section (src/circminer.cpp:373-379), which is its ingest ceiling.
-    uint64_t n = fast ? n_fast : 0, n2 = fast ? n_fast : 0;
+    uint64_t n = fast ? n_fast : 0, n2 = fast ? n2_fast : 0;
     int bad2 = 0;
     std::thread side_b([&]() {
         while (!fast && n2 < max_pairs) {
@@ -635,6 +664,7 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
         ++n;
     }
     side_b.join();
+    if (f->s1.io_error || f->s2.io_error) return CM_EIO;
     if (bad1 || bad2 || n2 < n) return CM_EINVAL;                   // malformed record, or R2 ends before R1
     if (n2 > n) {        // R1 ended first: like the reference, which stops at R1's end, the surplus R2 records are not paired
         G.b.off.resize(n + 1);

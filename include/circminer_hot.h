@@ -44,7 +44,7 @@ enum {
     CM_EHIP = -4,       /* a HIP runtime call or kernel failed                          */
     CM_ESTATE = -5,     /* contig / annotation not loaded                               */
     CM_ELIMIT = -6,     /* a documented capacity limit of the device path was exceeded  */
-    CM_EIO = -7         /* a write to an output file failed (disk full, ...)            */
+    CM_EIO = -7         /* a read from an input file or a write to an output file failed */
 };
 
 #define CM_WINDOW_SIZE 14          /* WINDOW_SIZE, src/common.cpp:7                         */

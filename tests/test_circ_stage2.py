@@ -89,6 +89,15 @@ def test_circ_report_rows(built, tmp_path):
     assert {r[7] for r in rows} == {"Pass", "Fail"}
     cl.circ_report([], path)
     assert open(path).read() == ""
+    # a full device is an error (CM_EIO), not a silently truncated report; the sorted remain file likewise
+    import os
+    if os.path.exists("/dev/full"):
+        with pytest.raises(RuntimeError):
+            cl.circ_report(calls, "/dev/full")
+        fq = str(tmp_path / "x.fastq")
+        open(fq, "w").write("".join(f"@r{i} {1000 - i} 3 chr1\nACGT\n+\nIIII\n" for i in range(50000)))
+        with pytest.raises(RuntimeError):
+            cl.sort_remain(fq, "/dev/full")
 
 
 def test_regional_hash_table(built):

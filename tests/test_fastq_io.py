@@ -2,6 +2,7 @@
 (circminer_amd/csrc/host_fastq.cpp) against Python restatements of the reference's formats
 (src/fastq_parser.cpp:178-269, src/filter.cpp:413-455, src/output.cpp:118-333)."""
 import gzip
+import os
 
 import numpy as np
 import pytest
@@ -346,3 +347,86 @@ def test_write_errors_are_reported(built, tmp_path):
     w.write_pam(b, st)
     w.close()
     rd.close()
+
+
+def _call_log(r1, r2, batch, serial, monkeypatch):
+    """(pairs or 'error') of every cm_fastq_next call until the end of input or the first error"""
+    if serial:
+        monkeypatch.setenv("CM_FASTQ_SERIAL", "1")
+    else:
+        monkeypatch.delenv("CM_FASTQ_SERIAL", raising=False)
+    rd = cl.FastqReader(r1, r2, CHRS, 4)
+    log = []
+    while True:
+        try:
+            b = rd.next_batch(batch)
+        except RuntimeError:
+            log.append("error")
+            break
+        if b is None:
+            break
+        log.append(b.n)
+    rd.close()
+    return log
+
+
+@pytest.mark.parametrize("tail", ["\n", "\n\n\n", "\n\n\n\n", "@partial\nACGT\n", "@partial\nACGT\n+\n"])
+def test_trailing_garbage_is_refused_alike_by_both_parsers(built, tmp_path, monkeypatch, tail):
+    """What follows the last whole record (blank lines, a partial record) is malformed: the reference asserts the '@' of the next
+    record (src/fastq_parser.h:64-65).  The chunk-parallel plain-text path and the record-by-record path (gzip / pipes) give
+    the same verdict in the same cm_fastq_next call, for any batch size, on either mate's file."""
+    rng = np.random.default_rng(5)
+    n = 40
+    seqs, quals = _rand_reads(rng, n, 30, 151)
+    names = [f"r{i}" for i in range(n)]
+    good, dirty = str(tmp_path / "good.fq"), str(tmp_path / "dirty.fq")
+    _fastq(good, names, seqs, quals)
+    _fastq(dirty, names, seqs, quals)
+    with open(dirty, "a") as f:
+        f.write(tail)
+    for r1, r2 in ((dirty, good), (good, dirty)):
+        for batch in (n + 5, n, 16, 7):
+            fast = _call_log(r1, r2, batch, False, monkeypatch)
+            slow = _call_log(r1, r2, batch, True, monkeypatch)
+            assert fast == slow, (r1 == dirty, batch, fast, slow)
+            assert fast[-1] == "error"
+
+
+def test_fifo_and_gzip_fifo_input(built, tmp_path):
+    """Non-seekable input (named pipe, process substitution, /dev/stdin) is read through zlib on the open descriptor, plain text
+    and gzip alike, as the reference's gzopen / gzread does for every input (src/fastq_parser.cpp:60,85) -- no magic sniff,
+    no pread(), no reopening."""
+    import gzip
+    import threading
+    rng = np.random.default_rng(8)
+    n = 3000
+    seqs, quals = _rand_reads(rng, n, 30, 151)
+    names = [f"r{i}" for i in range(n)]
+    plain = str(tmp_path / "p.fq")
+    _fastq(plain, names, seqs, quals)
+    data = open(plain, "rb").read()
+    for payload in (data, gzip.compress(data, 1)):
+        f1, f2 = str(tmp_path / "f1"), str(tmp_path / "f2")
+        for f in (f1, f2):
+            if os.path.exists(f):
+                os.unlink(f)
+            os.mkfifo(f)
+
+        def feed(path):
+            with open(path, "wb") as w:
+                w.write(payload)
+
+        th = [threading.Thread(target=feed, args=(f,)) for f in (f1, f2)]
+        [t.start() for t in th]
+        rd = cl.FastqReader(f1, f2, CHRS, 4)
+        got = 0
+        while True:
+            b = rd.next_batch(1024)
+            if b is None:
+                break
+            assert [b.seq(i) for i in (0, b.n - 1)] == [seqs[got].encode(), seqs[got + b.n - 1].encode()]
+            assert b.name(b.n - 1, 2) == names[got + b.n - 1]
+            got += b.n
+        rd.close()
+        [t.join() for t in th]
+        assert got == n

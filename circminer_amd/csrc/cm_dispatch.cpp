@@ -33,6 +33,9 @@ CM_VARIANTS(int, cm_collect_records, (void *, uint64_t, uint64_t, cm_record *, u
 CM_VARIANTS(int, cm_collect_records_device, (void *, uint64_t, uint64_t, void *, uint64_t *))
 CM_VARIANTS(int, cm_host_alloc, (void *, uint64_t, void **))
 CM_VARIANTS(int, cm_host_free, (void *, void *))
+CM_VARIANTS(int, cm_host_register, (void *, void *, uint64_t))
+CM_VARIANTS(int, cm_host_unregister, (void *, void *))
+CM_VARIANTS(int, cm_type_histogram, (void *, uint64_t *))
 CM_VARIANTS(int, cm_reads_download, (void *, cm_mapped_read *, int32_t *, uint8_t *))
 CM_VARIANTS(int, cm_map_batch, (void *, int, int, const cm_reads *, const cm_mapped_read *, cm_mapped_read *, int32_t *))
 CM_VARIANTS(int, cm_seed_batch, (void *, int, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *))
@@ -85,6 +88,9 @@ int cm_collect_records_device(cm_ctx *ctx, uint64_t base, uint64_t cap, void *d_
 }
 int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out) { return ctx ? GO(cm_host_alloc, bytes, out) : CM_EINVAL; }
 int cm_host_free(cm_ctx *ctx, void *p) { return ctx ? GO(cm_host_free, p) : CM_EINVAL; }
+int cm_host_register(cm_ctx *ctx, void *p, uint64_t bytes) { return ctx ? GO(cm_host_register, p, bytes) : CM_EINVAL; }
+int cm_host_unregister(cm_ctx *ctx, void *p) { return ctx ? GO(cm_host_unregister, p) : CM_EINVAL; }
+int cm_type_histogram(cm_ctx *ctx, uint64_t out[14]) { return ctx ? GO(cm_type_histogram, out) : CM_EINVAL; }
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *st, int32_t *cat, uint8_t *act) { return ctx ? GO(cm_reads_download, st, cat, act) : CM_EINVAL; }
 int cm_map_batch(cm_ctx *ctx, int slot, int is_last, const cm_reads *reads, const cm_mapped_read *prior, cm_mapped_read *st, int32_t *cat) {
     return ctx ? GO(cm_map_batch, slot, is_last, reads, prior, st, cat) : CM_EINVAL;

@@ -1154,6 +1154,18 @@ __global__ void __launch_bounds__(BLK) k_gather_records(const uint32_t *perm, co
     out[i].state = state[p];
 }
 
+// final MatchedRead::type histogram of a batch (cm_type_histogram): block-private counts in LDS, 14 atomics per block
+__global__ void __launch_bounds__(BLK) k_type_hist(const cm_mapped_read *state, uint64_t n, unsigned long long *hist) {
+    __shared__ unsigned int h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const int t = state[i].type;
+        if (t >= 0 && t < 14) atomicAdd(&h[t], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 14 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
 __global__ void k_err_clear(int *err, int mask) {
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAnd(err, ~mask);
 }
@@ -1267,6 +1279,7 @@ struct cm_ctx {
     unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
     uint32_t *d_hlist = nullptr;
     HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
+    unsigned long long *d_type_hist = nullptr;
     uint32_t *d_pair_err = nullptr, *d_retry_list = nullptr;      // per-pair capacity flags of a tile (zero between launches), pairs to re-run (RetryArgs)
     cmc::MemoSpill *d_spill = nullptr;                            // RETRY_GRID x 64 lanes x RETRY_SPILL overflow entries of the extension memo
     uint8_t *d_pool = nullptr;
@@ -1340,7 +1353,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill);
+    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
@@ -2387,6 +2400,35 @@ int cm_host_free(cm_ctx *ctx, void *p) {
     if (!ctx) return CM_EINVAL;
     if (p) HIPCHK(ctx, hipHostFree(p));
     return CM_OK;
+}
+
+int cm_host_register(cm_ctx *ctx, void *p, uint64_t bytes) {
+    if (!ctx || !p || !bytes) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return CM_OK;
+}
+
+int cm_host_unregister(cm_ctx *ctx, void *p) {
+    if (!ctx) return CM_EINVAL;
+    if (p) HIPCHK(ctx, hipHostUnregister(p));
+    return CM_OK;
+}
+
+int cm_type_histogram(cm_ctx *ctx, uint64_t out[14]) {
+    if (!ctx || !out) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    for (int i = 0; i < 14; ++i) out[i] = 0;
+    if (ctx->n_pairs == 0) return CM_OK;
+    HIPCHK(ctx, ensure(ctx, ctx->d_type_hist, 16 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_type_hist, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    const unsigned grid = (unsigned)std::min<uint64_t>((ctx->n_pairs + BLK - 1) / BLK, 1024);
+    hipLaunchKernelGGL(k_type_hist, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->d_state, ctx->n_pairs, ctx->d_type_hist);
+    unsigned long long h[16];
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_type_hist, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 14; ++i) out[i] = h[i];
+    return check_dev_err(ctx);
 }
 
 int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_category, uint8_t *out_active) {

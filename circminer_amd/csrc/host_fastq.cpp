@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cerrno>
 #include <cinttypes>
@@ -90,6 +91,7 @@ struct Stream {
         plain = nullptr;
     }
     uint64_t file_pos = 0;                   // plain: offset of the next unread byte
+    uint64_t file_end = ~0ull;               // plain: this reader's share of the file ends here (cm_fastq_open_shard)
     int read_threads = 1;
     int read_some(char *dst, size_t cap) {
         if (cap > (1u << 30)) cap = 1u << 30;
@@ -100,6 +102,8 @@ struct Stream {
         }
         // page-cache -> buffer copies are what a read() of a hot file is: several pread()s side by side
         const int fd = fileno(plain);
+        if (file_pos >= file_end) return 0;
+        if ((uint64_t)cap > file_end - file_pos) cap = (size_t)(file_end - file_pos);
         const int nt = (read_threads > 1 && cap >= (8u << 20)) ? read_threads : 1;
         std::vector<long> got((size_t)nt, 0);
         std::vector<char> failed((size_t)nt, 0);
@@ -229,13 +233,14 @@ struct Side {
 
 struct cm_fastq {
     Stream s1, s2;
-    // three generations of batch storage, used in turn: the batch a call returns stays valid over the next two calls, so a
-    // caller can have batch k-1 with its writer thread, batch k on the GPU and batch k+1 in the parser at the same time
+    // four generations of batch storage, used in turn: the batch a call returns stays valid over the next three calls, so a
+    // caller can have batch k-1 with its writer thread, batch k on the GPU, batch k+1 staged (its H2D copy in flight) and
+    // batch k+2 in the parser at the same time
     struct Gen {
         Side a, b;
         RawVec<cm_mapped_read> prior;
-    } gen[3];
-    int cur = 2;
+    } gen[4];
+    int cur = 3;
     int n_threads = 0;                       // tokeniser threads of the plain-text path (0 = hardware concurrency, at most 32)
     std::vector<size_t> nl1, nl2;            // newline index of the two block buffers (plain-text path)
     std::vector<std::string> chr_names;
@@ -619,9 +624,118 @@ int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *c
     return CM_OK;
 }
 
+// Byte offsets at which the records `rec[0..n)` (4 lines each) of a plain-text FASTQ file start: the newlines of the file are
+// counted in blocks on several threads, then the block holding the wanted newline is looked at again.  A record index equal to
+// the number of records maps to the end of the file.  Returns the number of records, or -1 on a read error.
+static long long record_offsets(int fd, uint64_t size, const uint64_t *rec, int n, uint64_t *off, int nt) {
+    constexpr uint64_t BLK = 32ull << 20;
+    const uint64_t nblk = (size + BLK - 1) / BLK;
+    std::vector<uint64_t> cnt(nblk + 1, 0);
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> bad{0};
+    auto read_blk = [&](uint64_t b, std::vector<char> &buf) -> size_t {
+        const uint64_t a = b * BLK, e = std::min(size, a + BLK);
+        buf.resize((size_t)(e - a));
+        size_t done = 0;
+        while (done < buf.size()) {
+            const ssize_t r = pread(fd, buf.data() + done, buf.size() - done, (off_t)(a + done));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) {
+                bad = 1;
+                return 0;
+            }
+            done += (size_t)r;
+        }
+        return done;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < std::max(1, nt); ++t)
+        th.emplace_back([&]() {
+            std::vector<char> buf;
+            for (uint64_t b; (b = next.fetch_add(1)) < nblk;) {
+                const size_t got = read_blk(b, buf);
+                cnt[b + 1] = (uint64_t)std::count(buf.data(), buf.data() + got, '\n');
+            }
+        });
+    for (auto &x : th) x.join();
+    if (bad) return -1;
+    for (uint64_t b = 0; b < nblk; ++b) cnt[b + 1] += cnt[b];
+    uint64_t lines = cnt[nblk];
+    if (size > 0) {                                   // a last line without a newline still is a line
+        char last = 0;
+        if (pread(fd, &last, 1, (off_t)(size - 1)) != 1) return -1;
+        if (last != '\n') ++lines;
+    }
+    const uint64_t n_rec = lines / 4;
+    std::vector<char> buf;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t want = rec[i] * 4;             // the record starts behind the want-th newline
+        if (rec[i] >= n_rec) {
+            off[i] = size;
+            continue;
+        }
+        if (want == 0) {
+            off[i] = 0;
+            continue;
+        }
+        const uint64_t b = (uint64_t)(std::lower_bound(cnt.begin(), cnt.end(), want) - cnt.begin()) - 1;     // cnt[b] < want <= cnt[b + 1]
+        const size_t got = read_blk(b, buf);
+        if (bad) return -1;
+        uint64_t seen = cnt[b];
+        size_t k = 0;
+        for (; k < got; ++k)
+            if (buf[k] == '\n' && ++seen == want) break;
+        off[i] = b * BLK + k + 1;
+    }
+    return (long long)n_rec;
+}
+
+int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed, int32_t rank,
+                        int32_t world, int n_threads, cm_fastq **out, uint64_t *first_pair, uint64_t *n_pairs) {
+    if (world < 1 || rank < 0 || rank >= world) return CM_EINVAL;
+    const int rc = cm_fastq_open(r1_path, r2_path, chrs, n_chr, max_ed, out);
+    if (rc != CM_OK) return rc;
+    cm_fastq *f = *out;
+    if (first_pair) *first_pair = 0;
+    if (n_pairs) *n_pairs = ~0ull;
+    if (world == 1 && !n_pairs) return CM_OK;
+    auto fail = [&](int e) {
+        cm_fastq_close(f);
+        *out = nullptr;
+        return e;
+    };
+    // contiguous blocks of pairs need both files cut at the same RECORD: seekable plain text only (gzip members cannot be entered
+    // in the middle, a pipe cannot be read twice)
+    if (!f->s1.plain || !f->s2.plain) return world == 1 ? CM_OK : fail(CM_EINVAL);
+    struct stat sa, sb;
+    if (fstat(fileno(f->s1.plain), &sa) != 0 || fstat(fileno(f->s2.plain), &sb) != 0) return fail(CM_EIO);
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+    // number of records first (R1 decides, as everywhere), then this rank's [lo, hi) in both files
+    uint64_t none = 0, dummy = 0;
+    const long long n1 = record_offsets(fileno(f->s1.plain), (uint64_t)sa.st_size, &none, 0, &dummy, nt);
+    if (n1 < 0) return fail(CM_EIO);
+    const uint64_t lo = (uint64_t)n1 * (uint64_t)rank / (uint64_t)world, hi = (uint64_t)n1 * (uint64_t)(rank + 1) / (uint64_t)world;
+    const uint64_t want[2] = {lo, hi};
+    uint64_t o1[2], o2[2];
+    if (record_offsets(fileno(f->s1.plain), (uint64_t)sa.st_size, want, 2, o1, nt) < 0) return fail(CM_EIO);
+    const long long n2 = record_offsets(fileno(f->s2.plain), (uint64_t)sb.st_size, want, 2, o2, nt);
+    if (n2 < 0) return fail(CM_EIO);
+    if ((uint64_t)n2 < hi) return fail(CM_EINVAL);                                      // R2 ends before R1
+    f->s1.file_pos = o1[0];
+    f->s2.file_pos = o2[0];
+    // the last rank reads to the end of both files, so that what follows the last whole record is seen (and refused) as in an
+    // unsharded run; R2's surplus records, if any, stay with it too
+    f->s1.file_end = rank == world - 1 ? ~0ull : o1[1];
+    f->s2.file_end = rank == world - 1 ? ~0ull : o2[1];
+    if (first_pair) *first_pair = lo;
+    if (n_pairs) *n_pairs = hi - lo;
+    return CM_OK;
+}
+
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     if (!f || !out) return CM_EINVAL;
-    f->cur = (f->cur + 1) % 3;
+    f->cur = (f->cur + 1) % 4;
     cm_fastq::Gen &G = f->gen[f->cur];
     G.a.clear();
     G.b.clear();
@@ -722,13 +836,14 @@ int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs
 static const char *chr_name(const cm_writer *w, int id) { return (id >= 0 && (size_t)id < w->chr_names.size()) ? w->chr_names[(size_t)id].c_str() : "-"; }
 
 // write_read_category (PE) for the selected pairs of a batch; sel == NULL selects every pair
-int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel) {
-    if (!w || !w->f2 || !b || !states) return CM_EINVAL;
-    const uint64_t n = sel ? n_sel : b->reads.n_pairs;
+}  // extern "C"
+// write_read_category for n pairs: pair(k) = index in the batch, state(k) = its MatchedRead
+template <class PairOf, class StateOf>
+static int write_remain_rows(cm_writer *w, const cm_fastq_batch *b, uint64_t n, PairOf pair, StateOf state) {
     for (uint64_t k = 0; k < n; ++k) {
-        const uint64_t i = sel ? sel[k] : k;
+        const uint64_t i = pair(k);
         if (i >= b->reads.n_pairs) return CM_EINVAL;
-        const cm_mapped_read &m = states[i];
+        const cm_mapped_read &m = state(k);
         Out *os[2] = {&w->o1, &w->o2};
         for (int s = 0; s < 2; ++s) {
             Out &o = *os[s];
@@ -777,6 +892,18 @@ int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read 
         }
     }
     return (w->o1.failed || w->o2.failed) ? CM_EIO : CM_OK;
+}
+
+extern "C" {
+int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel) {
+    if (!w || !w->f2 || !b || !states) return CM_EINVAL;
+    return write_remain_rows(w, b, sel ? n_sel : b->reads.n_pairs, [&](uint64_t k) { return sel ? sel[k] : k; },
+                             [&](uint64_t k) -> const cm_mapped_read & { return states[sel ? sel[k] : k]; });
+}
+
+int cm_write_remain_records(cm_writer *w, const cm_fastq_batch *b, const cm_record *recs, uint64_t n) {
+    if (!w || !w->f2 || !b || (n && !recs)) return CM_EINVAL;
+    return write_remain_rows(w, b, n, [&](uint64_t k) { return recs[k].pair; }, [&](uint64_t k) -> const cm_mapped_read & { return recs[k].state; });
 }
 
 // write_pam_rec_pe for the selected pairs (names of R1)

@@ -14,8 +14,14 @@
 // A pair retired in round r is left untouched by later rounds (cm_map_round), so its final state is the one the
 // reference printed in round r.
 //
-// Three batches are in flight: batch k-1's rows are being written by a worker thread, batch k is on the GPU, batch k+1
-// is being parsed (cm_fastq_next keeps three generations of storage).
+// Four batches are in flight: batch k-1's rows are being written by a worker thread, batch k is on the GPU, batch k+1 is staged
+// (copied over PCIe on the copy stream out of page-locked parser buffers; its first round is seeded and chained under batch k's
+// last pair stage, cm_map_rounds) and batch k+2 is being parsed on another worker thread (cm_fastq_next keeps four generations).
+// Only what the rows need leaves the device: with report 0 (the reference's default, src/commandline_parser.cpp:26) that is the
+// (pair, state) records of the re-queued pairs and a 14-bin type histogram.
+//
+// One process per GPU: rank r of w maps the r-th contiguous block of pairs (cm_fastq_open_shard) and writes .part<r> files;
+// cm_merge_parts on rank 0 concatenates them in rank order -- the bytes one process would have written.
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -57,6 +63,9 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     const double t0 = now();
     const int n_threads = a->n_threads > 0 ? a->n_threads : 1;
     const uint64_t batch_pairs = a->batch_pairs ? a->batch_pairs : (1ull << 18);
+    const int world = a->world > 1 ? a->world : 1, rank = a->world > 1 ? a->rank : 0;
+    if (rank < 0 || rank >= world) return fail(CM_EINVAL, "rank %d of %d", a->rank, a->world);
+    const std::string part = world > 1 ? ".part" + std::to_string(rank) : "";
 
     cm_chr_info *chrs = nullptr;
     uint32_t n_chr = 0;
@@ -71,8 +80,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         std::vector<cm_mapped_read> state;
         std::vector<uint8_t> active;
         std::vector<uint64_t> sel;
+        std::vector<cm_record> recs;
+        uint64_t n_rec = 0;
         cm_fastq_batch batch;
     } res[2];
+    std::vector<std::pair<void *, uint64_t>> pinned;            // parser arrays registered with the runtime (cm_host_register)
     std::thread writer, parser;
     int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
@@ -81,6 +93,9 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         if (writer.joinable()) writer.join();
         if (w_map) cm_writer_close(w_map);
         if (w_rem) cm_writer_close(w_rem);
+        if (cm) (void)cm_sync(cm);                             // no copy out of the parser's arrays is in flight any more
+        for (auto &pr : pinned) (void)cm_host_unregister(cm, pr.first);
+        pinned.clear();
         if (fq) cm_fastq_close(fq);
         if (cm) cm_destroy(cm);
         if (!annots.empty()) cm_host_free_annotation(annots.data(), (uint32_t)annots.size());
@@ -154,59 +169,104 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     // ---- outputs (FilterRead::init, src/filter.cpp:34-84; SAMOutput::init) ----
     const std::string out = a->out_prefix;
     if (a->report) {
-        const std::string path = out + (a->report == 2 ? ".mapping.sam" : ".mapping.pam");
+        const std::string path = out + (a->report == 2 ? ".mapping.sam" : ".mapping.pam") + part;
         MAP_TRY(cm_writer_open(path.c_str(), nullptr, chrs, n_chr, &w_map), "cm_writer_open (mapping)");
-        if (a->report == 2) MAP_TRY(cm_write_sam_header(w_map), "cm_write_sam_header");
+        if (a->report == 2 && rank == 0) MAP_TRY(cm_write_sam_header(w_map), "cm_write_sam_header");      // one header: rank 0's part comes first
     }
     {
-        const std::string r1 = out + "_" + std::to_string(n_con) + "_remain_R1.fastq", r2 = out + "_" + std::to_string(n_con) + "_remain_R2.fastq";
+        const std::string r1 = out + "_" + std::to_string(n_con) + "_remain_R1.fastq" + part, r2 = out + "_" + std::to_string(n_con) + "_remain_R2.fastq" + part;
         MAP_TRY(cm_writer_open(r1.c_str(), r2.c_str(), chrs, n_chr, &w_rem), "cm_writer_open (remain)");
     }
-    MAP_TRY(cm_fastq_open(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, &fq), "cm_fastq_open");
+    MAP_TRY(cm_fastq_open_shard(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, rank, world, n_threads, &fq, nullptr, nullptr), "cm_fastq_open_shard");
 
-    // ---- batches: write k-1 (worker thread) | all rounds of k (device, driven by this thread) | parse k+1 (worker thread) ----
+    // ---- batches: write k-1 (worker) | rounds of k (device, driven by this thread) | H2D + first round of k+1 | parse k+2 (worker) ----
     const double t1 = now();
-    cm_fastq_batch cur, nxt;
+    std::vector<int> all(n_con);
+    for (uint32_t c = 0; c < n_con; ++c) all[c] = (int)c;
+    // page-lock the parser's arrays of a batch (they are reused every fourth batch; re-registered only when one has moved or grown)
+    auto pin_batch = [&](const cm_fastq_batch &b) -> int {
+        const uint64_t n = b.reads.n_pairs;
+        const void *ptr[4] = {b.reads.seq1, b.reads.seq2, b.reads.off1, b.reads.off2};
+        const uint64_t bytes[4] = {b.reads.off1[n], b.reads.off2[n], (n + 1) * sizeof(uint64_t), (n + 1) * sizeof(uint64_t)};
+        for (int j = 0; j < 4; ++j) {
+            if (!bytes[j]) continue;
+            bool have = false;
+            for (auto it = pinned.begin(); it != pinned.end();) {
+                const char *lo = (const char *)it->first, *hi = lo + it->second, *p = (const char *)ptr[j];
+                if (p >= lo && p + bytes[j] <= hi) {
+                    have = true;
+                    break;
+                }
+                if (p < hi && p + bytes[j] > lo) {                    // overlaps a stale registration: drop that one
+                    (void)cm_host_unregister(cm, it->first);
+                    it = pinned.erase(it);
+                } else ++it;
+            }
+            if (have) continue;
+            if (cm_host_register(cm, (void *)ptr[j], bytes[j]) == CM_OK) pinned.emplace_back((void *)ptr[j], bytes[j]);
+            // (a failed registration is not an error: the copy is then a staged pageable one)
+        }
+        return CM_OK;
+    };
+    cm_fastq_batch cur, nxt, nn;
+    memset(&nxt, 0, sizeof nxt);
+    memset(&nn, 0, sizeof nn);
     double write_s = 0.0;                                       // written by the writer thread, read after its join
     {
         const double tp = now();
         MAP_TRY(cm_fastq_next(fq, batch_pairs, &cur), "cm_fastq_next");
+        if (cur.reads.n_pairs) MAP_TRY(cm_fastq_next(fq, batch_pairs, &nxt), "cm_fastq_next");
         st.seconds_parse += now() - tp;
+    }
+    if (cur.reads.n_pairs) {
+        pin_batch(cur);
+        MAP_TRY(cm_reads_stage(cm, &cur.reads, cur.prior), "cm_reads_stage");
+        MAP_TRY(cm_reads_swap(cm), "cm_reads_swap");
     }
     for (uint64_t k = 0; cur.reads.n_pairs; ++k) {
         const uint64_t n = cur.reads.n_pairs;
         Result &R = res[k & 1];
-        // cm_map_rounds keeps this thread busy for most of the device time (the chain stage reads two words back per round), so
-        // the next batch is tokenised on a thread of its own meanwhile (the parser keeps three batches alive: k - 1 being
-        // written, k on the device, k + 1 being parsed)
         double parse_s = 0.0;
-        parser = std::thread([&]() {
-            const double tp = now();
-            parser_rc = cm_fastq_next(fq, batch_pairs, &nxt);
-            parse_s = now() - tp;
-        });
-        double td = now();
-        MAP_TRY(cm_reads_upload(cm, &cur.reads, cur.prior), "cm_reads_upload");
-        {
-            std::vector<int> all(n_con);
-            for (uint32_t c = 0; c < n_con; ++c) all[c] = (int)c;
-            MAP_TRY(cm_map_rounds(cm, all.data(), (int)n_con, 1), "cm_map_rounds");   // round r + 1 seeds while r pairs
+        const bool more = nxt.reads.n_pairs != 0;
+        parser_rc = CM_OK;
+        memset(&nn, 0, sizeof nn);
+        if (more)
+            parser = std::thread([&]() {
+                const double tp = now();
+                parser_rc = cm_fastq_next(fq, batch_pairs, &nn);
+                parse_s = now() - tp;
+            });
+        const double td = now();
+        if (more) {
+            pin_batch(nxt);
+            MAP_TRY(cm_reads_stage(cm, &nxt.reads, nxt.prior), "cm_reads_stage");
         }
-        R.state.resize(n);
-        R.active.resize(n);
-        MAP_TRY(cm_reads_download(cm, R.state.data(), nullptr, R.active.data()), "cm_reads_download");
+        MAP_TRY(cm_map_rounds(cm, all.data(), (int)n_con, 1), "cm_map_rounds");          // round r + 1 seeds while r pairs
+        // results of batch k: rows of every pair (PAM / SAM) or just the re-queued pairs' records
+        uint64_t n_rec = 0;
+        if (a->report) {
+            R.state.resize(n);
+            R.active.resize(n);
+            MAP_TRY(cm_reads_download(cm, R.state.data(), nullptr, R.active.data()), "cm_reads_download");
+            R.sel.clear();
+            for (uint64_t i = 0; i < n; ++i) {
+                if (R.active[i]) R.sel.push_back(i);
+                const int t = R.state[i].type;
+                if (t >= 0 && t < 14) ++st.by_type[t];
+            }
+            n_rec = R.sel.size();
+        } else {
+            if (R.recs.size() < n) R.recs.resize(n);
+            MAP_TRY(cm_collect_records(cm, 0, n, R.recs.data(), &n_rec), "cm_collect_records");
+            uint64_t h[14];
+            MAP_TRY(cm_type_histogram(cm, h), "cm_type_histogram");
+            for (int t = 0; t < 14; ++t) st.by_type[t] += h[t];
+        }
+        R.n_rec = n_rec;
+        if (more) MAP_TRY(cm_reads_swap(cm), "cm_reads_swap");
         st.seconds_device += now() - td;
-        parser.join();
-        st.seconds_parse += parse_s;
-        MAP_TRY(parser_rc, "cm_fastq_next");
-        R.sel.clear();
-        for (uint64_t i = 0; i < n; ++i) {
-            if (R.active[i]) R.sel.push_back(i);
-            const int t = R.state[i].type;
-            if (t >= 0 && t < 14) ++st.by_type[t];
-        }
         st.pairs += n;
-        st.bsj_pairs += R.sel.size();
+        st.bsj_pairs += n_rec;
         R.batch = cur;
         if (writer.joinable()) writer.join();                    // rows of batch k-1 are out: file order = batch order
         MAP_TRY(writer_rc, "writer");
@@ -217,11 +277,18 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
             int r = CM_OK;
             if (report == 1) r = cm_write_pam(w_map, &R.batch, R.state.data(), nullptr, 0);
             if (report == 2) r = cm_write_sam(w_map, &R.batch, R.state.data(), nullptr, 0);
-            if (r == CM_OK && !R.sel.empty()) r = cm_write_remain(w_rem, &R.batch, R.state.data(), R.sel.data(), R.sel.size());
+            if (r == CM_OK && R.n_rec) {
+                if (report) r = cm_write_remain(w_rem, &R.batch, R.state.data(), R.sel.data(), R.sel.size());
+                else r = cm_write_remain_records(w_rem, &R.batch, R.recs.data(), R.n_rec);
+            }
             writer_rc = r;
             write_s += now() - tw;
         });
+        if (parser.joinable()) parser.join();
+        st.seconds_parse += parse_s;
+        MAP_TRY(parser_rc, "cm_fastq_next");
         cur = nxt;
+        nxt = nn;
     }
     if (writer.joinable()) writer.join();
     MAP_TRY(writer_rc, "writer");
@@ -233,4 +300,41 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     if (stats) *stats = st;
     return CM_OK;
 #undef MAP_TRY
+}
+
+extern "C" int cm_merge_parts(const char *out_prefix, int32_t rounds, int32_t world, int32_t report) {
+    if (!out_prefix || rounds < 1 || world < 1 || report < 0 || report > 2) return CM_EINVAL;
+    if (world == 1) return CM_OK;
+    const std::string out = out_prefix;
+    std::vector<std::string> names = {out + "_" + std::to_string(rounds) + "_remain_R1.fastq", out + "_" + std::to_string(rounds) + "_remain_R2.fastq"};
+    if (report) names.push_back(out + (report == 2 ? ".mapping.sam" : ".mapping.pam"));
+    std::vector<char> buf(8u << 20);
+    for (const std::string &name : names) {
+        FILE *dst = fopen(name.c_str(), "wb");
+        if (!dst) return CM_EIO;
+        for (int r = 0; r < world; ++r) {
+            const std::string pn = name + ".part" + std::to_string(r);
+            FILE *src = fopen(pn.c_str(), "rb");
+            if (!src) {
+                fclose(dst);
+                return CM_EINVAL;                             // a rank has not written its part
+            }
+            size_t got;
+            while ((got = fread(buf.data(), 1, buf.size(), src)) > 0)
+                if (fwrite(buf.data(), 1, got, dst) != got) {
+                    fclose(src);
+                    fclose(dst);
+                    return CM_EIO;
+                }
+            const bool bad = ferror(src) != 0;
+            fclose(src);
+            if (bad) {
+                fclose(dst);
+                return CM_EIO;
+            }
+        }
+        if (fclose(dst) != 0) return CM_EIO;
+        for (int r = 0; r < world; ++r) remove((name + ".part" + std::to_string(r)).c_str());
+    }
+    return CM_OK;
 }

@@ -185,6 +185,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_collect_records_device": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, pp(C.c_uint64)]),
         "cm_host_alloc": (C.c_int, [vp, C.c_uint64, pp(vp)]),
         "cm_host_free": (C.c_int, [vp, vp]),
+        "cm_host_register": (C.c_int, [vp, vp, C.c_uint64]),
+        "cm_host_unregister": (C.c_int, [vp, vp]),
+        "cm_type_histogram": (C.c_int, [vp, pp(C.c_uint64)]),
         "cm_seed_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_uint32, pp(C.c_uint32)]),
         "cm_chain_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "cm_prof_enable": (C.c_int, [vp, C.c_int]),
@@ -207,10 +210,14 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_host_free_loaded_contig": (None, [pp(IndexView)]),
         "cm_host_close_index": (None, [vp]),
         "cm_fastq_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, C.c_int32, pp(vp)]),
+        "cm_fastq_open_shard": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int, pp(vp),
+                                          pp(C.c_uint64), pp(C.c_uint64)]),
+        "cm_merge_parts": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
         "cm_fastq_next": (C.c_int, [vp, C.c_uint64, pp(FastqBatch)]),
         "cm_fastq_close": (None, [vp]),
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
+        "cm_write_remain_records": (C.c_int, [vp, pp(FastqBatch), vp, C.c_uint64]),
         "cm_write_pam": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_host_gene_overlap": (C.c_int, [pp(AnnotView), C.c_uint32, pp(u32p), pp(C.c_uint32)]),
         "cm_sort_remain": (C.c_int, [C.c_char_p, C.c_char_p]),
@@ -236,11 +243,11 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_map_rounds", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_host_register", "cm_host_unregister", "cm_type_histogram", "cm_write_remain_records", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_index_stats", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_next_contig_genome", "cm_host_free_loaded_contig",
-                    "cm_host_close_index", "cm_fastq_open", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
+                    "cm_host_close_index", "cm_fastq_open", "cm_fastq_open_shard", "cm_merge_parts", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
                     "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_flush", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
 
@@ -468,11 +475,12 @@ def run_circ(index_path, gtf, out_prefix, last_round, params=None, n_threads=4, 
     return st
 
 
-def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report=1, n_threads=4, batch_pairs=0, index_info=None):
-    """cm_mapping_run: stage 1 from files to files (the reference's mapping(), src/circminer.cpp:98-352)."""
+def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report=1, n_threads=4, batch_pairs=0, index_info=None, rank=0, world=1):
+    """cm_mapping_run: stage 1 from files to files (the reference's mapping(), src/circminer.cpp:98-352).  rank / world: this
+    process maps the rank-th block of pairs and writes .part<rank> files (merge_parts() on rank 0 afterwards)."""
     L = load()
     a = MappingArgs(index_path.encode(), (index_info or index_path + ".info").encode(), gtf.encode(), fastq1.encode(), fastq2.encode(),
-                    out_prefix.encode(), params if params is not None else default_params(), report, n_threads, batch_pairs)
+                    out_prefix.encode(), params if params is not None else default_params(), report, n_threads, batch_pairs, rank, world)
     st = MappingStats()
     err = C.create_string_buffer(1024)
     rc = L.cm_mapping_run(C.byref(a), C.byref(st), err, len(err))
@@ -481,16 +489,30 @@ def run_mapping(index_path, gtf, fastq1, fastq2, out_prefix, params=None, report
     return st
 
 
-class FastqReader:
-    """Paired FASTQ (plain / gzip) -> batches in the cm_reads layout; a batch is valid until the next one is read."""
+def merge_parts(out_prefix, rounds, world, report=1):
+    """cm_merge_parts: the .part<rank> files of a sharded stage 1 -> the files one process would have written."""
+    rc = load().cm_merge_parts(out_prefix.encode(), rounds, world, report)
+    if rc != 0:
+        raise RuntimeError(f"cm_merge_parts failed ({rc})")
 
-    def __init__(self, r1: str, r2: str, chr_table=(), max_ed: int = 4):
+
+class FastqReader:
+    """Paired FASTQ (plain / gzip) -> batches in the cm_reads layout; a batch is valid until the next one is read.
+    rank / world: only the rank-th contiguous block of pairs (cm_fastq_open_shard; plain-text files)."""
+
+    def __init__(self, r1: str, r2: str, chr_table=(), max_ed: int = 4, rank: int = 0, world: int = 1, n_threads: int = 0):
         self.L = load()
         self._chrs = chr_array(list(chr_table))
         self.h = C.c_void_p()
-        rc = self.L.cm_fastq_open(r1.encode(), r2.encode(), self._chrs, len(chr_table), max_ed, C.byref(self.h))
+        first, count = C.c_uint64(0), C.c_uint64(0)
+        if world == 1:
+            rc = self.L.cm_fastq_open(r1.encode(), r2.encode(), self._chrs, len(chr_table), max_ed, C.byref(self.h))
+        else:
+            rc = self.L.cm_fastq_open_shard(r1.encode(), r2.encode(), self._chrs, len(chr_table), max_ed, rank, world, n_threads, C.byref(self.h),
+                                            C.byref(first), C.byref(count))
         if rc != 0:
             raise RuntimeError(f"cm_fastq_open failed ({rc})")
+        self.first_pair, self.n_pairs = first.value, (count.value if world > 1 else None)
 
     def next_batch(self, max_pairs: int):
         fb = FastqBatch()

@@ -251,6 +251,12 @@ int cm_collect_records_device(cm_ctx *ctx, uint64_t index_base, uint64_t cap, vo
  * records): the copies in cm_reads_upload / cm_reads_download / cm_collect_active are direct DMA for such
  * buffers instead of staged pageable copies.  Optional: every entry point also accepts ordinary memory. */
 int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out);
+/* The same for memory the caller already owns (e.g. the batch arrays cm_fastq_next returns): page-locks [p, p + bytes) until
+ * cm_host_unregister(p); the range must stay allocated meanwhile. */
+int cm_host_register(cm_ctx *ctx, void *p, uint64_t bytes);
+int cm_host_unregister(cm_ctx *ctx, void *p);
+/* MatchedRead::type histogram of the resident batch (CM_CONCRD .. CM_NOPROC_NOMATCH), counted on the device. */
+int cm_type_histogram(cm_ctx *ctx, uint64_t out[14]);
 int cm_host_free(cm_ctx *ctx, void *p);
 
 /* ---------------- finer-grained entry points used by the parity tests ---------------- */
@@ -342,8 +348,8 @@ void cm_host_close_index(cm_index_file *f);
 
 /* ---------------- FASTQ ingest, carry-over header, PAM / remain writers ---------- */
 /* One batch of parsed pairs in the layout cm_reads_upload takes.  All pointers belong to the parser and stay
- * valid over the next TWO cm_fastq_next calls (three generations of storage take turns: batch k-1 can be with a writer
- * thread and batch k on the GPU while batch k+1 is parsed) or until cm_fastq_close.  names*: NUL-terminated read names (first header token,
+ * valid over the next THREE cm_fastq_next calls (four generations of storage take turns: batch k-1 can be with a writer
+ * thread, batch k on the GPU and batch k+1 staged for it while batch k+2 is parsed) or until cm_fastq_close.  names*: NUL-terminated read names (first header token,
  * trailing "/x" cut: FASTQParser::extract_map_info, src/fastq_parser.cpp:178-198), name i at names + name_off[i].
  * prior: the MatchedRead each pair carried in its 23-token header (fill_map_info, :200-269) or NULL when no
  * pair of the batch carried one (fresh reads: cm_reads_upload's default state). */
@@ -359,6 +365,12 @@ typedef struct cm_fastq cm_fastq;
  * names of the carried headers -> chr_id); max_ed = maxEd of the run (state of unmapped carried reads). */
 int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed,
                   cm_fastq **out);
+/* One rank's contiguous block of pairs of a paired FASTQ ("rank r gets pairs [r*N/W, (r+1)*N/W)"): both files
+ * are cut at the same record, found by counting the newlines of the files in blocks on n_threads threads (no parsing).
+ * Needs seekable plain-text input when world > 1 (CM_EINVAL for gzip / pipes).  first_pair / n_pairs (nullable): the
+ * block's position in the whole input.  Every rank of a node can open its share at the same time. */
+int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed,
+                        int32_t rank, int32_t world, int n_threads, cm_fastq **out, uint64_t *first_pair, uint64_t *n_pairs);
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);   /* out->reads.n_pairs == 0 at the end */
 void cm_fastq_close(cm_fastq *f);
 
@@ -370,6 +382,9 @@ void cm_fastq_close(cm_fastq *f);
 typedef struct cm_writer cm_writer;
 int cm_writer_open(const char *path1, const char *path2, const cm_chr_info *chrs, uint32_t n_chr, cm_writer **out);
 int cm_write_remain(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
+/* cm_write_remain for (pair index, state) records as cm_collect_records delivers them (index_base 0): only the re-queued
+ * pairs' states have to leave the device. */
+int cm_write_remain_records(cm_writer *w, const cm_fastq_batch *batch, const cm_record *recs, uint64_t n);
 int cm_write_pam(cm_writer *w, const cm_fastq_batch *b, const cm_mapped_read *states, const uint64_t *sel, uint64_t n_sel);
 /* <out>.mapping.sam (--sam): header = SAMOutput::print_header (src/output.cpp:301-311, one @SQ per row of the chromosome
  * table), records = write_sam_rec_pe with set_flag_pe / set_output_pe (src/output.cpp:118-277): two lines per pair,
@@ -399,6 +414,11 @@ typedef struct cm_mapping_args {
     int32_t report;                /* reportMapping: 0 none, 1 PAM, 2 SAM */
     int32_t n_threads;             /* host threads for the index loader   */
     uint64_t batch_pairs;          /* pairs per resident batch, 0 = 2^18  */
+    /* One process per GPU: rank `rank` of `world` maps the rank-th contiguous block of pairs
+     * (cm_fastq_open_shard) on device params.device and writes <file>.part<rank> instead of <file> for every output;
+     * cm_merge_parts on rank 0 then makes the files of an unsharded run (same bytes: blocks are contiguous, rows are in
+     * input order).  world 0 or 1: one process, final file names. */
+    int32_t rank, world;
 } cm_mapping_args;
 typedef struct cm_mapping_stats {
     uint64_t pairs, bsj_pairs;
@@ -406,10 +426,15 @@ typedef struct cm_mapping_stats {
     int32_t rounds, reserved;
     double seconds_load, seconds_map;
     /* where seconds_map went, summed over the batches (the three overlap, so they add up to more than seconds_map):
-     * parsing FASTQ on the calling thread, waiting for the device (upload + rounds + download), writing rows */
+     * parsing FASTQ (parser thread), driving the device (stage + rounds + results + swap, calling thread), writing rows
+     * (writer thread) */
     double seconds_parse, seconds_device, seconds_write;
 } cm_mapping_stats;
 int cm_mapping_run(const cm_mapping_args *args, cm_mapping_stats *stats, char *err, uint64_t err_cap);
+/* After every rank's cm_mapping_run(rank, world) has returned: <out>_<rounds>_remain_R{1,2}.fastq and the mapping file
+ * (report 1 / 2) are concatenated from their .part<r> files in rank order, the parts are removed.  The result is what one
+ * process writes for the whole input; cm_circ_run takes it from there (stage 2 runs once, on the host of rank 0). */
+int cm_merge_parts(const char *out_prefix, int32_t rounds, int32_t world, int32_t report);
 
 /* ---------------- stage 2: ProcessCirc, src/process_circ.cpp -- host code, no GPU involved -------- */
 /* ProcessCirc::sort_fq (src/process_circ.cpp:179-193): the remain FASTQ of the last round ordered like

@@ -430,3 +430,60 @@ def test_fifo_and_gzip_fifo_input(built, tmp_path):
         rd.close()
         [t.join() for t in th]
         assert got == n
+
+
+def test_sharded_reader_blocks(built, tmp_path):
+    """cm_fastq_open_shard: rank r of W gets the pairs [r*N/W, (r+1)*N/W) of both files, cut at the same record
+    although the two files have different record sizes; the blocks of all ranks, in rank order, are the unsharded input.  Ragged
+    reads, last record without a newline, R2 longer than R1, more ranks than pairs; gzip input cannot be sharded."""
+    import gzip
+    rng = np.random.default_rng(3)
+    n = 4001
+    seqs1, quals1 = _rand_reads(rng, n, 20, 301)
+    seqs2, quals2 = _rand_reads(rng, n + 3, 20, 301)
+    p1, p2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    _fastq(p1, [f"frag{i} x" for i in range(n)], seqs1, quals1)
+    _fastq(p2, [f"frag{i}/2" for i in range(n + 3)], seqs2, quals2)
+    with open(p1, "rb+") as f:
+        f.seek(-1, 2)
+        f.truncate()
+
+    def block(rank, world):
+        rd = cl.FastqReader(p1, p2, CHRS, 4, rank=rank, world=world, n_threads=3)
+        out = []
+        while True:
+            b = rd.next_batch(700)
+            if b is None:
+                break
+            out += [(b.name(i), b.seq(i), b.qual(i), b.name(i, 2), b.seq(i, 2)) for i in range(b.n)]
+        first, cnt = rd.first_pair, rd.n_pairs
+        rd.close()
+        return out, first, cnt
+
+    whole, _, _ = block(0, 1)
+    assert len(whole) == n and whole[-1][1] == seqs1[-1].encode()
+    for world in (2, 3, 7):
+        got, at = [], 0
+        for r in range(world):
+            part, first, cnt = block(r, world)
+            assert first == at == n * r // world and cnt == len(part) == n * (r + 1) // world - n * r // world
+            got += part
+            at += cnt
+        assert got == whole
+    tiny1, tiny2 = str(tmp_path / "t_1.fq"), str(tmp_path / "t_2.fq")
+    _fastq(tiny1, ["a", "b"], seqs1[:2], quals1[:2])
+    _fastq(tiny2, ["a", "b"], seqs2[:2], quals2[:2])
+    sizes = []
+    for r in range(5):
+        rd = cl.FastqReader(tiny1, tiny2, CHRS, 4, rank=r, world=5)
+        b = rd.next_batch(10)
+        sizes.append(0 if b is None else b.n)
+        rd.close()
+    assert sum(sizes) == 2 and max(sizes) == 1
+    gz = str(tmp_path / "g_1.fq.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(open(tiny1, "rb").read())
+    with pytest.raises(RuntimeError):
+        cl.FastqReader(gz, tiny2, CHRS, 4, rank=0, world=2)
+    with pytest.raises(RuntimeError):
+        cl.FastqReader(tiny1, tiny2, CHRS, 4, rank=2, world=2)

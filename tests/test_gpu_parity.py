@@ -132,6 +132,16 @@ def test_full_size_parity_chr21(tmp_path_factory, n_pairs, seed, kw):
     import threading
     from conftest import DataSet
     ds = DataSet(tmp_path_factory.mktemp("chr21"), "chr21", n_pairs, seed)
+    if not kw:
+        # At this size too the oracle runs on index + annotation from ITS OWN builders (oracle/cm_oracle_build.cpp, single thread,
+        # from src/mrsfast/HashTable.c:769-839 + Sort.c:116-117 and gene_annotation.cpp / interval_tree_impl.h), compared array by
+        # array with the product's (the range-partitioned parallel build of host_index.cpp) before anything is mapped.
+        import time
+        from builders_util import assert_host_views_equal
+        t = time.time()
+        ds.ohi = op.OracleIndex(ds.d.contigs, ds.d.chr_table, ds.gtf, kmer=ds.kmer)
+        assert_host_views_equal(ds.hi, ds.ohi)
+        print(f"oracle's own builders on {len(ds.d.contigs[0])} bp: {time.time() - t:.0f}s, views identical to the product's", flush=True)
     P = cl.default_params(**kw)
     hp = cl.HotPath(P)
     hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
@@ -141,12 +151,12 @@ def test_full_size_parity_chr21(tmp_path_factory, n_pairs, seed, kw):
     n = ds.batch.n
     st0, act0 = op.default_state(P, n)
     cat0 = np.full(n, -1, np.int32)
-    T = max(1, min(os.cpu_count() or 1, 64))
+    T = max(1, os.cpu_count() or 1)
     L = op.load()
     import ctypes as C
 
     def work(a, b):
-        L.oracle_map_round(C.byref(P), C.byref(ds.hi.views[0]), C.byref(ds.hi.annots[0]), C.byref(ds.batch.c), 1, st0.ctypes.data,
+        L.oracle_map_round(C.byref(P), C.byref(ds.ohi.views[0]), C.byref(ds.ohi.annots[0]), C.byref(ds.batch.c), 1, st0.ctypes.data,
                            act0.ctypes.data, cat0.ctypes.data, a, b)
 
     th = [threading.Thread(target=work, args=((n * i) // T, (n * (i + 1)) // T)) for i in range(T)]
@@ -424,6 +434,51 @@ def test_stage1_from_files_to_files(preset, contig_size, report, tmp_path):
         cl.run_mapping(idx, gtf, fq[0], fq[1], out, cl.default_params(kmer=18))
     with pytest.raises(RuntimeError):
         cl.run_mapping(idx + ".nope", gtf, fq[0], fq[1], out, P)
+
+
+def test_two_ranks_on_one_card_end_in_one_circ_report(tmp_path):
+    """SURVEY 8(e) on the device path: two rank PROCESSES (both on cuda:0 here; one per GPU on a node) run cm_mapping_run with
+    rank / world = their block of the plain-text FASTQ (cm_fastq_open_shard), each writing .part<rank> files; cm_merge_parts and
+    one cm_circ_run on "rank 0".  Mapping file, remain files, candidates.pam and circ_report are the bytes of the one-process
+    run, report 0 (records of the re-queued pairs only leave the device) and report 1 (PAM) alike."""
+    import subprocess
+    import sys
+    from circminer_amd import synth
+    from stage2_util import write_fastq_pair
+    n = 6000
+    d = synth.generate("tiny2r", n_pairs=n, seed=44, mix=(0.5, 0.2, 0.3))
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as f:
+        for name, con, start, ln in d.chr_table:
+            f.write(f">{name}\n{d.contigs[con - 1][start:start + ln].tobytes().decode()}\n")
+    packed, info = cl.pack_genome(fa, 150_000)
+    idx = cl.write_index(packed, kmer=20, n_threads=4)
+    gtf = str(tmp_path / "ref.gtf")
+    open(gtf, "w").write(d.gtf_text)
+    fq1, fq2 = write_fastq_pair(tmp_path, d, n)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from circminer_amd import lib as cl; "
+            "st = cl.run_mapping(%r, %r, %r, %r, sys.argv[1], cl.default_params(kmer=0), report=int(sys.argv[4]), n_threads=4, batch_pairs=700, "
+            "rank=int(sys.argv[2]), world=int(sys.argv[3])); print(st.pairs, st.bsj_pairs, list(st.by_type))") % (root, idx, gtf, fq1, fq2)
+    files = {}
+    for report in (0, 1):
+        for world in (1, 2):
+            out = str(tmp_path / f"r{report}w{world}")
+            procs = [subprocess.Popen([sys.executable, "-c", code, out, str(r), str(world), str(report)], stdout=subprocess.PIPE, text=True)
+                     for r in range(world)]
+            outs = [p.communicate()[0] for p in procs]
+            assert all(p.returncode == 0 for p in procs), outs
+            stats = [o.strip().split(" ", 2) for o in outs]
+            assert sum(int(x[0]) for x in stats) == n
+            cl.merge_parts(out, 2, world, report)
+            cs = cl.run_circ(idx, gtf, out, 2, cl.default_params(kmer=0))
+            assert cs.pairs == sum(int(x[1]) for x in stats) > 100
+            names = ["_2_remain_R1.fastq", "_2_remain_R2.fastq", ".candidates.pam", ".circ_report"] + ([".mapping.pam"] if report else [])
+            files[(report, world)] = {s: open(out + s, "rb").read() for s in names}
+            assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
+        assert files[(report, 1)] == files[(report, 2)]
+    for s in ("_2_remain_R1.fastq", ".circ_report"):
+        assert files[(0, 1)][s] == files[(1, 1)][s] and len(files[(0, 1)][s]) > 1000
 
 
 def test_genes_with_more_than_64_isoforms(ds_tiny, tmp_path):

@@ -259,30 +259,10 @@ def test_product_builders_equal_the_oracles_own(name, request):
     reference's HashTable.c, gene_annotation.cpp and interval_tree_impl.h with the reference's containers): every array of every
     contig's cm_index_view and cm_annot_view is identical -- including the variety preset with nested / overlapping /
     opposite-strand / single-exon / duplicate-span genes, an exon next to the chromosome start and unordered gene blocks."""
+    from builders_util import assert_host_views_equal
     ds = request.getfixturevalue(name)
     assert ds.ohi is not ds.hi
-    for ci in range(ds.hi.n_contigs):
-        a, b = ds.hi.views[ci], ds.ohi.views[ci]
-        assert a.n_entries == b.n_entries and a.ref_len == b.ref_len
-        assert np.array_equal(_arr(a.bucket_off, 2 ** 28 + 1), _arr(b.bucket_off, 2 ** 28 + 1))
-        assert np.array_equal(_arr(a.checksum, a.n_entries, np.uint16), _arr(b.checksum, b.n_entries, np.uint16))
-        assert np.array_equal(_arr(a.pos, a.n_entries), _arr(b.pos, b.n_entries))
-        x, y = ds.hi.annots[ci], ds.ohi.annots[ci]
-        for f in ("n_iv", "n_seg", "n_trans", "n_gene", "n_bits", "n_chr", "n_giv"):
-            assert getattr(x, f) == getattr(y, f), f
-        for f, n in (("iv_spos", "n_iv"), ("iv_epos", "n_iv"), ("iv_max_end", "n_iv"), ("iv_min_end", "n_iv"), ("iv_max_next_exon", "n_iv"),
-                     ("seg_start", "n_seg"), ("seg_end", "n_seg"), ("seg_next_exon_beg", "n_seg"), ("seg_gene_id", "n_seg"), ("gene_start", "n_gene"),
-                     ("gene_end", "n_gene"), ("chr_shift", "n_chr"), ("giv_spos", "n_giv"), ("giv_epos", "n_giv")):
-            assert np.array_equal(_arr(getattr(x, f), getattr(x, n)), _arr(getattr(y, f), getattr(y, n))), f
-        for off, val, n in (("iv_seg_off", "iv_seg", "n_iv"), ("seg_tid_off", "seg_tid", "n_seg"), ("giv_gene_off", "giv_gene", "n_giv"), ("t2s_off", "t2s", "n_trans")):
-            ox, oy = _arr(getattr(x, off), getattr(x, n) + 1), _arr(getattr(y, off), getattr(y, n) + 1)
-            assert np.array_equal(ox, oy), off
-            dt = np.uint8 if val == "t2s" else np.uint32
-            assert np.array_equal(_arr(getattr(x, val), ox[-1], dt), _arr(getattr(y, val), oy[-1], dt)), val
-        assert np.array_equal(_arr(x.trans_start_ind, x.n_trans, np.int32), _arr(y.trans_start_ind, y.n_trans, np.int32))
-        assert np.array_equal(_arr(x.chr_id, x.n_chr, np.int32), _arr(y.chr_id, y.n_chr, np.int32))
-        for f in ("near_border_bits", "intronic_bits"):
-            assert np.array_equal(_arr(getattr(x, f), x.n_bits // 64, np.uint64), _arr(getattr(y, f), y.n_bits // 64, np.uint64)), f
+    assert_host_views_equal(ds.hi, ds.ohi)
     if name == "ds_variety":        # the shapes are really there
         av = ds.hi.annots[0]
         nseg = np.diff(_arr(av.iv_seg_off, av.n_iv + 1))

@@ -105,6 +105,91 @@ def cpu_baseline(P, hi, batch, target_s=12.0):
                     "no reference --thread N run and no reference/port bridge ratio"}
 
 
+def write_fastq_fixed(path, seqs, mate, first=0, chunk=1 << 19):
+    """(n, L) uint8 reads -> FASTQ text with fixed-width names "@r<9 digits>/<mate>" and constant qualities, written in
+    vectorised chunks (a Python loop over 8 M records would take minutes)."""
+    n, L = seqs.shape
+    rec = 14 + L + 3 + L + 1
+    with open(path, "wb") as f:
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            m = np.empty((b - a, rec), dtype=np.uint8)
+            m[:, 0] = ord("@")
+            m[:, 1] = ord("r")
+            idx = np.arange(first + a, first + b, dtype=np.int64)
+            for k in range(9):
+                m[:, 2 + k] = (idx // 10 ** (8 - k)) % 10 + 48
+            m[:, 11] = ord("/")
+            m[:, 12] = 48 + mate
+            m[:, 13] = 10
+            m[:, 14:14 + L] = seqs[a:b]
+            m[:, 14 + L] = 10
+            m[:, 15 + L] = ord("+")
+            m[:, 16 + L] = 10
+            m[:, 17 + L:17 + 2 * L] = ord("I")
+            m[:, 17 + 2 * L] = 10
+            m.tofile(f)
+
+
+def end_to_end(d, workload, n_pairs, n_threads, batch_pairs, dev_index, workdir=None):
+    """What a user of the reference runs, on files (src/circminer.cpp:98-352): <ref>.packed.fa(.index, .index.info) + GTF + two
+    plain-text FASTQ files -> cm_mapping_run (index file + GTF -> HBM, FASTQ text -> last round's remain files: the reference's
+    default output, reportMapping = DISCARDMAPREPORT, src/commandline_parser.cpp:26) -> cm_circ_run (sort, stage 2) ->
+    <out>.candidates.pam + <out>.circ_report.  Everything lives in tmpfs (no disk in the measurement).  Outside the timed
+    hot-path region of the bench line; reported next to it."""
+    from circminer_amd import lib as cl
+    base = workdir or share_dir(f"cm_e2e_{os.getpid()}", 12 * sum(len(c) for c in d.contigs) + 700 * n_pairs)
+    shutil.rmtree(base, ignore_errors=True)
+    os.makedirs(base)
+    res = {"workload": workload, "pairs": int(n_pairs), "threads": n_threads, "batch_pairs": int(batch_pairs), "dir": os.path.dirname(base)}
+    try:
+        t = time.time()
+        packed = os.path.join(base, "ref.fa.packed.fa")
+        with open(packed, "wb") as f:                       # GenomePacker::pack_genome's output, straight from the generator's contigs
+            for ci, c in enumerate(d.contigs):
+                f.write(b">%d\n" % (ci + 1))
+                np.ascontiguousarray(c).tofile(f)
+                f.write(b"\n")
+        with open(packed + ".index.info", "w") as f:
+            for name, con, start, ln in d.chr_table:
+                f.write(f"{con}\t{start}\t{start + ln}\t{name}\n")
+        gtf = os.path.join(base, "ref.gtf")
+        with open(gtf, "w") as f:
+            f.write(d.gtf_text)
+        fq = [os.path.join(base, f"reads_{m}.fq") for m in (1, 2)]
+        write_fastq_fixed(fq[0], d.seq1[:n_pairs], 1)
+        write_fastq_fixed(fq[1], d.seq2[:n_pairs], 2)
+        res["prep_files_s"] = round(time.time() - t, 1)
+        res["fastq_bytes"] = os.path.getsize(fq[0]) + os.path.getsize(fq[1])
+        t = time.time()
+        idx = cl.write_index(packed, kmer=20, n_threads=n_threads)          # `circminer --index`: once per genome, not part of a run
+        res["write_index_s"] = round(time.time() - t, 1)
+        res["index_bytes"] = os.path.getsize(idx)
+        out = os.path.join(base, "run")
+        t = time.time()
+        st = cl.run_mapping(idx, gtf, fq[0], fq[1], out, cl.default_params(kmer=0, device=dev_index), report=0, n_threads=n_threads,
+                            batch_pairs=batch_pairs)
+        stage1_s = time.time() - t
+        t = time.time()
+        cs = cl.run_circ(idx, gtf, out, st.rounds, cl.default_params(kmer=0), n_threads=n_threads)
+        stage2_s = time.time() - t
+        res.update({
+            "load_s": round(st.seconds_load, 2),                      # index file + GTF -> HBM (all packed contigs resident)
+            "index_GBps": round(res["index_bytes"] / max(st.seconds_load, 1e-9) / 1e9, 2),
+            "map_s": round(st.seconds_map, 3),                        # FASTQ text -> remain files
+            "fastq_to_remain_pairs_per_s": st.pairs / max(st.seconds_map, 1e-9),
+            "map_parts_s": {"parse": round(st.seconds_parse, 3), "device": round(st.seconds_device, 3), "write": round(st.seconds_write, 3)},
+            "bsj_pairs": int(st.bsj_pairs), "stage2_s": round(stage2_s, 2), "candidate_rows": int(cs.candidate_rows), "calls": int(cs.calls),
+            "stage1_total_s": round(stage1_s, 2),
+            "fastq_to_circ_report_pairs_per_s_excl_load": st.pairs / max(st.seconds_map + stage2_s, 1e-9),
+            "fastq_to_circ_report_pairs_per_s_incl_load": st.pairs / max(stage1_s + stage2_s, 1e-9),
+            "circ_report_rows": sum(1 for _ in open(out + ".circ_report")),
+        })
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -155,6 +240,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=1 << 21, help="pairs per batch (= per step and GPU); the library maps tiles of <= 2^20 pairs")
     ap.add_argument("--seed", type=int, default=38)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", type=int, default=0, metavar="PAIRS",
+                    help="also run the file-to-file flow (index file + GTF + FASTQ text -> circ_report) on this many pairs and add an "
+                         "'end_to_end' object to the line (minutes of extra preparation at hg38 scale: off by default)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: CPU rehearsal of the launch, tests only)")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if collected")
@@ -218,7 +306,7 @@ def main():
     t0 = time.time()
     n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
     # two different batches take turns, so that consecutive steps really move different reads over PCIe
-    d = synth.generate(args.workload, n_pairs=2 * args.pairs, seed=args.seed, read_seed=rank)
+    d = synth.generate(args.workload, n_pairs=max(2 * args.pairs, args.e2e if rank == 0 else 0), seed=args.seed, read_seed=rank)
     gen_s = time.time() - t0
     tag = f"cm_bench_{args.workload}_{args.seed}_{os.environ.get('MASTER_PORT', '0')}"
     sdir = share_dir(tag, 8 * sum(len(c) for c in d.contigs)) if world > 1 else None
@@ -383,6 +471,9 @@ def main():
             "counters": {"probes": counters[0], "search_touches": counters[1], "hits_consumed": counters[2], "pair_rounds": counters[3],
                          "pair_rounds_rerun": counters[4]},
         }
+        if args.e2e:
+            hp.close()                                          # its HBM goes back before cm_mapping_run makes a context of its own
+            out["end_to_end"] = end_to_end(d, args.workload, args.e2e, os.cpu_count() or 8, args.pairs, dev_index)
         # rank 0's host cores, after the timed region (the other ranks are idle at the final barrier by then)
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(P, hi, batches[0])
         sys.stdout.flush()

@@ -38,7 +38,7 @@ class CircRes(C.Structure):
 class MappingArgs(C.Structure):
     _fields_ = [("index_path", C.c_char_p), ("index_info_path", C.c_char_p), ("gtf_path", C.c_char_p), ("fastq1", C.c_char_p),
                 ("fastq2", C.c_char_p), ("out_prefix", C.c_char_p), ("params", Params), ("report", C.c_int32), ("n_threads", C.c_int32),
-                ("batch_pairs", C.c_uint64)]
+                ("batch_pairs", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32)]
 
 
 class CircStats(C.Structure):
@@ -233,17 +233,25 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_writer_flush": (C.c_int, [vp]),
         "cm_writer_close": (None, [vp]),
     }
+    sigs["cm_abi_sizes"] = (C.c_int, [pp(C.c_uint32), C.c_uint32])
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors below must be the structs the library was compiled with
+    got = (C.c_uint32 * 16)()
+    n = L.cm_abi_sizes(got, 16)
+    mine = [C.sizeof(t) for t in (Params, IndexView, AnnotView, MappedRead, Reads, C.c_uint8 * RECORD_DTYPE.itemsize, ChrInfo, FastqBatch, MappingArgs,
+                                  MappingStats, CircRes, CircArgs, CircStats)]
+    if n != len(mine) or list(got[:n]) != mine:
+        raise RuntimeError(f"circminer_amd.lib: struct sizes differ from {path}: library {list(got[:max(n, 0)])}, ctypes {mine}")
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_map_rounds", "cm_reads_download", "cm_map_batch",
-                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_host_alloc", "cm_host_free", "cm_host_register", "cm_host_unregister", "cm_type_histogram", "cm_write_remain_records", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
+                    "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_abi_sizes", "cm_host_alloc", "cm_host_free", "cm_host_register", "cm_host_unregister", "cm_type_histogram", "cm_write_remain_records", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_index_stats", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_next_contig_genome", "cm_host_free_loaded_contig",

@@ -481,6 +481,11 @@ typedef struct cm_circ_args {
 } cm_circ_args;
 int cm_circ_run(const cm_circ_args *args, cm_circ_stats *stats, char *err, uint64_t err_cap);
 
+/* sizeof of the structs above, in this order: cm_params, cm_index_view, cm_annot_view, cm_mapped_read, cm_reads, cm_record,
+ * cm_chr_info, cm_fastq_batch, cm_mapping_args, cm_mapping_stats, cm_circ_res, cm_circ_args, cm_circ_stats -- for a binding to
+ * check its mirrors of them against the library it loaded.  Returns the number of entries written (cap must hold them). */
+int cm_abi_sizes(uint32_t *out, uint32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

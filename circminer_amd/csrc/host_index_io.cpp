@@ -23,8 +23,12 @@
 // The FASTA loader of the reference lives in the absent mrsfast submodule (RefGenome.c); its contract is
 // fixed by the in-tree callers (HashTable.c:288-293, 618-633): one record = one contig, bases upper-cased,
 // anything but A/C/G/T becomes N, offset 0.
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,6 +143,9 @@ struct cm_index_file {
     std::vector<std::string> names;
     std::vector<int32_t> lens;
     bool done = false;
+    void *tab = nullptr;                 // the table of the contig being loaded as it is in the file; reused from contig to contig
+    size_t tab_bytes = 0;
+    ~cm_index_file() { free(tab); }
 };
 
 extern "C" {
@@ -417,43 +424,120 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         return CM_EINVAL;
     }
     const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
-    std::vector<uint32_t> hvs, cnts;
-    if (!genome_only) {
-        hvs.reserve(nbuckets);
-        cnts.reserve(nbuckets);
-    }
-    std::vector<uint8_t> buf;
-    uint64_t hv = 0, mem = 0;
-    for (uint32_t i = 0; i < nbuckets;) {
-        int32_t bytes = 0;
-        if (!get(f, bytes) || bytes <= 0) {
-            free(g);
-            return CM_EINVAL;
-        }
-        buf.resize((size_t)bytes);
-        if (fread(buf.data(), 1, (size_t)bytes, f) != (size_t)bytes) {
-            free(g);
-            return CM_EINVAL;
-        }
-        size_t idx = 0;
-        while (idx < (size_t)bytes) {
-            uint32_t d = 0, cn = 0;
-            int a = decode_varbyte(buf.data() + idx, (size_t)bytes - idx, &d);
-            if (a < 0) { free(g); return CM_EINVAL; }
-            idx += (size_t)a;
-            a = decode_varbyte(buf.data() + idx, (size_t)bytes - idx, &cn);
-            if (a < 0) { free(g); return CM_EINVAL; }
-            idx += (size_t)a;
-            hv += d;
-            if (hv >= nb) { free(g); return CM_EINVAL; }
-            if (!genome_only) {
-                hvs.push_back((uint32_t)hv);
-                cnts.push_back(cn);
+    // The bucket headers (hv delta, count14) come in blocks of varbyte pairs, each behind its byte length (HashTable.c:197-254).
+    // The blocks are read in one sequential pass -- a block's entry count is half its number of terminator bytes -- and decoded
+    // side by side: pass 1 gives every block's sum of deltas, its entries and its table slots, a prefix over the blocks gives the
+    // starting hv and position of each, pass 2 writes hvs[] / cnts[].
+    struct Blk { size_t off, bytes; uint64_t n, dsum, mem; };
+    std::vector<Blk> blks;
+    std::vector<uint8_t> hdr;
+    uint64_t mem = 0;
+    {
+        uint64_t seen = 0;
+        while (seen < nbuckets) {
+            int32_t bytes = 0;
+            if (!get(f, bytes) || bytes <= 0) {
+                free(g);
+                return CM_EINVAL;
             }
-            mem += (uint64_t)cn + 1;
-            ++i;
+            const size_t at = hdr.size();
+            hdr.resize(at + (size_t)bytes);
+            if (fread(hdr.data() + at, 1, (size_t)bytes, f) != (size_t)bytes) {
+                free(g);
+                return CM_EINVAL;
+            }
+            uint64_t term = 0;
+            for (size_t k = at; k < at + (size_t)bytes; ++k) term += hdr[k] >> 7;
+            if (term == 0 || (term & 1)) {
+                free(g);
+                return CM_EINVAL;
+            }
+            blks.push_back(Blk{at, (size_t)bytes, term / 2, 0, 0});
+            seen += term / 2;
+        }
+        if (seen != nbuckets) {
+            free(g);
+            return CM_EINVAL;
         }
     }
+    const int TH = std::max(1, std::min(n_threads, 32));
+    auto over_blocks = [&](auto &&body) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        auto run = [&]() {
+            for (size_t b; (b = next.fetch_add(1)) < blks.size();) body(b);
+        };
+        for (int t = 1; t < TH; ++t) th.emplace_back(run);
+        run();
+        for (auto &t : th) t.join();
+    };
+    std::atomic<int> hdr_bad{0};
+    over_blocks([&](size_t b) {
+        Blk &B = blks[b];
+        const uint8_t *p = hdr.data() + B.off;
+        size_t idx = 0;
+        uint64_t dsum = 0, msum = 0, cnt = 0;
+        while (idx < B.bytes) {
+            uint32_t d = 0, cn = 0;
+            int a = decode_varbyte(p + idx, B.bytes - idx, &d);
+            if (a < 0) { hdr_bad = 1; return; }
+            idx += (size_t)a;
+            a = decode_varbyte(p + idx, B.bytes - idx, &cn);
+            if (a < 0) { hdr_bad = 1; return; }
+            idx += (size_t)a;
+            dsum += d;
+            msum += (uint64_t)cn + 1;
+            ++cnt;
+        }
+        if (cnt != B.n) hdr_bad = 1;
+        B.dsum = dsum;
+        B.mem = msum;
+    });
+    if (hdr_bad) {
+        free(g);
+        return CM_EINVAL;
+    }
+    std::unique_ptr<uint32_t[]> hvs, cnts;                 // not cleared: pass 2 fills them
+    const size_t n_hdr = (size_t)nbuckets;
+    {
+        uint64_t hv0 = 0, at = 0;
+        std::vector<uint64_t> start_hv(blks.size()), start_at(blks.size());
+        for (size_t b = 0; b < blks.size(); ++b) {
+            start_hv[b] = hv0;
+            start_at[b] = at;
+            hv0 += blks[b].dsum;
+            at += blks[b].n;
+            mem += blks[b].mem;
+        }
+        if (hv0 >= nb && nbuckets) {
+            free(g);
+            return CM_EINVAL;
+        }
+        if (!genome_only) {
+            hvs.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
+            cnts.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
+            if (!hvs || !cnts) {
+                free(g);
+                return CM_ENOMEM;
+            }
+            over_blocks([&](size_t b) {
+                const Blk &B = blks[b];
+                const uint8_t *p = hdr.data() + B.off;
+                size_t idx = 0;
+                uint64_t hv = start_hv[b], w = start_at[b];
+                while (idx < B.bytes) {
+                    uint32_t d = 0, cn = 0;
+                    idx += (size_t)decode_varbyte(p + idx, B.bytes - idx, &d);
+                    idx += (size_t)decode_varbyte(p + idx, B.bytes - idx, &cn);
+                    hv += d;
+                    hvs[w] = (uint32_t)hv;
+                    cnts[w] = cn;
+                    ++w;
+                }
+            });
+        }
+    }
+    std::vector<uint8_t>().swap(hdr);
     lap("bucket headers decoded");
     const int kmer = x->window + x->checksum_len;
     const int contig_num = atoi(name) - 1;            // contigNum of the mapping loop, src/circminer.cpp:266-267
@@ -476,14 +560,45 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(g);
             return CM_EINVAL;
         }
-        std::unique_ptr<Entry[]> tab(new (std::nothrow) Entry[(size_t)memsz + 1]);      // not cleared: fread fills it
+        // the table itself (8 bytes per slot, ~8.5 GB for a full-size contig): pread()s side by side into a buffer that is kept
+        // for the next contig (its pages are faulted in once per file, not once per contig)
+        const size_t tab_need = ((size_t)memsz + 1) * sizeof(Entry);
+        if (x->tab_bytes < tab_need) {
+            free(x->tab);
+            x->tab = malloc(tab_need);
+            x->tab_bytes = x->tab ? tab_need : 0;
+        }
+        Entry *tab = (Entry *)x->tab;
         if (!tab) {
             free(g);
             return CM_ENOMEM;
         }
-        if (memsz && fread(tab.get(), sizeof(Entry), memsz, f) != memsz) {
-            free(g);
-            return CM_EINVAL;
+        {
+            const off_t at = ftello(f);
+            const int fd = fileno(f);
+            const size_t total_b = (size_t)memsz * sizeof(Entry);
+            const int T = total_b < (64u << 20) ? 1 : std::max(1, std::min(n_threads, 32));
+            std::atomic<int> bad{0};
+            auto piece = [&](int t) {
+                size_t a = total_b * (size_t)t / (size_t)T, b = total_b * (size_t)(t + 1) / (size_t)T;
+                while (a < b) {
+                    const ssize_t r = pread(fd, (char *)tab + a, std::min<size_t>(b - a, 256u << 20), at + (off_t)a);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) {
+                        bad = 1;
+                        return;
+                    }
+                    a += (size_t)r;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(piece, t);
+            piece(0);
+            for (auto &t : th) t.join();
+            if (bad || fseeko(f, at + (off_t)total_b, SEEK_SET) != 0) {
+                free(g);
+                return CM_EINVAL;
+            }
         }
         lap("table read");
         uint32_t *boff = (uint32_t *)calloc(nb + 1, sizeof(uint32_t));
@@ -496,8 +611,8 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         {
             uint64_t run = 0;
             int t = 0;
-            for (size_t b = 0; b < hvs.size(); ++b) {
-                while (t < TT && b == hvs.size() * (size_t)t / (size_t)TT) start[(size_t)t++] = run;
+            for (size_t b = 0; b < n_hdr; ++b) {
+                while (t < TT && b == n_hdr * (size_t)t / (size_t)TT) start[(size_t)t++] = run;
                 run += (uint64_t)cnts[b] + 1;
             }
             while (t <= TT) start[(size_t)t++] = run;
@@ -513,7 +628,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             std::vector<uint8_t> bad((size_t)TT, 0);
             over_ranges([&](int t) {
                 uint64_t c0 = start[(size_t)t], s = 0;
-                for (size_t b = hvs.size() * (size_t)t / (size_t)TT, e = hvs.size() * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
+                for (size_t b = n_hdr * (size_t)t / (size_t)TT, e = n_hdr * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
                     const int32_t c = tab[c0].info;
                     if (c < 0 || (uint32_t)c > cnts[b]) {
                         bad[(size_t)t] = 1;
@@ -571,7 +686,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         }
         over_ranges([&](int t) {
             uint64_t c0 = start[(size_t)t];
-            for (size_t b = hvs.size() * (size_t)t / (size_t)TT, e = hvs.size() * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
+            for (size_t b = n_hdr * (size_t)t / (size_t)TT, e = n_hdr * (size_t)(t + 1) / (size_t)TT; b < e; ++b) {
                 const uint32_t c = (uint32_t)tab[c0].info, w = boff[hvs[b]];
                 for (uint32_t k = 0; k < c; ++k) {
                     cs[w + k] = tab[c0 + 1 + k].checksum;

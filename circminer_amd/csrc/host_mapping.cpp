@@ -22,6 +22,7 @@
 //
 // One process per GPU: rank r of w maps the r-th contiguous block of pairs (cm_fastq_open_shard) and writes .part<r> files;
 // cm_merge_parts on rank 0 concatenates them in rank order -- the bytes one process would have written.
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -85,10 +86,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         cm_fastq_batch batch;
     } res[2];
     std::vector<std::pair<void *, uint64_t>> pinned;            // parser arrays registered with the runtime (cm_host_register)
-    std::thread writer, parser;
+    std::thread writer, parser, gtf_thread;
     int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
+        if (gtf_thread.joinable()) gtf_thread.join();           // it reads chrs
         if (parser.joinable()) parser.join();
         if (writer.joinable()) writer.join();
         if (w_map) cm_writer_close(w_map);
@@ -128,18 +130,58 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     MAP_TRY(cm_create(&P, &cm), "cm_create");
 
     // ---- every packed contig into its own slot (loadHashTable + pac2char_whole_contig per round in the reference) ----
-    for (;;) {
-        cm_index_view iv;
-        int loaded = 0;
-        MAP_TRY(cm_host_next_contig(idx, n_threads, &iv, &loaded), "cm_host_next_contig");
-        if (!loaded) break;
-        views.push_back(iv);
-        if (iv.contig_num != (int32_t)views.size() - 1) {
-            rc = fail(CM_EINVAL, "packed contigs out of order: record %zu is contig %d", views.size(), iv.contig_num + 1);
-            cleanup();
-            return rc;
+    // Contig c + 1 is read and decoded from the index file (host threads) while contig c goes over PCIe and gets its bucket
+    // descriptors built (cm_load_contig), and the GTF is parsed meanwhile on a thread of its own (it needs the contig lengths
+    // only at the end: they are in the .index.info rows already).
+    const bool trace = getenv("CM_INDEX_TRACE") != nullptr;
+    auto lap = [&](const char *what, double since) {
+        if (trace) fprintf(stderr, "[load] %s %.3f s (at %.3f s)\n", what, now() - since, now() - t0);
+    };
+    lap("index info + header + context", t0);
+    // the GTF model is built on a thread of its own meanwhile; the contig lengths it needs follow from the .index.info rows
+    // (a packed contig ends with its last chromosome) and are checked against the index file's afterwards
+    std::vector<uint32_t> clen_guess;
+    for (uint32_t i = 0; i < n_chr; ++i) {
+        if (chrs[i].contig_id == 0) continue;
+        if (clen_guess.size() < chrs[i].contig_id) clen_guess.resize(chrs[i].contig_id, 0);
+        clen_guess[chrs[i].contig_id - 1] = std::max(clen_guess[chrs[i].contig_id - 1], chrs[i].start_pos + chrs[i].len);
+    }
+    std::vector<cm_annot_view> annots_early(clen_guess.size());
+    int early_rc = CM_EINVAL;
+    if (!clen_guess.empty())
+        gtf_thread = std::thread([&]() {
+            const double tg = now();
+            early_rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen_guess.data(), (uint32_t)clen_guess.size(), P.max_read_len, annots_early.data());
+            lap("GTF -> annotation tables (under the contig loads)", tg);
+        });
+    {
+        cm_index_view nxt_iv;
+        int nxt_loaded = 0, nxt_rc = CM_OK;
+        double tl = now();
+        nxt_rc = cm_host_next_contig(idx, n_threads, &nxt_iv, &nxt_loaded);
+        lap("contig decoded", tl);
+        for (;;) {
+            MAP_TRY(nxt_rc, "cm_host_next_contig");
+            if (!nxt_loaded) break;
+            cm_index_view iv = nxt_iv;
+            views.push_back(iv);
+            if (iv.contig_num != (int32_t)views.size() - 1) {
+                rc = fail(CM_EINVAL, "packed contigs out of order: record %zu is contig %d", views.size(), iv.contig_num + 1);
+                cleanup();
+                return rc;
+            }
+            std::thread ahead([&]() {
+                const double ta = now();
+                nxt_rc = cm_host_next_contig(idx, n_threads, &nxt_iv, &nxt_loaded);
+                lap("next contig decoded (under the upload)", ta);
+            });
+            tl = now();
+            const int lrc = cm_load_contig(cm, (int)views.size() - 1, &iv);
+            lap("contig uploaded + descriptors", tl);
+            ahead.join();
+            if (nxt_rc == CM_OK && nxt_loaded && lrc != CM_OK) cm_host_free_loaded_contig(&nxt_iv);
+            MAP_TRY(lrc, "cm_load_contig");
         }
-        MAP_TRY(cm_load_contig(cm, (int)views.size() - 1, &iv), "cm_load_contig");
     }
     const uint32_t n_con = (uint32_t)views.size();
     if (n_con == 0) {
@@ -151,15 +193,26 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     {
         std::vector<uint32_t> clen(n_con);
         for (uint32_t c = 0; c < n_con; ++c) clen[c] = views[c].ref_len;
-        annots.resize(n_con);
-        rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen.data(), n_con, P.max_read_len, annots.data());
+        if (gtf_thread.joinable()) gtf_thread.join();
+        if (early_rc == CM_OK && clen == clen_guess) {
+            annots = annots_early;
+            rc = CM_OK;
+        } else {                                      // .index.info and the index file disagree on the contig lengths: the file decides
+            if (early_rc == CM_OK) cm_host_free_annotation(annots_early.data(), (uint32_t)annots_early.size());
+            annots.resize(n_con);
+            const double tg = now();
+            rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen.data(), n_con, P.max_read_len, annots.data());
+            lap("GTF -> annotation tables", tg);
+        }
         if (rc != CM_OK) {
             annots.clear();
             rc = fail(rc, "cm_host_build_annotation failed (%d)", rc);
             cleanup();
             return rc;
         }
+        const double tu = now();
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_load_annotation(cm, (int)c, &annots[c]), "cm_load_annotation");
+        lap("annotation uploaded", tu);
         for (auto &v : views) cm_host_free_loaded_contig(&v);      // host copies are no longer needed: everything is in HBM
         views.clear();
     }

@@ -446,8 +446,17 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
                 free(g);
                 return CM_EINVAL;
             }
-            uint64_t term = 0;
-            for (size_t k = at; k < at + (size_t)bytes; ++k) term += hdr[k] >> 7;
+            uint64_t term = 0;                      // bytes with the top bit set end a varbyte; eight at a time
+            {
+                size_t k = at;
+                const size_t e = at + (size_t)bytes;
+                for (; k + 8 <= e; k += 8) {
+                    uint64_t w;
+                    memcpy(&w, hdr.data() + k, 8);
+                    term += (uint64_t)__builtin_popcountll(w & 0x8080808080808080ull);
+                }
+                for (; k < e; ++k) term += hdr[k] >> 7;
+            }
             if (term == 0 || (term & 1)) {
                 free(g);
                 return CM_EINVAL;
@@ -472,6 +481,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         for (auto &t : th) t.join();
     };
     std::atomic<int> hdr_bad{0};
+    if (!genome_only || !x->full)          // (stage 2 steps over the table: its size follows the blocks in the file, nothing to decode)
     over_blocks([&](size_t b) {
         Blk &B = blks[b];
         const uint8_t *p = hdr.data() + B.off;
@@ -545,7 +555,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     if (genome_only) {                                   // the table is stepped over, not decoded (stage 2 needs the sequence only)
         if (x->full) {
             uint32_t memsz = 0;
-            if (!get(f, memsz) || memsz != mem || fseeko(f, (off_t)memsz * (off_t)sizeof(Entry), SEEK_CUR) != 0) {
+            if (!get(f, memsz) || fseeko(f, (off_t)memsz * (off_t)sizeof(Entry), SEEK_CUR) != 0) {
                 free(g);
                 return CM_EINVAL;
             }

@@ -86,10 +86,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         cm_fastq_batch batch;
     } res[2];
     std::vector<std::pair<void *, uint64_t>> pinned;            // parser arrays registered with the runtime (cm_host_register)
-    std::thread writer, parser, gtf_thread;
+    std::thread writer, parser, gtf_thread, free_thread;
     int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
+        if (free_thread.joinable()) free_thread.join();
         if (gtf_thread.joinable()) gtf_thread.join();           // it reads chrs
         if (parser.joinable()) parser.join();
         if (writer.joinable()) writer.join();
@@ -213,8 +214,13 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         const double tu = now();
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_load_annotation(cm, (int)c, &annots[c]), "cm_load_annotation");
         lap("annotation uploaded", tu);
-        for (auto &v : views) cm_host_free_loaded_contig(&v);      // host copies are no longer needed: everything is in HBM
+        // host copies are no longer needed, everything is in HBM: returning ~25 GB to the system takes a second or two, done
+        // off the critical path
+        free_thread = std::thread([old = views]() mutable {
+            for (auto &v : old) cm_host_free_loaded_contig(&v);
+        });
         views.clear();
+        lap("load done", t0);
     }
     st.rounds = (int32_t)n_con;
     st.seconds_load = now() - t0;

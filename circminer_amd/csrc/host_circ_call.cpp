@@ -1081,40 +1081,71 @@ extern "C" int cm_circ_run(const cm_circ_args *a, cm_circ_stats *stats, char *er
     snprintf(r1, sizeof r1, "%s_%d_remain_R1.fastq", out.c_str(), a->last_round);
     snprintf(r2, sizeof r2, "%s_%d_remain_R2.fastq", out.c_str(), a->last_round);
     const std::string s1 = std::string(r1) + ".srt", s2 = std::string(r2) + ".srt";
-    {   // the two files are sorted side by side
-        int rc2 = CM_OK;
-        std::thread t2([&]() { rc2 = cm_sort_remain(r2, s2.c_str()); });
-        const int rc1 = cm_sort_remain(r1, s1.c_str());
-        t2.join();
-        S2_TRY(rc1, "cm_sort_remain (R1)");
-        S2_TRY(rc2, "cm_sort_remain (R2)");
-    }
-    lap("sort remain files");
+    // three things that do not depend on one another run side by side: the two sorts, the genome out of the index file, the GTF
+    int rc_s1 = CM_OK, rc_s2 = CM_OK;
+    std::thread t_s1([&]() { rc_s1 = cm_sort_remain(r1, s1.c_str()); });
+    std::thread t_s2([&]() { rc_s2 = cm_sort_remain(r2, s2.c_str()); });
+    struct Join2 {
+        std::thread &a, &b;
+        ~Join2() {
+            if (a.joinable()) a.join();
+            if (b.joinable()) b.join();
+        }
+    } join_sorts{t_s1, t_s2};
     S2_TRY(cm_host_read_index_info(a->index_info_path, &chrs, &n_chr), "cm_host_read_index_info");
     int32_t kmer = 0, full = 0;
     uint32_t n_rec = 0;
     S2_TRY(cm_host_open_index(a->index_path, &idx, &kmer, &full, &n_rec), "cm_host_open_index");
     cm_params P = a->params;
     if (P.kmer == 0) P.kmer = kmer;
+    // the GTF model needs the contig lengths: those of the .index.info rows first (checked against the index file's below)
+    std::vector<uint32_t> clen_guess;
+    for (uint32_t i = 0; i < n_chr; ++i) {
+        if (chrs[i].contig_id == 0) continue;
+        if (clen_guess.size() < chrs[i].contig_id) clen_guess.resize(chrs[i].contig_id, 0);
+        clen_guess[chrs[i].contig_id - 1] = std::max(clen_guess[chrs[i].contig_id - 1], chrs[i].start_pos + chrs[i].len);
+    }
+    std::vector<cm_annot_view> early(clen_guess.size());
+    int early_rc = CM_EINVAL;
+    std::thread t_gtf([&]() {
+        if (!clen_guess.empty())
+            early_rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen_guess.data(), (uint32_t)clen_guess.size(), P.max_read_len, early.data());
+    });
+    int grc = CM_OK;
     for (;;) {
         cm_index_view iv;
         int loaded = 0;
-        S2_TRY(cm_host_next_contig_genome(idx, &iv, &loaded), "cm_host_next_contig_genome");      // the sequence only: stage 2 never probes the k-mer table
-        if (!loaded) break;
+        grc = cm_host_next_contig_genome(idx, &iv, &loaded);      // the sequence only: stage 2 never probes the k-mer table
+        if (grc != CM_OK || !loaded) break;
         views.push_back(iv);
     }
-    lap("genome from the index file");
+    t_gtf.join();
+    lap("genome from the index file | GTF");
+    if (grc != CM_OK) {
+        if (early_rc == CM_OK) cm_host_free_annotation(early.data(), (uint32_t)early.size());
+        S2_TRY(grc, "cm_host_next_contig_genome");
+    }
     std::vector<uint32_t> clen;
     for (auto &v : views) clen.push_back(v.ref_len);
-    annots.resize(views.size());
-    rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen.data(), (uint32_t)views.size(), P.max_read_len, annots.data());
+    if (early_rc == CM_OK && clen == clen_guess) {
+        annots = early;
+        rc = CM_OK;
+    } else {
+        if (early_rc == CM_OK) cm_host_free_annotation(early.data(), (uint32_t)early.size());
+        annots.resize(views.size());
+        rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen.data(), (uint32_t)views.size(), P.max_read_len, annots.data());
+    }
     if (rc != CM_OK) {
         annots.clear();
         rc = fail(rc, "cm_host_build_annotation failed (%d)", rc);
         cleanup();
         return rc;
     }
-    lap("annotation");
+    t_s1.join();
+    t_s2.join();
+    S2_TRY(rc_s1, "cm_sort_remain (R1)");
+    S2_TRY(rc_s2, "cm_sort_remain (R2)");
+    lap("sorted remain files ready");
     S2_TRY(cm_fastq_open(s1.c_str(), s2.c_str(), chrs, n_chr, P.max_ed, &fq), "cm_fastq_open (sorted remain files)");
     cm_fastq_batch b;
     S2_TRY(cm_fastq_next(fq, ~0ull >> 2, &b), "cm_fastq_next");

@@ -179,6 +179,9 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
             tl = now();
             const int lrc = cm_load_contig(cm, (int)views.size() - 1, &iv);
             lap("contig uploaded + descriptors", tl);
+            // its host copy is dead now (everything is in HBM): returned to the system here, while the next contig is still being
+            // decoded, rather than in one 25-GB sweep next to the FASTQ parser's first page faults
+            cm_host_free_loaded_contig(&views.back());
             ahead.join();
             if (nxt_rc == CM_OK && nxt_loaded && lrc != CM_OK) cm_host_free_loaded_contig(&nxt_iv);
             MAP_TRY(lrc, "cm_load_contig");
@@ -214,12 +217,7 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         const double tu = now();
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_load_annotation(cm, (int)c, &annots[c]), "cm_load_annotation");
         lap("annotation uploaded", tu);
-        // host copies are no longer needed, everything is in HBM: returning ~25 GB to the system takes a second or two, done
-        // off the critical path
-        free_thread = std::thread([old = views]() mutable {
-            for (auto &v : old) cm_host_free_loaded_contig(&v);
-        });
-        views.clear();
+        views.clear();                                              // (their arrays went back after each upload)
         lap("load done", t0);
     }
     st.rounds = (int32_t)n_con;

@@ -465,7 +465,8 @@ def main():
         try:
             with open(args.traffic) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("pairs") == min(args.pairs, 1 << 20):      # pairs per launch (tile)
+            if tj.get("workload") == args.workload and tj.get("pairs") == min(args.pairs, 1 << 20) and \
+                    (args.workload != "hg38like" or "dense" in tj.get("preset", "")):                  # pairs per launch (tile); not the r02 genome's
                 traffic = tj.get("bytes_per_launch", {}).get(KERNELS[dom])
                 traffic_src = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/traffic.json), not this run"
         except Exception:

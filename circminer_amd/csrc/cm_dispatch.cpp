@@ -41,6 +41,7 @@ CM_VARIANTS(int, cm_map_batch, (void *, int, int, const cm_reads *, const cm_map
 CM_VARIANTS(int, cm_seed_batch, (void *, int, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *))
 CM_VARIANTS(int, cm_chain_batch, (void *, int, void *, int32_t *, int32_t *))
 CM_VARIANTS(int, cm_debug_lane_clk, (void *, unsigned long long *))
+CM_VARIANTS(int, cm_debug_counters, (void *, unsigned long long *))
 CM_VARIANTS(int, cm_prof_enable, (void *, int))
 CM_VARIANTS(int, cm_prof_reset, (void *))
 CM_VARIANTS(int, cm_prof_get, (void *, double *, uint64_t *))
@@ -104,6 +105,7 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out, int32_t *nchain, int32_
     return cm_chain_batch_k16(ctx->inner, slot, out, nchain, high);
 }
 int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) { return ctx ? GO(cm_debug_lane_clk, out) : CM_EINVAL; }
+int cm_debug_counters(cm_ctx *ctx, unsigned long long *out) { return ctx ? GO(cm_debug_counters, out) : CM_EINVAL; }
 int cm_prof_enable(cm_ctx *ctx, int on) { return ctx ? GO(cm_prof_enable, on) : CM_EINVAL; }
 int cm_prof_reset(cm_ctx *ctx) { return ctx ? GO(cm_prof_reset) : CM_EINVAL; }
 int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) { return ctx ? GO(cm_prof_get, ms, launches) : CM_EINVAL; }

@@ -86,18 +86,23 @@ __global__ void __launch_bounds__(BLK) k_seed(KCore kc, ReadsDev rd, const uint8
 // k_scan_c: adds the block base.  out[n] = grand total.
 constexpr int SCAN_T = 256;
 constexpr int SCAN_ELEMS = 1024;       // 4 per thread
-__global__ void __launch_bounds__(SCAN_T) k_scan_a(const uint32_t *scnt, int S, uint32_t n, unsigned long long *out, unsigned long long *bsum) {
+__global__ void __launch_bounds__(SCAN_T) k_scan_a(const uint32_t *scnt, int S, uint32_t n, unsigned long long *out, unsigned long long *bsum,
+                                                   unsigned int *bmax) {
     // element k * SCAN_T + t of the block belongs to thread t: consecutive lanes read consecutive problems
     // (28-byte stride, the S loads of a lane reuse its sectors) instead of four problems per lane
     __shared__ unsigned long long sh[SCAN_T];
+    __shared__ unsigned int shmax;
     const uint32_t base = blockIdx.x * SCAN_ELEMS;
     unsigned long long run = 0;
+    unsigned int my_max = 0;                     // the largest problem of the block (cells = retained hits): sizes k_chain_heavy's LDS
+    if (threadIdx.x == 0) shmax = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ELEMS / SCAN_T; ++k) {
         const uint32_t r = base + k * SCAN_T + threadIdx.x;
         uint32_t c = 0;
         if (r < n)
             for (int s = 0; s < S; ++s) c += scnt[(uint64_t)r * S + s];
+        my_max = c > my_max ? c : my_max;
         sh[threadIdx.x] = c;
         __syncthreads();
         for (int d = 1; d < SCAN_T; d <<= 1) {
@@ -110,15 +115,28 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_a(const uint32_t *scnt, int S, 
         run += sh[SCAN_T - 1];
         __syncthreads();
     }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = run;
+    atomicMax(&shmax, my_max);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = run;
+        bmax[blockIdx.x] = shmax;
+    }
 }
-__global__ void __launch_bounds__(1024) k_scan_b(unsigned long long *bsum, uint32_t nb, unsigned long long *total) {
+__global__ void __launch_bounds__(1024) k_scan_b(unsigned long long *bsum, uint32_t nb, unsigned long long *total, const unsigned int *bmax) {
     __shared__ unsigned long long part[1024];
+    __shared__ unsigned int gmax;
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = (nb + 1023u) / 1024u;
     const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
     unsigned long long s = 0;
-    for (uint32_t i = a; i < b; ++i) s += bsum[i];
+    unsigned int m = 0;
+    if (t == 0) gmax = 0;
+    __syncthreads();
+    for (uint32_t i = a; i < b; ++i) {
+        s += bsum[i];
+        m = bmax[i] > m ? bmax[i] : m;
+    }
+    atomicMax(&gmax, m);
     part[t] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -133,7 +151,10 @@ __global__ void __launch_bounds__(1024) k_scan_b(unsigned long long *bsum, uint3
         bsum[i] = run;
         run += x;
     }
-    if (t == 1023) *total = part[1023];
+    if (t == 1023) {
+        total[0] = part[1023];
+        total[1] = gmax;                          // (every atomicMax above is followed by a barrier of the scan)
+    }
 }
 __global__ void __launch_bounds__(SCAN_T) k_scan_c(unsigned long long *out, const unsigned long long *bsum, uint32_t n) {
     const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
@@ -212,11 +233,15 @@ struct RetryArgs {
 #ifndef CM_PAIR_WAVES
 #define CM_PAIR_WAVES 4       // waves per SIMD the pair kernels are compiled for (128 VGPRs; LDS: 2 x lbuf_bytes x 64 per wave)
 #endif
-__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
-                                                   const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
-                                                   int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
-                                                   const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk,
-                                                   RetryArgs ra) {
+// The pair stage's light kernel and its re-run (RetryArgs) are the same code: FIRST = the first pass over the tile (a pair that
+// hits a device capacity is recorded, skipped and queued), !FIRST = the re-run of the queued pairs (k_pair_rerun: spill memo,
+// longer staging buffers, limits fail the call).  Two kernel symbols, so that profiles tell the two launches apart.
+template <bool FIRST>
+__device__ __forceinline__ void pair_kernel(const KCore &kc, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+                                            const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
+                                            int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
+                                            const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk,
+                                            const RetryArgs &ra) {
     const unsigned long long clk0 = lane_clk ? wall_clock64() : 0ull;
     // per-lane staging buffers for the two DP strings, word-interleaved across the wave (cm_core.h LBuf)
     extern __shared__ uint32_t lds_words[];
@@ -265,11 +290,11 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
     // First pass: a device-capacity limit hit by this pair (cmc::ERR_MEMO / ERR_BAND) is recorded in the pair's own word; such
     // a pair keeps its inputs (nothing is written) and is queued for the re-run.  Re-run (ra.first == 0): limits go to the
     // launch-wide word and fail the call -- with the spill memo and the longer staging buffers none is known to be reachable.
-    int *perr = ra.first ? (int *)(ra.pair_err + t) : err;
+    int *perr = FIRST ? (int *)(ra.pair_err + t) : err;
     sm.err = (cmc::g_err)perr;
     const int st = cmc::process_read(c, sm, (cmc::g_u8)(rd.seq1 + a0), (int)(a1 - a0), (cmc::g_u8)(rd.seq2 + b0), (int)(b1 - b0), sets, hh, mr, (cmc::g_err)perr);
     bool keep = true;
-    if (ra.first) {
+    if (FIRST) {
         if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             ra.list[atomicAdd(ra.count, 1u)] = t;
             keep = false;
@@ -286,7 +311,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
         const unsigned long long m = __ballot(1), mk = __ballot(keep);
         if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1 && mk) {
             atomicAdd(&counters[3], (unsigned long long)__popcll(mk));
-            if (!ra.first) atomicAdd(&counters[4], (unsigned long long)__popcll(mk));       // pairs mapped by the re-run launch
+            if (!FIRST) atomicAdd(&counters[4], (unsigned long long)__popcll(mk));       // pairs mapped by the re-run launch
         }
     }
 #if defined(CM_DIAG)
@@ -307,6 +332,22 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, Read
     if (lane_clk) lane_clk[slot] = ((wall_clock64() - it0) & 0xFFFFFFFFull) | ((unsigned long long)t << 32);
 #endif
     }
+}
+
+
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains, const int32_t *nchain,
+                                                   const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
+                                                   int *err, unsigned long long *counters, int str_cap, unsigned long long *lane_clk,
+                                                   const uint32_t *perm, const unsigned int *n_light, unsigned int *next_chunk,
+                                                   RetryArgs ra) {
+    pair_kernel<true>(kc, rd, pair0, n_tile, chains, nchain, high, state, active, cat, is_last, err, counters, str_cap, lane_clk, perm, n_light, next_chunk, ra);
+}
+__global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_pair_rerun(KCore kc, ReadsDev rd, uint64_t pair0, uint32_t n_tile, const cm_chain *chains,
+                                                         const int32_t *nchain, const int32_t *high, cm_mapped_read *state, uint8_t *active, int32_t *cat,
+                                                         int is_last, int *err, unsigned long long *counters, int str_cap,
+                                                         unsigned long long *lane_clk, const uint32_t *perm, const unsigned int *n_light,
+                                                         unsigned int *next_chunk, RetryArgs ra) {
+    pair_kernel<false>(kc, rd, pair0, n_tile, chains, nchain, high, state, active, cat, is_last, err, counters, str_cap, lane_clk, perm, n_light, next_chunk, ra);
 }
 
 // ---- wave-cooperative chaining of heavy problems ----------------------------------------------
@@ -330,6 +371,9 @@ template <class T> __device__ inline T wave_excl_scan(T v, int lane, T &total) {
     return x - v;
 }
 struct HeavyChainCtx {
+#if defined(CM_CHAIN_DIAG)
+    unsigned long long *tk;      // per-lane ticks: [0] binary searches, [1] upper_bound, [2] window loops, [3] cells, [4] pair evaluations
+#endif
     const Core *c;
     CM_L const uint32_t *LP;     // hit positions of every slot, concatenated (LDS)
     const uint32_t *base, *cnt;  // per slot (uniform)
@@ -350,21 +394,49 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
     double my_score = (double)kmer;
     int32_t my_prev = -1;
     uint32_t n = 0;
+    // the near-border bit of this hit (one random 8-byte read out of a 130-MB bitset: an HBM round trip) is asked for now and
+    // needed only after the first binary search: nearly every cell of a heavy problem gets that far
+    const bool near = cmc::bit_at(c.A.near_border_bits, c.A.n_bits, seg_start);
+#if defined(CM_CHAIN_DIAG)
+    if (!ev) h.tk[3] += 1;
+#define CD_T0 const unsigned long long cd_t = wall_clock64()
+#define CD_ADD(k) h.tk[k] += wall_clock64() - cd_t
+#else
+#define CD_T0
+#define CD_ADD(k)
+#endif
     for (int jj = ii + 1; jj < h.kc; ++jj) {
         const uint32_t pcn = h.cnt[jj];
         if (pcn == 0) continue;
         CM_L const uint32_t *pp = h.LP + h.base[jj];
         uint32_t lo = 0, hi = pcn;                   // first hit of jj strictly right of this hit
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((int32_t)pp[mid] <= cur_info) lo = mid + 1;
-            else hi = mid;
+        {
+            CD_T0;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((int32_t)pp[mid] <= cur_info) lo = mid + 1;
+                else hi = mid;
+            }
+            CD_ADD(0);
         }
         if (lo >= pcn) continue;
         if (cur_info + c.P.max_intron < (int32_t)pp[lo]) continue;      // nothing within maxIntronLen
-        if (max_lpos_lim == cmc::MAXUB) max_lpos_lim = cmc::upper_bound(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
+        if (max_lpos_lim == cmc::MAXUB) {           // cmc::upper_bound with its bit test hoisted (see `near`)
+            CD_T0;
+            if (near) max_lpos_lim = cmc::upper_bound_lookup(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
+            else {
+                max_exon_end = 0;
+                ol = -1;
+                max_lpos_lim = seg_start + read_remain + (uint32_t)c.P.max_ed;
+            }
+            CD_ADD(1);
+        }
         const int distr = (jj - ii) * kmer - kmer;
+        CD_T0;
         for (uint32_t j = lo; j < pcn && pp[j] <= max_lpos_lim; ++j) {
+#if defined(CM_CHAIN_DIAG)
+            if (!ev) h.tk[4] += 1;
+#endif
             const uint32_t pinfo = pp[j];
             int genome_dist, distt, trans_dist;
             if (max_exon_end == 0 || (pinfo + kmer - 1) <= max_exon_end) genome_dist = (int)(pinfo - seg_end - 1);
@@ -389,6 +461,7 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
                 ++n;
             }
         }
+        CD_ADD(2);
     }
     out_score = my_score;
     out_prev = my_prev;
@@ -457,7 +530,13 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
 #if defined(CM_CHAIN_DIAG)
         const unsigned long long dg1 = wall_clock64();
 #endif
+#if defined(CM_CHAIN_DIAG)
+        unsigned long long tk[5] = {0, 0, 0, 0, 0};
+        unsigned long long wv[4] = {0, 0, 0, 0};       // wave time: first evaluation, scan + log growth, store / second evaluation, barrier
+        HeavyChainCtx H{tk, &c, LP, base, cn, kc, len, dps, dpp};
+#else
         HeavyChainCtx H{&c, LP, base, cn, kc, len, dps, dpp};
+#endif
         CM_G cmc::Event *ev = nullptr;
         uint32_t n_ev = 0, cap_ev = 0;
         bool lost = false;
@@ -467,7 +546,13 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
                 const bool on = i < cn[ii];
                 double sc = 0, e0 = 0, e1 = 0;
                 int32_t pv = -1;
+#if defined(CM_CHAIN_DIAG)
+                const unsigned long long w0 = wall_clock64();
+#endif
                 const uint32_t mine = on ? heavy_cell(H, ii, i, (CM_G cmc::Event *)nullptr, sc, pv, e0, e1) : 0u;
+#if defined(CM_CHAIN_DIAG)
+                const unsigned long long w1 = wall_clock64();
+#endif
                 uint32_t total;
                 const uint32_t off = wave_excl_scan(mine, lane, total);
                 if (n_ev + total > cap_ev && !lost) {                 // grow the log (uniform decision)
@@ -503,10 +588,26 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
                     dpp[base[ii] + i] = pv;
                 }
                 if (!lost) n_ev += total;
+#if defined(CM_CHAIN_DIAG)
+                const unsigned long long w3 = wall_clock64();
+                wv[0] += w1 - w0;
+                wv[2] += w3 - w1;
+#endif
             }
+#if defined(CM_CHAIN_DIAG)
+            const unsigned long long w4 = wall_clock64();
+#endif
             __threadfence_block();
             __syncthreads();
+#if defined(CM_CHAIN_DIAG)
+            wv[3] += wall_clock64() - w4;
+#endif
         }
+#if defined(CM_CHAIN_DIAG)
+        for (int k = 0; k < 5; ++k) atomicAdd(&counters[8 + k], tk[k]);          // lane sums
+        if (lane == 0)
+            for (int k = 0; k < 4; ++k) atomicAdd(&counters[16 + k], wv[k]);      // wave times
+#endif
         // ---- back-tracking (src/chain.cpp:242-298), wave-parallel.  The reference walks the scores downwards; per score it takes
         // the first <= maxChainLen logged cells in insertion order, skips one whose start is a non-first fragment of a chain
         // already emitted (only below the best score), and emits the others until maxChainLen chains are out.  Here, per score:
@@ -1250,6 +1351,7 @@ struct cm_ctx {
     uint32_t tile = 0;
     uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
     unsigned long long *d_celloff = nullptr, *d_bsum = nullptr;
+    unsigned int *d_bmax = nullptr;
     double *d_dpscore = nullptr;
     int32_t *d_dpprev = nullptr;
     unsigned long long cells_cap = 0;
@@ -1350,7 +1452,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_active_b); dfree(c->d_cat);
     dfree(c->d_chains_b); dfree(c->d_nchain_b); dfree(c->d_high_b); dfree(c->d_resid_b); dfree(c->d_cctr); dfree(c->d_cblk);
-    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum);
+    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum); dfree(c->d_bmax);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist);
@@ -1440,14 +1542,15 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
     {
         Timer t(ctx, 3);
         const uint32_t nb = (n_prob + SCAN_ELEMS - 1) / SCAN_ELEMS;
-        hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(SCAN_T), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_celloff, ctx->d_bsum);
-        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_bsum, nb, ctx->d_celloff + n_prob);
+        hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(SCAN_T), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_celloff, ctx->d_bsum, ctx->d_bmax);
+        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_bsum, nb, ctx->d_celloff + n_prob, (const unsigned int *)ctx->d_bmax);
         hipLaunchKernelGGL(k_scan_c, dim3((n_prob + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, ctx->stream, ctx->d_celloff, ctx->d_bsum, n_prob);
         ctx->launches[3] += 3;
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_celloff + n_prob, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_celloff + n_prob, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned long long total = ctx->h_pin[0];
+    const unsigned long long max_cells = ctx->h_pin[1];       // of one problem
     // problem ranges whose DP cells fit the workspace
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
     if (total <= ctx->cells_cap) {
@@ -1472,7 +1575,11 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
     static const char *split_env = getenv("CM_CHAIN_SPLIT");
     static const unsigned long long light_w = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 256ull;
     static const unsigned int light_cells = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 96u;
-    const size_t heavy_lds = (size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t);
+    // k_chain_heavy keeps a problem's hit positions in LDS: sized for the largest problem of this tile (a multiple of 2 KB, so
+    // that launches of similar tiles share a configuration), not for the n_seeds x seed_lim a problem could have in theory --
+    // the kernel waits on memory most of the time and the LDS request decides how many waves a CU holds.
+    const size_t heavy_lds = std::min<size_t>((size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t),
+                                              ((size_t)max_cells * sizeof(uint32_t) + 2047) / 2048 * 2048 + 2048);
     const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;
     if (split) {
         Timer t(ctx, 5);
@@ -1631,13 +1738,13 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     }
     if (hipMalloc((void **)&ctx->d_pool_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault) != hipSuccess) {
         delete ctx;
         return CM_ENOMEM;
     }
     (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);
-    (void)hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), ctx->stream);
     if (getenv("CM_ONE_STREAM")) {           // diagnostic: no concurrency between the light and the heavy kernels
         (void)hipStreamDestroy(ctx->stream2);
         ctx->stream2 = ctx->stream;
@@ -1836,7 +1943,8 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_scnt, nprobe * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_sraw, nprobe * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_cells, nprob * 4));
-    HIPCHK(ctx, ensure(ctx, ctx->d_celloff, (nprob + 1) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_celloff, (nprob + 2) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_bmax, (nprob / SCAN_ELEMS + 2) * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_bsum, (nprob / SCAN_ELEMS + 2) * 8));
     // DP cells: room for 64 cells per problem on average, at least 8M (one worst-case problem is
     // n_seeds * seed_lim cells); larger tiles are split into ranges by run_chain_tile.
@@ -2039,7 +2147,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     const int cap2 = std::min(((2 * ctx->max_len + 64 + 7) / 8) * 8, 1016);      // 1016: 64 KB of LDS per wave
     const size_t lds2 = (size_t)2 * lbuf_bytes(cap2) * BLK_PAIR;
     if (lds_heavy > 48 * 1024 || lds2 > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_bytes, lds2)));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_rerun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_heavy));
     }
     {
@@ -2105,7 +2214,7 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         // the same kernel over the re-run list, one pair per lane, memo spill area, staging buffers for strings of any length a
         // read of this batch can produce.  It ends before ev_pair[b] frees this item's chain records.
         const RetryArgs ra2{ctx->d_pair_err, ctx->d_retry_list, ctx->d_cls_ctr + CTR_RETRY, ctx->d_spill, RETRY_SPILL, 0};
-        hipLaunchKernelGGL(k_pair, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
+        hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,
                            (const uint32_t *)ctx->d_retry_list, (const unsigned int *)(ctx->d_cls_ctr + CTR_RETRY), ctx->d_cls_ctr + CTR_RETRY + 1, ra2);
     }
@@ -2495,6 +2604,15 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
 }
 
 /* diagnostic: per-pair k_pair lane time in 100 MHz ticks (only when CM_LANE_CLK was set at upload) */
+// diagnostic builds (-DCM_CHAIN_DIAG ...): the 32 raw counter words, [8..31] = whatever the build accumulates there
+int cm_debug_counters(cm_ctx *ctx, unsigned long long *out) {
+    if (!ctx || !out) return CM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_counters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CM_OK;
+}
+
 int cm_debug_lane_clk(cm_ctx *ctx, unsigned long long *out) {
     if (!ctx || !out || !ctx->d_lane_clk) return CM_EINVAL;
 #if defined(CM_DIAG)
@@ -2524,7 +2642,7 @@ int cm_prof_reset(cm_ctx *ctx) {
         ctx->ms[i] = 0;
         ctx->launches[i] = 0;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CM_OK;
 }

@@ -25,4 +25,13 @@ print("stage ms:", [round(x, 2) for x in ms], "launches", nl)
 t = [c / 1e5 for c in cnt[5:8]]          # ms of wave time
 print(f"k_chain_heavy wave-ms: load+init {t[0]:.0f}, DP {t[1]:.0f}, back-tracking {t[2]:.0f}  (sum {sum(t):.0f}; "
       f"3072 resident waves -> {sum(t) / 3072:.2f} ms if perfectly packed)")
+import ctypes as C
+raw = (C.c_ulonglong * 32)()
+hp.L.cm_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+hp.L.cm_debug_counters(hp.h, raw)
+tk = [raw[8 + k] for k in range(5)]
+wv = [raw[16 + k] / 1e5 for k in range(4)]
+print(f"DP, lane time (ms, summed over lanes): binary searches {tk[0] / 1e5:.0f}, upper_bound {tk[1] / 1e5:.0f}, window loops {tk[2] / 1e5:.0f}; "
+      f"{tk[3]} cells, {tk[4]} pair evaluations ({tk[4] / max(tk[3], 1):.2f} per cell)")
+print(f"DP, wave time (ms): first evaluation {wv[0]:.0f}, scan + store + second evaluation {wv[2]:.0f}, barriers {wv[3]:.0f}")
 hp.close()

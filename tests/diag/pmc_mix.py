@@ -17,3 +17,8 @@ for k in sorted(acc, key=lambda k: -acc[k].get('SQ_INSTS_VALU', 0))[:8]:
     a = acc[k]
     if a.get('SQ_ACTIVE_INST_VALU'):
         print('   lanes per VALU instruction   %.1f' % (a['SQ_THREAD_CYCLES_VALU'] / a['SQ_ACTIVE_INST_VALU']))
+    if a.get('SQ_BUSY_CYCLES') and a.get('SQ_ACTIVE_INST_VALU'):
+        # SQ_ACTIVE_INST_VALU: cycles (x4, per SIMD quad-cycle) a VALU instruction was executing; SQ_WAVE_CYCLES: wave-resident cycles
+        print('   VALU busy / wave cycles      %.3f' % (a['SQ_ACTIVE_INST_VALU'] / max(a.get('SQ_WAVE_CYCLES', 0), 1)))
+    if a.get('SQ_LDS_IDX_ACTIVE'):
+        print('   LDS bank-conflict cycles / LDS active cycles   %.3f' % (a.get('SQ_LDS_BANK_CONFLICT', 0) / a['SQ_LDS_IDX_ACTIVE']))

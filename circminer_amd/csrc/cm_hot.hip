@@ -1313,7 +1313,8 @@ struct cm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // The pair stage of round r runs on its own pair of streams while `stream` / `stream2` already seed and chain round r + 1
     // (cm_map_rounds): seeds and chains are functions of (read, contig) only, the carried state enters in the pair stage.
-    hipStream_t stream_p = nullptr, stream_p2 = nullptr;
+    hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_p3 = nullptr;      // p3: the re-run launch of the pair stage (RetryArgs)
+    hipEvent_t ev_first[2] = {nullptr, nullptr};      // an item's two pair kernels are done (set b): its re-run may start
     hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
     bool pair_pending[2] = {false, false};
     // cross-batch prefetch (cm_map_rounds): the staged batch's first round seeded and chained under this batch's last pair stage
@@ -1382,6 +1383,7 @@ struct cm_ctx {
     uint32_t *d_hlist = nullptr;
     HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
     unsigned long long *d_type_hist = nullptr;
+    unsigned int *d_retry_ctr = nullptr;                          // [set][count, cursor]
     uint32_t *d_pair_err = nullptr, *d_retry_list = nullptr;      // per-pair capacity flags of a tile (zero between launches), pairs to re-run (RetryArgs)
     cmc::MemoSpill *d_spill = nullptr;                            // RETRY_GRID x 64 lanes x RETRY_SPILL overflow entries of the extension memo
     uint8_t *d_pool = nullptr;
@@ -1455,7 +1457,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum); dfree(c->d_bmax);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist);
+    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist); dfree(c->d_retry_ctr);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
@@ -1722,6 +1724,9 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_p3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_first[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_first[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork_p, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join_p, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep[0], hipEventDisableTiming) != hipSuccess ||
@@ -1760,6 +1765,7 @@ void cm_destroy(cm_ctx *ctx) {
     if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream_p) (void)hipStreamSynchronize(ctx->stream_p);
     if (ctx->stream_p2) (void)hipStreamSynchronize(ctx->stream_p2);
+    if (ctx->stream_p3) (void)hipStreamSynchronize(ctx->stream_p3);
     for (auto e : ctx->ev_free) (void)hipEventDestroy(e);
     ctx->ev_free.clear();
     for (auto &r : ctx->recs) {
@@ -1780,8 +1786,10 @@ void cm_destroy(cm_ctx *ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (hipEvent_t e : {ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail})
+    for (hipEvent_t e : {ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail, ctx->ev_first[0],
+                         ctx->ev_first[1]})
         if (e) (void)hipEventDestroy(e);
+    if (ctx->stream_p3) (void)hipStreamDestroy(ctx->stream_p3);
     if (ctx->stream_p) (void)hipStreamDestroy(ctx->stream_p);
     if (ctx->stream_p2) (void)hipStreamDestroy(ctx->stream_p2);
     if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
@@ -1973,10 +1981,11 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)HEAVY_GRID_MAX * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
     {
         const uint32_t *before = ctx->d_pair_err;
-        HIPCHK(ctx, ensure(ctx, ctx->d_pair_err, (size_t)tile * 4));
-        if (ctx->d_pair_err != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_err, 0, (size_t)tile * 4, ctx->stream_p));   // the kernels keep it zero
+        HIPCHK(ctx, ensure(ctx, ctx->d_pair_err, (size_t)tile * 4 * 2));      // one set per set of chain records (run_pair_tile)
+        if (ctx->d_pair_err != before) HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_err, 0, (size_t)tile * 4 * 2, ctx->stream_p));   // the kernels keep it zero
     }
-    HIPCHK(ctx, ensure(ctx, ctx->d_retry_list, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_retry_list, (size_t)tile * 4 * 2));
+    HIPCHK(ctx, ensure(ctx, ctx->d_retry_ctr, 4 * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_spill, (size_t)RETRY_GRID * BLK_PAIR * RETRY_SPILL * sizeof(cmc::MemoSpill)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
@@ -2124,11 +2133,18 @@ int cm_reads_swap(cm_ctx *ctx) {
 
 // The pair stage of one tile and round on the pair streams: waits for that item's chains (ev_prep[b]), reads the flags
 // act_in, writes act_out for every pair of the tile, signals ev_pair[b] when the chain buffers of set b are free again.
+// same_tile_as_prev: the previous item was this tile's previous round -- its re-run launch (stream p3) wrote states and flags this
+// item's pair kernels read; every other consumer is ordered behind the re-run through ev_pair[].
 static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t nt, int is_last_round, const uint8_t *act_in, uint8_t *act_out,
-                         const RoundBufs &rb, int b) {
+                         const RoundBufs &rb, int b, bool same_tile_as_prev) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
-    hipStream_t sp = ctx->stream_p, sp2 = ctx->stream_p2;
+    hipStream_t sp = ctx->stream_p, sp2 = ctx->stream_p2, sp3 = ctx->stream_p3;
     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
+    if (same_tile_as_prev && ctx->pair_pending[b ^ 1]) HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pair[b ^ 1], 0));
+    // (the re-run list, its counters and the per-pair flags exist once per set of chain records, like those: item i + 1 leaves
+    // item i's alone, item i + 2 starts after ev_pair[b])
+    uint32_t *pair_err = ctx->d_pair_err + (size_t)b * ctx->tile, *retry_list = ctx->d_retry_list + (size_t)b * ctx->tile;
+    unsigned int *retry_ctr = ctx->d_retry_ctr + 2 * b;
     // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
     // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
     const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
@@ -2177,8 +2193,9 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                            ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 4 * sizeof(unsigned int), sp));     // both cursors, re-run count + cursor
-    const RetryArgs ra1{ctx->d_pair_err, ctx->d_retry_list, ctx->d_cls_ctr + CTR_RETRY, nullptr, 0, 1};
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), sp));     // both work cursors
+    HIPCHK(ctx, hipMemsetAsync(retry_ctr, 0, 2 * sizeof(unsigned int), sp));                     // re-run count + cursor of this set
+    const RetryArgs ra1{pair_err, retry_list, retry_ctr, nullptr, 0, 1};
     // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
     // behind it.
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
@@ -2210,15 +2227,21 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                            ctx->d_cls_ctr + CTR_SUM, ctx->d_cls_ctr + CTR_NEXT, ra1);
         HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
         ++ctx->launches[2];
-        // the re-run of whatever the two kernels queued (usually nothing: the launch reads the count on the device and ends):
-        // the same kernel over the re-run list, one pair per lane, memo spill area, staging buffers for strings of any length a
-        // read of this batch can produce.  It ends before ev_pair[b] frees this item's chain records.
-        const RetryArgs ra2{ctx->d_pair_err, ctx->d_retry_list, ctx->d_cls_ctr + CTR_RETRY, ctx->d_spill, RETRY_SPILL, 0};
-        hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
-                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,
-                           (const uint32_t *)ctx->d_retry_list, (const unsigned int *)(ctx->d_cls_ctr + CTR_RETRY), ctx->d_cls_ctr + CTR_RETRY + 1, ra2);
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp));
+    // The re-run of whatever the two kernels queued (usually nothing: the launch reads the count on the device and ends): the same
+    // code over the re-run list, one pair per lane, memo spill area, staging buffers for strings of any length a read of this
+    // batch can produce.  On a stream of its own: a launch of 8 blocks behind kernels that fill the chip can wait milliseconds
+    // for its turn (2.5 ms on average on the hg38-like bench), and only the consumers of this item's results have to wait for
+    // it -- ev_pair[b] (chain records of set b free, flags and states of the tile final) is recorded behind it.
+    HIPCHK(ctx, hipEventRecord(ctx->ev_first[b], sp));
+    HIPCHK(ctx, hipStreamWaitEvent(sp3, ctx->ev_first[b], 0));
+    {
+        const RetryArgs ra2{pair_err, retry_list, retry_ctr, ctx->d_spill, RETRY_SPILL, 0};
+        hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp3, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
+                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,
+                           (const uint32_t *)retry_list, (const unsigned int *)retry_ctr, retry_ctr + 1, ra2);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp3));
     ctx->pair_pending[b] = true;
     HIPCHK(ctx, hipGetLastError());
     return CM_OK;
@@ -2289,7 +2312,8 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
             HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         }
         const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
-        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b))) return bail(rc);
+        const bool same_tile = i > 0 && items[i - 1].p0 == p0;
+        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile))) return bail(rc);
         ++*items_done;
         if (++tiles_of_round[(size_t)r] == (int)n_tiles) ++*rounds_done;
         static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
@@ -2330,7 +2354,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         ctx->pre_nt = nt;
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
-    HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p3));               // (p3's last launch waits for p's last)
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;                     // covered by the wait above
     if (n_rounds & 1) std::swap(ctx->d_active, ctx->d_active_b);             // the current flags are in the other array now
@@ -2356,6 +2380,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream_p);
     (void)hipStreamSynchronize(ctx->stream_p2);
+    (void)hipStreamSynchronize(ctx->stream_p3);
     ctx->item_base = (ctx->item_base + items_done) & 1;
     if (rounds_done & 1) std::swap(ctx->d_active, ctx->d_active_b);
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;

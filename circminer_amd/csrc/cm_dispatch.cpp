@@ -112,15 +112,3 @@ int cm_prof_get(cm_ctx *ctx, double ms[8], uint64_t launches[8]) { return ctx ? 
 int cm_prof_counters(cm_ctx *ctx, uint64_t c[8]) { return ctx ? GO(cm_prof_counters, c) : CM_EINVAL; }
 
 }  // extern "C"
-
-// sizeof of every struct that crosses the ABI, in the order of the header: lets a binding (ctypes, cgo, JNI) check its mirrors
-extern "C" int cm_abi_sizes(uint32_t *out, uint32_t cap) {
-    const uint32_t v[] = {(uint32_t)sizeof(cm_params),       (uint32_t)sizeof(cm_index_view),  (uint32_t)sizeof(cm_annot_view), (uint32_t)sizeof(cm_mapped_read),
-                          (uint32_t)sizeof(cm_reads),        (uint32_t)sizeof(cm_record),      (uint32_t)sizeof(cm_chr_info),   (uint32_t)sizeof(cm_fastq_batch),
-                          (uint32_t)sizeof(cm_mapping_args), (uint32_t)sizeof(cm_mapping_stats), (uint32_t)sizeof(cm_circ_res), (uint32_t)sizeof(cm_circ_args),
-                          (uint32_t)sizeof(cm_circ_stats)};
-    const uint32_t n = (uint32_t)(sizeof v / sizeof v[0]);
-    if (!out || cap < n) return CM_EINVAL;
-    for (uint32_t i = 0; i < n; ++i) out[i] = v[i];
-    return (int)n;
-}

@@ -85,7 +85,8 @@ struct SegRec { uint32_t start, end, next_exon_beg, gene_id, tid_off, ntid, pad0
 struct TrRec { int32_t start_ind; uint32_t t2s_off, t2s_len, pad; };
 struct GeneRec { uint32_t start, end; };
 struct AnnotDev {            // plain-pointer form (kernel argument / host side)
-    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket, pad;
+    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket;
+    uint32_t pair_reach;         // see pair_code(): no two chains farther apart than this share a transcript or lie in one gene span
     uint64_t n_bits;
     const IvRec *iv;
     const uint32_t *iv_seg;
@@ -100,7 +101,7 @@ struct AnnotDev {            // plain-pointer form (kernel argument / host side)
     const uint32_t *iv_bucket;
 };
 struct AnnotV {              // the same with global-qualified pointers (device code)
-    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket;
+    uint32_t n_iv, n_seg, n_trans, n_gene, n_chr, iv_bucket_shift, n_iv_bucket, pair_reach;
     uint64_t n_bits;
     const CM_G IvRec *iv;
     g_u32 iv_seg;
@@ -123,7 +124,7 @@ CM_HD inline IndexV to_dev(const cm_index_view &v) {
 CM_HD inline AnnotV to_dev(const AnnotDev &v) {
     AnnotV d;
     d.n_iv = v.n_iv; d.n_seg = v.n_seg; d.n_trans = v.n_trans; d.n_gene = v.n_gene; d.n_chr = v.n_chr;
-    d.iv_bucket_shift = v.iv_bucket_shift; d.n_iv_bucket = v.n_iv_bucket; d.n_bits = v.n_bits;
+    d.iv_bucket_shift = v.iv_bucket_shift; d.n_iv_bucket = v.n_iv_bucket; d.n_bits = v.n_bits; d.pair_reach = v.pair_reach;
     d.iv = (const CM_G IvRec *)v.iv; d.iv_seg = (g_u32)v.iv_seg; d.seg = (const CM_G SegRec *)v.seg; d.seg_tid = (g_u32)v.seg_tid;
     d.tr = (const CM_G TrRec *)v.tr; d.t2s = (g_u8)v.t2s; d.gene = (const CM_G GeneRec *)v.gene;
     d.near_border_bits = (g_u64)v.near_border_bits; d.intronic_bits = (g_u64)v.intronic_bits;
@@ -2156,8 +2157,17 @@ CM_HD inline bool fold_task(const Core &c, const MM &r1, const MM &r2, bool is_l
     return false;
 }
 // the pairing predicate of pair_chains for one (i, j): 0 = not paired, else pair type + 1
+// Quick exact reject (the 30 x 30 chain pairs of a read from a repeat family are mostly copies megabases apart): let d = the
+// distance of the two chain starts.  d > MAXDISCRDTLEN makes tlen > MAXDISCRDTLEN (tlen spans both starts).  same_tr needs a
+// transcript T with a segment in both starts' intervals, so d <= the extent of T's intervals; same_gen needs a gene whose span
+// contains one chain while a segment of it lies in the other start's interval, so d <= the hull of that interval and that gene
+// span.  pair_reach = the largest such extent / hull of the contig's annotation (cm_aos.h); beyond it none of the three holds.
 CM_HD inline uint32_t pair_code(const Core &c, const CHEnds &F, const CHEnds &R, int fe_i, int re_j, int saved_type) {
     const uint32_t fs = F.r0, rs = R.r0, fe_ = F.rend, re_ = R.rend;
+    {
+        const uint32_t d = fs > rs ? fs - rs : rs - fs;
+        if (d > (uint32_t)MAXDISCRDTLEN && d > c.A.pair_reach) return 0u;
+    }
     const int tlen = (int)((fs < rs) ? (re_ - fs) : (fe_ - rs));
     bool same_tr = false, same_gen = false;
     if (fe_i >= 0 && re_j >= 0) same_tr = any_common_tid(c, fe_i, re_j);

@@ -1859,6 +1859,7 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     cmc::AnnotDev &A = s.A;
     A = cmc::AnnotDev{};
     A.n_iv = av->n_iv; A.n_seg = av->n_seg; A.n_trans = av->n_trans; A.n_gene = av->n_gene; A.n_chr = av->n_chr; A.n_bits = av->n_bits;
+    A.pair_reach = aos.pair_reach;
     int rc;
     auto &al = s.ann_allocs;
     if ((rc = up(ctx, al, aos.iv.data(), aos.iv.size(), &A.iv))) return rc;

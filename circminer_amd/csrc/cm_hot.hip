@@ -290,8 +290,12 @@ __device__ __forceinline__ void pair_kernel(const KCore &kc, const ReadsDev &rd,
     // First pass: a device-capacity limit hit by this pair (cmc::ERR_MEMO / ERR_BAND) is recorded in the pair's own word; such
     // a pair keeps its inputs (nothing is written) and is queued for the re-run.  Re-run (ra.first == 0): limits go to the
     // launch-wide word and fail the call -- with the spill memo and the longer staging buffers none is known to be reachable.
+#if defined(CM_AB_GLOBAL_ERR)          // A/B experiment only: what the per-pair error word costs (results wrong for pairs over a capacity)
+    int *perr = err;
+#else
     int *perr = FIRST ? (int *)(ra.pair_err + t) : err;
     sm.err = (cmc::g_err)perr;
+#endif
     const int st = cmc::process_read(c, sm, (cmc::g_u8)(rd.seq1 + a0), (int)(a1 - a0), (cmc::g_u8)(rd.seq2 + b0), (int)(b1 - b0), sets, hh, mr, (cmc::g_err)perr);
     bool keep = true;
     if (FIRST) {
@@ -835,12 +839,43 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
         if (k == c) rank_in_wave = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
     }
 }
+// Where the light / heavy line of the pair stage goes depends on how much heavy work a tile holds.  The two pair kernels run side
+// by side and the stage ends with the later one.  With little heavy work (chr21, the round-2 genome: a few percent of the pairs
+// come from repeats) the heavy kernel is done long before the light one, and every multi-chain pair is best given a wave of its
+// own (threshold 6: 95 vs 57 M pairs/s on chr21 against 48).  On the section-8(d) genome a sixth of the pairs are heavy, most of
+// them with 30 x 30 chain pairs; the heavy kernel is the long pole, the light kernel has slack, and the many mid-cost pairs
+// (7 .. 48) fill whole waves of the light kernel with their like (they are sorted by cost): threshold 48 (16.7 vs 15.0 M pairs/s).
+// k_pair_cost adds up the cost beyond HEAVY_COST over the tile; k_pair_cls takes the wide threshold when that sum exceeds
+// HEAVY_LOAD per pair of the tile.  Results never depend on the split.
+constexpr int HEAVY_COST_WIDE = 48;
+constexpr unsigned long long HEAVY_LOAD = 16;
+__global__ void __launch_bounds__(BLK) k_pair_cost(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, int base_cost,
+                                                  unsigned long long *sum) {
+    __shared__ unsigned long long sh[BLK / 64];
+    const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+    unsigned long long v = 0;
+    if (t < n_tile && active[pair0 + t]) {
+        const int32_t *nc = nchain + 4 * (uint64_t)t;
+        const int a = nc[0], b = nc[1], cc = nc[2], d = nc[3];
+        const int cost = a * d + cc * b + a + b + cc + d;
+        if ((a + b) > 0 && (cc + d) > 0 && cost > base_cost) v = (unsigned long long)cost;
+    }
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s2 = 0;
+        for (int w = 0; w < BLK / 64; ++w) s2 += sh[w];
+        if (s2) atomicAdd(sum, s2);
+    }
+}
 __global__ void __launch_bounds__(BLK) k_pair_cls(KCore kc, const cm_chain *chains, const uint16_t *resid, const int32_t *nchain,
                                                  const uint8_t *active, uint64_t pair0, uint32_t n_tile, int8_t *cls, int32_t *cat, int heavy_cost,
-                                                 int8_t *cls_sub, int8_t *cls_sub2, uint8_t *act_out) {
+                                                 int8_t *cls_sub, int8_t *cls_sub2, uint8_t *act_out, const unsigned long long *heavy_load) {
     const uint32_t t = blockIdx.x * BLK + threadIdx.x;
     if (t >= n_tile) return;
     const Core c = cmc::to_core(kc);
+    if (heavy_load && *heavy_load > HEAVY_LOAD * (unsigned long long)n_tile) heavy_cost = HEAVY_COST_WIDE;
     int sub = 0;
     const int k = pair_class(c, chains, resid, nchain, active, pair0, t, heavy_cost, &sub);
     cls[t] = (int8_t)k;
@@ -1186,8 +1221,12 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
         }
         cm_mapped_read mr = state[p];
         int st = -1;
+#if defined(CM_AB_GLOBAL_ERR)
+        int *perr = err;
+#else
         int *perr = (int *)(ra.pair_err + t);        // capacity limits of this pair (see RetryArgs): every lane of the wave flags the same word
         sm.err = (cmc::g_err)perr;
+#endif
         const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
         if (n1 + n2 <= 0) {             // unreachable for a pair classified heavy; kept for completeness
             st = ((hh[0] + hh[1] > 0) && (hh[2] + hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
@@ -1211,7 +1250,10 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
             }
             if (st < 0) st = __shfl(mr.type, 0);
         }
-        __threadfence();
+        // the wave's own atomicOr's on the pair's word have reached the L2 after this (a workgroup-scope fence = s_waitcnt for a
+        // one-wave block; an agent-scope __threadfence() here invalidated the CU's vector L1 once per heavy pair and cost every
+        // kernel on the chip 10 - 15 %)
+        __threadfence_block();
         if (lane == 0) {
             if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 ra.list[atomicAdd(ra.count, 1u)] = t;          // left as it was; the re-run launch of k_pair maps it (one lane, exact)
@@ -1384,6 +1426,7 @@ struct cm_ctx {
     HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
     unsigned long long *d_type_hist = nullptr;
     unsigned int *d_retry_ctr = nullptr;                          // [set][count, cursor]
+    unsigned long long *d_heavy_load = nullptr;                   // cost beyond HEAVY_COST summed over the tile in the pair stage (k_pair_cost)
     uint32_t *d_pair_err = nullptr, *d_retry_list = nullptr;      // per-pair capacity flags of a tile (zero between launches), pairs to re-run (RetryArgs)
     cmc::MemoSpill *d_spill = nullptr;                            // RETRY_GRID x 64 lanes x RETRY_SPILL overflow entries of the extension memo
     uint8_t *d_pool = nullptr;
@@ -1457,7 +1500,7 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum); dfree(c->d_bmax);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist); dfree(c->d_retry_ctr);
+    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist); dfree(c->d_retry_ctr); dfree(c->d_heavy_load);
     dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
@@ -1987,6 +2030,7 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     }
     HIPCHK(ctx, ensure(ctx, ctx->d_retry_list, (size_t)tile * 4 * 2));
     HIPCHK(ctx, ensure(ctx, ctx->d_retry_ctr, 4 * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_heavy_load, sizeof(unsigned long long)));
     HIPCHK(ctx, ensure(ctx, ctx->d_spill, (size_t)RETRY_GRID * BLK_PAIR * RETRY_SPILL * sizeof(cmc::MemoSpill)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
@@ -2171,9 +2215,16 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     {
         Timer t(ctx, 5, sp);
         const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
-        static const int heavy_cost = getenv("CM_HEAVY_COST") ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
+        static const bool fixed_cost = getenv("CM_HEAVY_COST") != nullptr;             // tuning knob: no adaptive threshold
+        static const int heavy_cost = fixed_cost ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
+        unsigned long long *load = nullptr;
+        if (!fixed_cost) {
+            load = ctx->d_heavy_load;
+            HIPCHK(ctx, hipMemsetAsync(load, 0, sizeof(unsigned long long), sp));
+            hipLaunchKernelGGL(k_pair_cost, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, rb.nchain, act_in, p0, nt, HEAVY_COST, load);
+        }
         hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, core, rb.chains, rb.resid, rb.nchain, act_in, p0, nt, ctx->d_cls,
-                           ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2, act_out);
+                           ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2, act_out, (const unsigned long long *)load);
         // three-pass LSD radix sort, 16 x 16 x 16 classes: by the longest residual, by the set of extensions a pair needs,
         // then (stable) by its class
         const uint32_t *no_order = nullptr;
@@ -2236,7 +2287,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     // it -- ev_pair[b] (chain records of set b free, flags and states of the tile final) is recorded behind it.
     HIPCHK(ctx, hipEventRecord(ctx->ev_first[b], sp));
     HIPCHK(ctx, hipStreamWaitEvent(sp3, ctx->ev_first[b], 0));
-    {
+    static const bool no_rerun = getenv("CM_NO_RERUN") != nullptr;      // diagnostic: what the launch costs (a queued pair would stay unmapped)
+    if (!no_rerun) {
         const RetryArgs ra2{pair_err, retry_list, retry_ctr, ctx->d_spill, RETRY_SPILL, 0};
         hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp3, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,

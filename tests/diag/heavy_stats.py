@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from circminer_amd import lib as cl, synth
 n = int(os.environ.get("PAIRS", "100000"))
-d = synth.generate("hg38like", n_pairs=n, seed=38)
+preset = os.environ.get("PRESET", "hg38like")
+d = synth.generate(preset, n_pairs=n, seed=38 if preset.startswith("hg38") else 21)
 with tempfile.TemporaryDirectory() as td:
     gtf = os.path.join(td, "ref.gtf"); open(gtf, "w").write(d.gtf_text)
     hi = cl.HostIndex(d.contigs, d.chr_table, gtf, kmer=20, n_threads=32)
@@ -33,5 +34,10 @@ for ci in range(hi.n_contigs):
           f"(hit-pairs in heavy: {w[heavy_chain].sum():.3g} of {w[am].sum():.3g}; max hits {hits.max()}); "
           f"pairs with chains {((nc.sum(1) > 0) & actb).sum()}, heavy pairs {hv.sum()} cost pct [50,90,99,max] {np.percentile(cost[hv], [50, 90, 99]).tolist() if hv.any() else []} {cost.max()}", flush=True)
     print("   cost histogram of active pairs:", np.bincount(np.minimum(cost[actb], 40), minlength=41).tolist(), flush=True)
+    both = ((nc[:, 0] + nc[:, 1]) > 0) & ((nc[:, 2] + nc[:, 3]) > 0) & actb
+    cb = cost[both]
+    edges = [0, 6, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 100000]
+    print("   pairs with chains on both mates by cost level", [(edges[k + 1], int(((cb > edges[k]) & (cb <= edges[k + 1])).sum())) for k in range(len(edges) - 1)],
+          "sum of cost beyond 6:", int(cb[cb > 6].sum()), "of", int(cb.sum()), flush=True)
     hp.map_round(ci, ci == hi.n_contigs - 1)
 hp.close()

@@ -1312,6 +1312,7 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
 CM_HD inline bool pac2char(const Core &c, uint32_t start, int len, SV &out) {
     const int ref_len = (int)c.X.ref_len;
     if ((int)start < 0 || (int)start + len - 1 > ref_len) return false;
+    CM_STAT(15, len > 0 ? len : 0);          // reference bytes the algorithm asks for (host emulation only: tests/diag/window_bytes.py)
     if (start == 0) out = SV{c.X.genome, 0, 1, 2};
     else out = SV{c.X.genome, (int32_t)(start - 1), 1, 0};
     return true;

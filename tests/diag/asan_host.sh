@@ -26,6 +26,10 @@ int cm_collect_records(cm_ctx *, uint64_t, uint64_t, cm_record *, uint64_t *) { 
 int cm_collect_records_device(cm_ctx *, uint64_t, uint64_t, void *, uint64_t *) { return CM_ENODEV; }
 int cm_host_alloc(cm_ctx *, uint64_t, void **) { return CM_ENODEV; }
 int cm_host_free(cm_ctx *, void *) { return CM_ENODEV; }
+int cm_host_register(cm_ctx *, void *, uint64_t) { return CM_ENODEV; }
+int cm_host_unregister(cm_ctx *, void *) { return CM_ENODEV; }
+int cm_type_histogram(cm_ctx *, uint64_t *) { return CM_ENODEV; }
+int cm_debug_counters(cm_ctx *, unsigned long long *) { return CM_ENODEV; }
 int cm_reads_download(cm_ctx *, cm_mapped_read *, int32_t *, uint8_t *) { return CM_ENODEV; }
 int cm_map_batch(cm_ctx *, int, int, const cm_reads *, const cm_mapped_read *, cm_mapped_read *, int32_t *) { return CM_ENODEV; }
 int cm_seed_batch(cm_ctx *, int, uint32_t *, uint32_t *, uint32_t *, uint32_t, uint32_t *) { return CM_ENODEV; }

@@ -286,3 +286,17 @@ def test_index_shared_between_ranks_through_files(ds_tiny2r, tmp_path):
     open(os.path.join(d, "c0.pos"), "ab").write(b"\0\0\0\0")           # a torn file is refused
     with pytest.raises(RuntimeError):
         cl.HostIndex(ds.d.contigs, ds.d.chr_table, ds.gtf, kmer=ds.kmer, index_dir=d)
+
+
+def test_index_hit_stats_equal_a_kmer_count(ds_small):
+    """cm_host_index_stats (positions whose k-mer occurs more than once / more than seedLim times in the contig: the two
+    fractions SURVEY 8(d) fixes for the hg38-like preset) against a plain count of the contig's 20-mers."""
+    import collections
+    g = ds_small.d.contigs[0].tobytes()
+    k = 20
+    cnt = collections.Counter(g[i:i + k] for i in range(len(g) - k + 1) if set(g[i:i + k]) <= set(b"ACGT"))
+    n = sum(cnt.values())
+    for lim in (1, 3, 500):
+        want = (n, sum(c for c in cnt.values() if c > 1), sum(c for c in cnt.values() if c > lim), len(cnt))
+        assert ds_small.hi.hit_stats(lim, 3)[0] == want
+    assert want[1] > 0                                    # the preset has repeat families

@@ -18,7 +18,7 @@ SOURCES = ["cm_hot.hip", "cm_dispatch.cpp", "host_index.cpp", "host_annot.cpp", 
            "host_circ_call.cpp"]
 DEPS = SOURCES + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "circminer_hot.h")]
 # cm_hot.hip is compiled twice (reads of <= 16 seeds / <= 24 seeds, see cm_dispatch.cpp): its exported names get a suffix
-KERNEL_EXPORTS = ['cm_create', 'cm_destroy', 'cm_last_error', 'cm_load_contig', 'cm_load_annotation', 'cm_unload_contig', 'cm_reads_upload', 'cm_reads_stage', 'cm_reads_swap', 'cm_map_rounds', 'cm_map_round', 'cm_sync', 'cm_reads_reset', 'cm_collect_active', 'cm_collect_records', 'cm_collect_records_device', 'cm_host_alloc', 'cm_host_free', 'cm_host_register', 'cm_host_unregister', 'cm_type_histogram', 'cm_reads_download', 'cm_map_batch', 'cm_seed_batch', 'cm_chain_batch', 'cm_debug_lane_clk', 'cm_debug_counters', 'cm_prof_enable', 'cm_prof_reset', 'cm_prof_get', 'cm_prof_counters', 'cm_ctx', 'cm_chain']
+KERNEL_EXPORTS = ['cm_create', 'cm_destroy', 'cm_last_error', 'cm_load_contig', 'cm_load_contig_raw', 'cm_load_annotation', 'cm_unload_contig', 'cm_reads_upload', 'cm_reads_stage', 'cm_reads_swap', 'cm_map_rounds', 'cm_map_round', 'cm_sync', 'cm_reads_reset', 'cm_collect_active', 'cm_collect_records', 'cm_collect_records_device', 'cm_host_alloc', 'cm_host_free', 'cm_host_register', 'cm_host_unregister', 'cm_type_histogram', 'cm_reads_download', 'cm_map_batch', 'cm_seed_batch', 'cm_chain_batch', 'cm_debug_lane_clk', 'cm_debug_counters', 'cm_prof_enable', 'cm_prof_reset', 'cm_prof_get', 'cm_prof_counters', 'cm_ctx', 'cm_chain']
 VARIANTS = (("k16", []), ("k24", ["-DCM_MAX_CHAIN_FRAGS=24"]))
 
 

@@ -33,6 +33,7 @@ CM_VARIANTS(int, cm_collect_records, (void *, uint64_t, uint64_t, cm_record *, u
 CM_VARIANTS(int, cm_collect_records_device, (void *, uint64_t, uint64_t, void *, uint64_t *))
 CM_VARIANTS(int, cm_host_alloc, (void *, uint64_t, void **))
 CM_VARIANTS(int, cm_host_free, (void *, void *))
+CM_VARIANTS(int, cm_load_contig_raw, (void *, int, const cm_index_raw *))
 CM_VARIANTS(int, cm_host_register, (void *, void *, uint64_t))
 CM_VARIANTS(int, cm_host_unregister, (void *, void *))
 CM_VARIANTS(int, cm_type_histogram, (void *, uint64_t *))
@@ -89,6 +90,7 @@ int cm_collect_records_device(cm_ctx *ctx, uint64_t base, uint64_t cap, void *d_
 }
 int cm_host_alloc(cm_ctx *ctx, uint64_t bytes, void **out) { return ctx ? GO(cm_host_alloc, bytes, out) : CM_EINVAL; }
 int cm_host_free(cm_ctx *ctx, void *p) { return ctx ? GO(cm_host_free, p) : CM_EINVAL; }
+int cm_load_contig_raw(cm_ctx *ctx, int slot, const cm_index_raw *raw) { return ctx ? GO(cm_load_contig_raw, slot, raw) : CM_EINVAL; }
 int cm_host_register(cm_ctx *ctx, void *p, uint64_t bytes) { return ctx ? GO(cm_host_register, p, bytes) : CM_EINVAL; }
 int cm_host_unregister(cm_ctx *ctx, void *p) { return ctx ? GO(cm_host_unregister, p) : CM_EINVAL; }
 int cm_type_histogram(cm_ctx *ctx, uint64_t out[14]) { return ctx ? GO(cm_type_histogram, out) : CM_EINVAL; }

@@ -1323,6 +1323,96 @@ __global__ void __launch_bounds__(BLK) k_build_desc(const uint32_t *bucket_off, 
     v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
     ((uint4 *)desc)[hv] = v;
 }
+// ---- cm_load_contig_raw: the index table flattened on the device --------------------------------------------------
+// Multi-block scan of uint32 (totals stay below 2^32 here: table slots / entries of one contig): k_scan32_a scans blocks of
+// S32_B items (8 consecutive items per thread) and leaves the block totals, k_scan32_b scans those in one workgroup,
+// k_scan32_c adds the block bases.  add = 1: the items are in[i] + 1; inclusive: out[i] includes item i.
+constexpr int S32_T = 1024, S32_E = 8, S32_B = S32_T * S32_E;
+__global__ void __launch_bounds__(S32_T) k_scan32_a(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *bsum, uint32_t add, int inclusive) {
+    __shared__ uint32_t wsum[S32_T / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * S32_B + (uint64_t)threadIdx.x * S32_E;
+    uint32_t v[S32_E], run = 0;
+#pragma unroll
+    for (int k = 0; k < S32_E; ++k) {
+        const uint64_t i = base + k;
+        v[k] = i < n ? in[i] + add : 0u;
+        run += v[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    uint32_t pre = wbase + incl - run;               // items of this block in front of this thread's
+#pragma unroll
+    for (int k = 0; k < S32_E; ++k) {
+        const uint64_t i = base + k;
+        if (i < n) out[i] = inclusive ? pre + v[k] : pre;
+        pre += v[k];
+    }
+    if (threadIdx.x == S32_T - 1) bsum[blockIdx.x] = pre;
+}
+__global__ void __launch_bounds__(1024) k_scan32_b(uint32_t *bsum, uint32_t nb) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, chunk = (nb + 1023u) / 1024u;
+    const uint32_t a = t * chunk, b = (a + chunk < nb) ? a + chunk : nb;
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += bsum[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (t >= d) ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0u;
+    for (uint32_t i = a; i < b; ++i) {
+        const uint32_t x = bsum[i];
+        bsum[i] = run;
+        run += x;
+    }
+}
+__global__ void __launch_bounds__(S32_T) k_scan32_c(uint32_t *out, uint64_t n, const uint32_t *bsum) {
+    const uint32_t add = bsum[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * S32_B + (uint64_t)threadIdx.x * S32_E;
+    if (add)
+#pragma unroll
+        for (int k = 0; k < S32_E; ++k)
+            if (base + k < n) out[base + k] += add;
+}
+struct RawEntry { uint16_t checksum, pad; int32_t info; };        // GeneralIndex as the index file holds it (8 bytes)
+// bucket i of the file: header slot at start[i] (info = number of valid entries c <= count14[i]), then its slots.
+// counts[hv + 1] = c (the array is zero elsewhere: its inclusive scan is bucket_off)
+__global__ void __launch_bounds__(BLK) k_raw_counts(const RawEntry *tab, const uint32_t *start, const uint32_t *hv, const uint32_t *cnt14, uint32_t n_b,
+                                                   uint64_t n_buckets_all, uint32_t *counts, int *bad) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n_b) return;
+    const int32_t c = tab[start[i]].info;
+    if (c < 0 || (uint32_t)c > cnt14[i] || (uint64_t)hv[i] >= n_buckets_all || (i && hv[i] <= hv[i - 1])) {
+        atomicOr(bad, 1);
+        return;
+    }
+    counts[hv[i] + 1] = (uint32_t)c;
+}
+__global__ void __launch_bounds__(BLK) k_raw_scatter(const RawEntry *tab, const uint32_t *start, const uint32_t *hv, uint32_t n_b, const uint32_t *bucket_off,
+                                                    uint16_t *checksum, uint32_t *pos) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n_b) return;
+    const uint32_t h = hv[i], w = bucket_off[h], c = bucket_off[h + 1] - w;
+    const RawEntry *e = tab + start[i] + 1;
+    for (uint32_t k = 0; k < c; ++k) {
+        const RawEntry x = e[k];
+        checksum[w + k] = x.checksum;
+        pos[w + k] = (uint32_t)x.info;
+    }
+}
+
 __global__ void k_init_state(KCore kc, cm_mapped_read *state, uint8_t *active, int32_t *cat, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
@@ -1845,6 +1935,27 @@ void cm_destroy(cm_ctx *ctx) {
 
 const char *cm_last_error(const cm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// bucket descriptors + the final synchronisation of a contig load (s.X holds the device arrays)
+static int finish_contig(cm_ctx *ctx, Slot &s) {
+    const size_t nb = ((size_t)1 << (2 * CM_WINDOW_SIZE)) + 1;
+    s.d_desc = nullptr;
+    static const bool use_desc = !(getenv("CM_SEED_DESC") && getenv("CM_SEED_DESC")[0] == '0');
+    if (use_desc) {          // 16 bytes per bucket (4 GiB per contig): a probe becomes one random read instead of two dependent ones
+        const uint64_t n_buckets = nb - 1;
+        uint32_t *d = nullptr;
+        if (hipMalloc((void **)&d, n_buckets * cmc::DESC_WORDS * sizeof(uint32_t)) == hipSuccess) {
+            s.idx_allocs.push_back(d);
+            hipLaunchKernelGGL(k_build_desc, dim3((unsigned)((n_buckets + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, s.X.bucket_off, s.X.checksum, n_buckets,
+                               ctx->P.kmer, d);
+            HIPCHK(ctx, hipGetLastError());
+            s.d_desc = d;
+        } else (void)hipGetLastError();      // not enough HBM: probes go through the arrays
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    s.loaded = true;
+    return CM_OK;
+}
+
 int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     if (!ctx || !iv) return CM_EINVAL;
     if (slot < 0 || slot >= MAX_SLOTS) return fail(ctx, CM_EINVAL, "slot %d out of range", slot);
@@ -1870,22 +1981,96 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     if ((rc = up(ctx, s.idx_allocs, iv->bucket_off, nb, &s.X.bucket_off))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->checksum, (size_t)iv->n_entries, &s.X.checksum))) return rc;
     if ((rc = up(ctx, s.idx_allocs, iv->pos, (size_t)iv->n_entries, &s.X.pos))) return rc;
-    s.d_desc = nullptr;
-    static const bool use_desc = !(getenv("CM_SEED_DESC") && getenv("CM_SEED_DESC")[0] == '0');
-    if (use_desc) {          // 16 bytes per bucket (4 GiB per contig): a probe becomes one random read instead of two dependent ones
-        const uint64_t n_buckets = nb - 1;
-        uint32_t *d = nullptr;
-        if (hipMalloc((void **)&d, n_buckets * cmc::DESC_WORDS * sizeof(uint32_t)) == hipSuccess) {
-            s.idx_allocs.push_back(d);
-            hipLaunchKernelGGL(k_build_desc, dim3((unsigned)((n_buckets + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, s.X.bucket_off, s.X.checksum, n_buckets,
-                               ctx->P.kmer, d);
-            HIPCHK(ctx, hipGetLastError());
-            s.d_desc = d;
-        } else (void)hipGetLastError();      // not enough HBM: probes go through the arrays
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    s.loaded = true;
+    return finish_contig(ctx, s);
+}
+
+// exclusive (or inclusive) scan of n uint32 items on ctx->stream; tmp: (n / S32_B + 2) words
+static int scan32(cm_ctx *ctx, const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *tmp, uint32_t add, int inclusive) {
+    const uint32_t nb = (uint32_t)((n + S32_B - 1) / S32_B);
+    if (nb == 0) return CM_OK;
+    hipLaunchKernelGGL(k_scan32_a, dim3(nb), dim3(S32_T), 0, ctx->stream, in, n, out, tmp, add, inclusive);
+    hipLaunchKernelGGL(k_scan32_b, dim3(1), dim3(1024), 0, ctx->stream, tmp, nb);
+    hipLaunchKernelGGL(k_scan32_c, dim3(nb), dim3(S32_T), 0, ctx->stream, out, n, (const uint32_t *)tmp);
+    HIPCHK(ctx, hipGetLastError());
     return CM_OK;
+}
+
+int cm_load_contig_raw(cm_ctx *ctx, int slot, const cm_index_raw *raw) {
+    if (!ctx || !raw) return CM_EINVAL;
+    if (slot < 0 || slot >= MAX_SLOTS) return fail(ctx, CM_EINVAL, "slot %d out of range", slot);
+    if (!raw->genome || (raw->n_buckets && (!raw->hv || !raw->count14 || !raw->table))) return fail(ctx, CM_EINVAL, "null array in the raw record");
+    if (raw->table_slots > 0xffffffffull) return fail(ctx, CM_ELIMIT, "table of %llu slots", (unsigned long long)raw->table_slots);
+    HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    Slot &s = ctx->slots[slot];
+    free_all(s.idx_allocs);
+    s.d_desc = nullptr;
+    s.loaded = false;
+    ++s.gen;
+    const uint64_t n_all = (uint64_t)1 << (2 * CM_WINDOW_SIZE);
+    const uint32_t n_b = raw->n_buckets;
+    s.X = cm_index_view{};
+    s.X.contig_num = raw->contig_num;
+    s.X.ref_len = raw->ref_len;
+    int rc;
+    {
+        uint8_t *g = nullptr;
+        const size_t pad = cmc::CM_STAGE_PAD;
+        HIPCHK(ctx, hipMalloc((void **)&g, (size_t)raw->ref_len + 2 * pad));
+        s.idx_allocs.push_back(g);
+        HIPCHK(ctx, hipMemsetAsync(g, 0, (size_t)raw->ref_len + 2 * pad, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(g + pad, raw->genome, (size_t)raw->ref_len, hipMemcpyHostToDevice, ctx->stream));
+        s.X.genome = g + pad;
+    }
+    // temporaries: the table as in the file, the bucket list, the table offset of every bucket, scan block sums
+    std::vector<void *> tmp;
+    struct FreeTmp {
+        std::vector<void *> &v;
+        ~FreeTmp() { free_all(v); }
+    } free_tmp{tmp};
+    const RawEntry *d_tab = nullptr;
+    const uint32_t *d_hv = nullptr, *d_cnt = nullptr;
+    if ((rc = up(ctx, tmp, (const RawEntry *)raw->table, (size_t)raw->table_slots, &d_tab))) return rc;
+    if ((rc = up(ctx, tmp, raw->hv, (size_t)n_b, &d_hv))) return rc;
+    if ((rc = up(ctx, tmp, raw->count14, (size_t)n_b, &d_cnt))) return rc;
+    uint32_t *d_start = nullptr, *d_bs = nullptr, *d_off = nullptr;
+    int *d_bad = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_start, ((size_t)n_b + 1) * sizeof(uint32_t)));
+    tmp.push_back(d_start);
+    HIPCHK(ctx, hipMalloc((void **)&d_bs, ((size_t)(n_all / S32_B) + 4) * sizeof(uint32_t)));
+    tmp.push_back(d_bs);
+    HIPCHK(ctx, hipMalloc((void **)&d_bad, sizeof(int)));
+    tmp.push_back(d_bad);
+    HIPCHK(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMalloc((void **)&d_off, (n_all + 1) * sizeof(uint32_t)));
+    s.idx_allocs.push_back(d_off);
+    HIPCHK(ctx, hipMemsetAsync(d_off, 0, (n_all + 1) * sizeof(uint32_t), ctx->stream));
+    if ((rc = scan32(ctx, d_cnt, n_b, d_start, d_bs, 1u, 0))) return rc;                 // slot of every bucket's header
+    if (n_b) {
+        hipLaunchKernelGGL(k_raw_counts, dim3((n_b + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, d_tab, (const uint32_t *)d_start, d_hv, d_cnt, n_b, n_all, d_off, d_bad);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if ((rc = scan32(ctx, d_off, n_all + 1, d_off, d_bs, 0u, 1))) return rc;             // counts -> bucket offsets, in place
+    unsigned long long landing[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(&landing[0], d_off + n_all, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&landing[1], d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((int)landing[1]) return fail(ctx, CM_EINVAL, "malformed index table: a bucket header is out of range");
+    const uint64_t total = (uint32_t)landing[0];
+    uint16_t *d_cs = nullptr;
+    uint32_t *d_ps = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_cs, (total ? total : 1) * sizeof(uint16_t)));
+    s.idx_allocs.push_back(d_cs);
+    HIPCHK(ctx, hipMalloc((void **)&d_ps, (total ? total : 1) * sizeof(uint32_t)));
+    s.idx_allocs.push_back(d_ps);
+    if (n_b) {
+        hipLaunchKernelGGL(k_raw_scatter, dim3((n_b + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, d_tab, (const uint32_t *)d_start, d_hv, n_b, (const uint32_t *)d_off, d_cs, d_ps);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    s.X.bucket_off = d_off;
+    s.X.checksum = d_cs;
+    s.X.pos = d_ps;
+    s.X.n_entries = total;
+    return finish_contig(ctx, s);       // (synchronises the stream: the temporaries may go)
 }
 
 int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {

@@ -145,7 +145,22 @@ struct cm_index_file {
     bool done = false;
     void *tab = nullptr;                 // the table of the contig being loaded as it is in the file; reused from contig to contig
     size_t tab_bytes = 0;
-    ~cm_index_file() { free(tab); }
+    struct RawSet {                      // cm_host_next_contig_raw: two sets take turns
+        uint8_t *genome = nullptr;
+        uint32_t *hv = nullptr, *cnt = nullptr;
+        void *tab = nullptr;
+        size_t genome_cap = 0, hdr_cap = 0, tab_cap = 0;
+    } raw[2];
+    int raw_turn = 0;
+    ~cm_index_file() {
+        free(tab);
+        for (auto &r : raw) {
+            free(r.genome);
+            free(r.hv);
+            free(r.cnt);
+            free(r.tab);
+        }
+    }
 };
 
 extern "C" {
@@ -372,8 +387,11 @@ int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kme
 // (pac2char_whole_contig, src/match_read.cpp:301-332) and the table in the flattened layout of
 // cm_index_view.  Returns CM_OK and *loaded = 1, or *loaded = 0 after the last contig.
 // The view (including its genome) is released with cm_host_free_loaded_contig.
-static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded, bool genome_only) {
-    if (!x || !out || !loaded) return CM_EINVAL;
+static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded, bool genome_only, cm_index_raw *raw_out = nullptr) {
+    if (!x || (!out && !raw_out) || !loaded) return CM_EINVAL;
+    if (raw_out && !x->full) return CM_EINVAL;
+    cm_index_file::RawSet *RS = raw_out ? &x->raw[x->raw_turn] : nullptr;
+    if (raw_out) x->raw_turn ^= 1;
     const bool trace = getenv("CM_INDEX_TRACE") != nullptr;
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -397,7 +415,15 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     const uint32_t nw = n / 21 + (n % 21 != 0);
     std::vector<uint64_t> packed(nw);
     if (nw && fread(packed.data(), 8, nw, f) != nw) return CM_EINVAL;
-    uint8_t *g = (uint8_t *)malloc((size_t)n + 1);
+    uint8_t *g;
+    if (RS) {                                      // handle-owned, reused
+        if (RS->genome_cap < (size_t)n + 1) {
+            free(RS->genome);
+            RS->genome = (uint8_t *)malloc((size_t)n + 1);
+            RS->genome_cap = RS->genome ? (size_t)n + 1 : 0;
+        }
+        g = RS->genome;
+    } else g = (uint8_t *)malloc((size_t)n + 1);
     if (!g) return CM_ENOMEM;
     {   // 21 bases per 64-bit word, first base in the top bits; word ranges decoded side by side
         auto decode = [&](uint32_t w0, uint32_t w1) {
@@ -420,7 +446,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     lap("sequence read + decoded");
     uint32_t nbuckets = 0;
     if (!get(f, nbuckets)) {
-        free(g);
+        if (!RS) free(g);
         return CM_EINVAL;
     }
     const uint64_t nb = 1ull << (2 * CM_WINDOW_SIZE);
@@ -437,13 +463,13 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         while (seen < nbuckets) {
             int32_t bytes = 0;
             if (!get(f, bytes) || bytes <= 0) {
-                free(g);
+                if (!RS) free(g);
                 return CM_EINVAL;
             }
             const size_t at = hdr.size();
             hdr.resize(at + (size_t)bytes);
             if (fread(hdr.data() + at, 1, (size_t)bytes, f) != (size_t)bytes) {
-                free(g);
+                if (!RS) free(g);
                 return CM_EINVAL;
             }
             uint64_t term = 0;                      // bytes with the top bit set end a varbyte; eight at a time
@@ -458,14 +484,14 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
                 for (; k < e; ++k) term += hdr[k] >> 7;
             }
             if (term == 0 || (term & 1)) {
-                free(g);
+                if (!RS) free(g);
                 return CM_EINVAL;
             }
             blks.push_back(Blk{at, (size_t)bytes, term / 2, 0, 0});
             seen += term / 2;
         }
         if (seen != nbuckets) {
-            free(g);
+            if (!RS) free(g);
             return CM_EINVAL;
         }
     }
@@ -504,7 +530,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         B.mem = msum;
     });
     if (hdr_bad) {
-        free(g);
+        if (!RS) free(g);
         return CM_EINVAL;
     }
     std::unique_ptr<uint32_t[]> hvs, cnts;                 // not cleared: pass 2 fills them
@@ -520,14 +546,29 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             mem += blks[b].mem;
         }
         if (hv0 >= nb && nbuckets) {
-            free(g);
+            if (!RS) free(g);
             return CM_EINVAL;
         }
         if (!genome_only) {
-            hvs.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
-            cnts.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
-            if (!hvs || !cnts) {
-                free(g);
+            uint32_t *hv_w, *cn_w;
+            if (RS) {
+                if (RS->hdr_cap < n_hdr + 1) {
+                    free(RS->hv);
+                    free(RS->cnt);
+                    RS->hv = (uint32_t *)malloc((n_hdr + 1) * sizeof(uint32_t));
+                    RS->cnt = (uint32_t *)malloc((n_hdr + 1) * sizeof(uint32_t));
+                    RS->hdr_cap = (RS->hv && RS->cnt) ? n_hdr + 1 : 0;
+                }
+                hv_w = RS->hv;
+                cn_w = RS->cnt;
+            } else {
+                hvs.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
+                cnts.reset(new (std::nothrow) uint32_t[n_hdr + 1]);
+                hv_w = hvs.get();
+                cn_w = cnts.get();
+            }
+            if (!hv_w || !cn_w) {
+                if (!RS) free(g);
                 return CM_ENOMEM;
             }
             over_blocks([&](size_t b) {
@@ -540,8 +581,8 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
                     idx += (size_t)decode_varbyte(p + idx, B.bytes - idx, &d);
                     idx += (size_t)decode_varbyte(p + idx, B.bytes - idx, &cn);
                     hv += d;
-                    hvs[w] = (uint32_t)hv;
-                    cnts[w] = cn;
+                    hv_w[w] = (uint32_t)hv;
+                    cn_w[w] = cn;
                     ++w;
                 }
             });
@@ -556,7 +597,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
         if (x->full) {
             uint32_t memsz = 0;
             if (!get(f, memsz) || fseeko(f, (off_t)memsz * (off_t)sizeof(Entry), SEEK_CUR) != 0) {
-                free(g);
+                if (!RS) free(g);
                 return CM_EINVAL;
             }
         }
@@ -567,20 +608,22 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     } else if (x->full) {
         uint32_t memsz = 0;
         if (!get(f, memsz) || memsz != mem) {
-            free(g);
+            if (!RS) free(g);
             return CM_EINVAL;
         }
         // the table itself (8 bytes per slot, ~8.5 GB for a full-size contig): pread()s side by side into a buffer that is kept
         // for the next contig (its pages are faulted in once per file, not once per contig)
         const size_t tab_need = ((size_t)memsz + 1) * sizeof(Entry);
-        if (x->tab_bytes < tab_need) {
-            free(x->tab);
-            x->tab = malloc(tab_need);
-            x->tab_bytes = x->tab ? tab_need : 0;
+        void *&tab_buf = RS ? RS->tab : x->tab;
+        size_t &tab_cap = RS ? RS->tab_cap : x->tab_bytes;
+        if (tab_cap < tab_need) {
+            free(tab_buf);
+            tab_buf = malloc(tab_need);
+            tab_cap = tab_buf ? tab_need : 0;
         }
-        Entry *tab = (Entry *)x->tab;
+        Entry *tab = (Entry *)tab_buf;
         if (!tab) {
-            free(g);
+            if (!RS) free(g);
             return CM_ENOMEM;
         }
         {
@@ -606,11 +649,24 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             piece(0);
             for (auto &t : th) t.join();
             if (bad || fseeko(f, at + (off_t)total_b, SEEK_SET) != 0) {
-                free(g);
+                if (!RS) free(g);
                 return CM_EINVAL;
             }
         }
         lap("table read");
+        if (RS) {                                      // cm_load_contig_raw flattens it on the device
+            raw_out->contig_num = contig_num;
+            raw_out->ref_len = n;
+            raw_out->genome = g;
+            raw_out->n_buckets = (uint32_t)n_hdr;
+            raw_out->hv = RS->hv;
+            raw_out->count14 = RS->cnt;
+            raw_out->table = tab;
+            raw_out->table_slots = memsz;
+            if (!more) x->done = true;
+            *loaded = 1;
+            return CM_OK;
+        }
         uint32_t *boff = (uint32_t *)calloc(nb + 1, sizeof(uint32_t));
         uint64_t total = 0, cur = 0;
         bool ok = boff != nullptr;
@@ -661,7 +717,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
             free(boff);
             free(cs);
             free(ps);
-            free(g);
+            if (!RS) free(g);
             return ok ? CM_ENOMEM : CM_EINVAL;
         }
         lap("counts placed");
@@ -717,7 +773,7 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
     } else {
         rc = cm_host_build_index(g, n, kmer, contig_num, n_threads, out);     // calculateHashTableOnFly + sortHashTable
         if (rc != CM_OK) {
-            free(g);
+            if (!RS) free(g);
             return rc;
         }
     }
@@ -728,6 +784,9 @@ static int next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int 
 
 int cm_host_next_contig(cm_index_file *x, int n_threads, cm_index_view *out, int *loaded) { return next_contig(x, n_threads, out, loaded, false); }
 int cm_host_next_contig_genome(cm_index_file *x, cm_index_view *out, int *loaded) { return next_contig(x, 1, out, loaded, true); }
+int cm_host_next_contig_raw(cm_index_file *x, int n_threads, cm_index_raw *out, int *loaded) {
+    return next_contig(x, n_threads, nullptr, loaded, false, out);
+}
 
 void cm_host_free_loaded_contig(cm_index_view *iv) {
     if (!iv) return;

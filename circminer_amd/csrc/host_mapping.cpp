@@ -155,7 +155,40 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
             early_rc = cm_host_build_annotation(a->gtf_path, chrs, n_chr, clen_guess.data(), (uint32_t)clen_guess.size(), P.max_read_len, annots_early.data());
             lap("GTF -> annotation tables (under the contig loads)", tg);
         });
-    {
+    if (full) {
+        // full-format index: the table crosses PCIe as it is in the file and the device flattens it (cm_load_contig_raw); the
+        // host only reads and decodes the bucket headers -- of contig c + 1 while contig c uploads
+        cm_index_raw nxt_raw;
+        int nxt_loaded = 0, nxt_rc = CM_OK;
+        double tl = now();
+        nxt_rc = cm_host_next_contig_raw(idx, n_threads, &nxt_raw, &nxt_loaded);
+        lap("contig record read", tl);
+        for (;;) {
+            MAP_TRY(nxt_rc, "cm_host_next_contig_raw");
+            if (!nxt_loaded) break;
+            const cm_index_raw raw = nxt_raw;
+            cm_index_view iv;
+            memset(&iv, 0, sizeof iv);
+            iv.contig_num = raw.contig_num;
+            iv.ref_len = raw.ref_len;
+            views.push_back(iv);                                  // (lengths only: the arrays stay with the file handle)
+            if (iv.contig_num != (int32_t)views.size() - 1) {
+                rc = fail(CM_EINVAL, "packed contigs out of order: record %zu is contig %d", views.size(), iv.contig_num + 1);
+                cleanup();
+                return rc;
+            }
+            std::thread ahead([&]() {
+                const double ta = now();
+                nxt_rc = cm_host_next_contig_raw(idx, n_threads, &nxt_raw, &nxt_loaded);
+                lap("next contig record read (under the upload)", ta);
+            });
+            tl = now();
+            const int lrc = cm_load_contig_raw(cm, (int)views.size() - 1, &raw);
+            lap("contig uploaded, flattened on the device + descriptors", tl);
+            ahead.join();
+            MAP_TRY(lrc, "cm_load_contig_raw");
+        }
+    } else {
         cm_index_view nxt_iv;
         int nxt_loaded = 0, nxt_rc = CM_OK;
         double tl = now();
@@ -401,7 +434,7 @@ extern "C" int cm_abi_sizes(uint32_t *out, uint32_t cap) {
     const uint32_t v[] = {(uint32_t)sizeof(cm_params),       (uint32_t)sizeof(cm_index_view),  (uint32_t)sizeof(cm_annot_view), (uint32_t)sizeof(cm_mapped_read),
                           (uint32_t)sizeof(cm_reads),        (uint32_t)sizeof(cm_record),      (uint32_t)sizeof(cm_chr_info),   (uint32_t)sizeof(cm_fastq_batch),
                           (uint32_t)sizeof(cm_mapping_args), (uint32_t)sizeof(cm_mapping_stats), (uint32_t)sizeof(cm_circ_res), (uint32_t)sizeof(cm_circ_args),
-                          (uint32_t)sizeof(cm_circ_stats)};
+                          (uint32_t)sizeof(cm_circ_stats), (uint32_t)sizeof(cm_index_raw)};
     const uint32_t n = (uint32_t)(sizeof v / sizeof v[0]);
     if (!out || cap < n) return CM_EINVAL;
     for (uint32_t i = 0; i < n; ++i) out[i] = v[i];

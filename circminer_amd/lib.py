@@ -69,6 +69,11 @@ class IndexView(C.Structure):
                 ("checksum", u16p), ("pos", u32p), ("n_entries", C.c_uint64)]
 
 
+class IndexRaw(C.Structure):
+    _fields_ = [("contig_num", C.c_int32), ("ref_len", C.c_uint32), ("genome", u8p), ("n_buckets", C.c_uint32), ("hv", u32p),
+                ("count14", u32p), ("table", C.c_void_p), ("table_slots", C.c_uint64)]
+
+
 class AnnotView(C.Structure):
     _fields_ = [("n_iv", C.c_uint32), ("iv_spos", u32p), ("iv_epos", u32p), ("iv_max_end", u32p), ("iv_min_end", u32p),
                 ("iv_max_next_exon", u32p), ("iv_seg_off", u32p), ("iv_seg", u32p),
@@ -170,6 +175,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_last_error": (C.c_char_p, [vp]),
         "cm_load_contig": (C.c_int, [vp, C.c_int, pp(IndexView)]),
         "cm_load_annotation": (C.c_int, [vp, C.c_int, pp(AnnotView)]),
+        "cm_load_contig_raw": (C.c_int, [vp, C.c_int, pp(IndexRaw)]),
+        "cm_host_next_contig_raw": (C.c_int, [vp, C.c_int, pp(IndexRaw), pp(C.c_int)]),
         "cm_unload_contig": (C.c_int, [vp, C.c_int]),
         "cm_reads_upload": (C.c_int, [vp, pp(Reads), vp]),
         "cm_reads_stage": (C.c_int, [vp, pp(Reads), vp]),
@@ -242,14 +249,14 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     got = (C.c_uint32 * 16)()
     n = L.cm_abi_sizes(got, 16)
     mine = [C.sizeof(t) for t in (Params, IndexView, AnnotView, MappedRead, Reads, C.c_uint8 * RECORD_DTYPE.itemsize, ChrInfo, FastqBatch, MappingArgs,
-                                  MappingStats, CircRes, CircArgs, CircStats)]
+                                  MappingStats, CircRes, CircArgs, CircStats, IndexRaw)]
     if n != len(mine) or list(got[:n]) != mine:
         raise RuntimeError(f"circminer_amd.lib: struct sizes differ from {path}: library {list(got[:max(n, 0)])}, ctypes {mine}")
     _lib = L
     return L
 
 
-EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_annotation",
+EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig", "cm_load_contig_raw", "cm_host_next_contig_raw", "cm_load_annotation",
                     "cm_unload_contig", "cm_reads_upload", "cm_reads_stage", "cm_reads_swap", "cm_map_round", "cm_map_rounds", "cm_reads_download", "cm_map_batch",
                     "cm_sync", "cm_reads_reset", "cm_collect_active", "cm_collect_records", "cm_collect_records_device", "cm_abi_sizes", "cm_host_alloc", "cm_host_free", "cm_host_register", "cm_host_unregister", "cm_type_histogram", "cm_write_remain_records", "cm_seed_batch", "cm_chain_batch", "cm_prof_enable", "cm_prof_reset", "cm_prof_get",
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_index_stats", "cm_host_build_annotation",
@@ -358,10 +365,11 @@ class IndexFile:
     """Iterates the packed contigs of a stock index file as IndexView objects (one mapping round each).
     The view handed out is valid until the next iteration step / close()."""
 
-    def __init__(self, path: str, n_threads: int = 8, genome_only: bool = False):
+    def __init__(self, path: str, n_threads: int = 8, genome_only: bool = False, raw: bool = False):
         self.L = load()
         self.h = C.c_void_p()
         self.genome_only = genome_only          # cm_host_next_contig_genome: the k-mer tables are stepped over (what stage 2 does)
+        self.raw = raw                          # cm_host_next_contig_raw: records as in the file, for HotPath.load_contig_raw
         kmer, full, nrec = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
         rc = self.L.cm_host_open_index(path.encode(), C.byref(self.h), C.byref(kmer), C.byref(full), C.byref(nrec))
         if rc != 0:
@@ -377,9 +385,17 @@ class IndexFile:
             self.L.cm_host_free_loaded_contig(C.byref(self._cur))
             self._cur = None
 
-    def __next__(self) -> IndexView:
+    def __next__(self):
         self._drop()
         iv, loaded = IndexView(), C.c_int(0)
+        if self.raw:
+            rw = IndexRaw()
+            rc = self.L.cm_host_next_contig_raw(self.h, self.n_threads, C.byref(rw), C.byref(loaded))
+            if rc != 0:
+                raise RuntimeError(f"cm_host_next_contig_raw failed ({rc})")
+            if not loaded.value:
+                raise StopIteration
+            return rw                          # arrays belong to the file handle (valid until the call after next)
         if self.genome_only:
             rc = self.L.cm_host_next_contig_genome(self.h, C.byref(iv), C.byref(loaded))
         else:
@@ -597,6 +613,12 @@ class HotPath:
 
     def load_contig(self, slot, iv: IndexView, av: AnnotView = None):
         self._chk(self.L.cm_load_contig(self.h, slot, C.byref(iv)), "cm_load_contig")
+        if av is not None:
+            self._chk(self.L.cm_load_annotation(self.h, slot, C.byref(av)), "cm_load_annotation")
+
+    def load_contig_raw(self, slot, raw: IndexRaw, av: AnnotView = None):
+        """a record of IndexFile(raw=True): the table is flattened on the device"""
+        self._chk(self.L.cm_load_contig_raw(self.h, slot, C.byref(raw)), "cm_load_contig_raw")
         if av is not None:
             self._chk(self.L.cm_load_annotation(self.h, slot, C.byref(av)), "cm_load_annotation")
 

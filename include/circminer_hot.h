@@ -177,6 +177,13 @@ const char *cm_last_error(const cm_ctx *ctx);      /* never NULL */
 int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv);
 /* Stage the flattened annotation of the same contig.  Replaces gtf_parser.load_gtf's
  * query-side state for contigNum (src/circminer.cpp:205-206). */
+struct cm_index_raw;
+/* cm_load_contig from a record as cm_host_next_contig_raw leaves it: the table goes over PCIe as it is in the file and is
+ * flattened into the cm_index_view layout BY THE DEVICE (bucket offsets by two scans, entries scattered at HBM bandwidth)
+ * instead of by host threads (loadHashTable's pointer table + arena, src/mrsfast/HashTable.c:1013-1034, never exists).  The
+ * resident contig is the same as after cm_host_next_contig + cm_load_contig.  A malformed table (a header slot that claims
+ * more entries than its bucket has slots) is CM_EINVAL. */
+int cm_load_contig_raw(cm_ctx *ctx, int slot, const struct cm_index_raw *raw);
 int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av);
 int cm_unload_contig(cm_ctx *ctx, int slot);
 
@@ -342,6 +349,22 @@ int cm_host_open_index(const char *index_path, cm_index_file **out, int32_t *kme
 int cm_host_next_contig(cm_index_file *f, int n_threads, cm_index_view *out, int *loaded);
 /* The same record with its k-mer table stepped over: only genome / ref_len / contig_num of *out are set (ProcessCirc::load_genome,
  * src/process_circ.cpp:1659-1680: loadCompressedRefGenome, the sequence alone); stage 2 uses this. */
+/* The same record left as it is in the file, for cm_load_contig_raw: decoded genome, the (hv, count14) pair of every non-empty
+ * bucket in file order, and the table itself (GeneralIndex slots of 8 bytes: per bucket a header slot whose info = number of
+ * valid entries, then count14 slots).  Full-format index files only (CM_EINVAL for the compact format: take
+ * cm_host_next_contig).  The arrays belong to the file handle and stay valid until the call after next (two sets take turns, so
+ * the next record can be read while this one uploads) or cm_host_close_index. */
+typedef struct cm_index_raw {
+    int32_t contig_num;
+    uint32_t ref_len;
+    const uint8_t *genome;       /* ref_len bytes                                   */
+    uint32_t n_buckets;          /* non-empty 14-mer buckets                        */
+    const uint32_t *hv;          /* ascending                                       */
+    const uint32_t *count14;     /* slots of bucket i = count14[i] + 1              */
+    const void *table;           /* table_slots x 8 bytes, as in the file           */
+    uint64_t table_slots;
+} cm_index_raw;
+int cm_host_next_contig_raw(cm_index_file *f, int n_threads, cm_index_raw *out, int *loaded);
 int cm_host_next_contig_genome(cm_index_file *f, cm_index_view *out, int *loaded);
 void cm_host_free_loaded_contig(cm_index_view *iv);
 void cm_host_close_index(cm_index_file *f);
@@ -482,7 +505,7 @@ typedef struct cm_circ_args {
 int cm_circ_run(const cm_circ_args *args, cm_circ_stats *stats, char *err, uint64_t err_cap);
 
 /* sizeof of the structs above, in this order: cm_params, cm_index_view, cm_annot_view, cm_mapped_read, cm_reads, cm_record,
- * cm_chr_info, cm_fastq_batch, cm_mapping_args, cm_mapping_stats, cm_circ_res, cm_circ_args, cm_circ_stats -- for a binding to
+ * cm_chr_info, cm_fastq_batch, cm_mapping_args, cm_mapping_stats, cm_circ_res, cm_circ_args, cm_circ_stats, cm_index_raw -- for a binding to
  * check its mirrors of them against the library it loaded.  Returns the number of entries written (cap must hold them). */
 int cm_abi_sizes(uint32_t *out, uint32_t cap);
 

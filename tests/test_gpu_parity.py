@@ -213,6 +213,59 @@ def test_mapping_from_index_files_matches_in_memory_index(ds_tiny2r, tmp_path):
         assert got[0].tobytes() == ref[0].tobytes() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
 
 
+def test_index_table_flattened_on_the_device(ds_small, ds_tiny2r, tmp_path):
+    """cm_host_next_contig_raw + cm_load_contig_raw: the table of a full-format index file goes over PCIe as it is in the file and
+    the DEVICE builds bucket offsets (two scans) and the (checksum, position) arrays (a scatter at HBM bandwidth) -- what host
+    threads do in cm_host_next_contig.  The resident index must be the same: every seed range of every probe (first entry, count,
+    raw count: they pin bucket_off / checksum / pos) and all mapping results equal those of the host-flattened load.  A compact
+    index file has no table: CM_EINVAL (the caller takes cm_host_next_contig); a corrupted header slot is refused."""
+    for ds in (ds_small, ds_tiny2r):
+        packed = str(tmp_path / f"ref{ds.hi.n_contigs}.fa.packed.fa")
+        with open(packed, "w") as f:
+            for i, c in enumerate(ds.d.contigs):
+                f.write(f">{i + 1}\n{c.tobytes().decode()}\n")
+        idx = cl.write_index(packed, kmer=ds.kmer, n_threads=4)
+        P = cl.default_params(kmer=ds.kmer)
+        res = {}
+        for raw in (False, True):
+            hp = cl.HotPath(P)
+            hp.upload(ds.batch)
+            f = cl.IndexFile(idx, n_threads=3, raw=raw)
+            seeds = []
+            for ci, rec in enumerate(f):
+                assert rec.contig_num == ci
+                if raw:
+                    assert rec.n_buckets > 1000 and rec.table_slots > rec.n_buckets
+                    hp.load_contig_raw(ci, rec, ds.hi.annots[ci])
+                else:
+                    hp.load_contig(ci, rec, ds.hi.annots[ci])
+                seeds.append([x.copy() if hasattr(x, "copy") else x for x in hp.seeds(ci)])
+                hp.map_round(ci, ci == ds.hi.n_contigs - 1)
+                hp.sync()
+            f.close()
+            res[raw] = (seeds, hp.download())
+            hp.close()
+        for a, b in zip(res[False][0], res[True][0]):
+            assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
+        assert res[False][1][0].tobytes() == res[True][1][0].tobytes() and (res[False][1][2] == res[True][1][2]).all()
+    # compact format: no table in the file
+    idx2 = cl.write_index(packed, kmer=ds.kmer, compact=True, n_threads=4)
+    f = cl.IndexFile(idx2, n_threads=2, raw=True)
+    with pytest.raises(RuntimeError):
+        next(f)
+    f.close()
+    # a header slot that claims more entries than its bucket has slots
+    f = cl.IndexFile(idx, n_threads=2, raw=True)
+    rec = next(f)
+    tab = np.ctypeslib.as_array(C.cast(rec.table, C.POINTER(C.c_int32)), (int(rec.table_slots) * 2,))
+    tab[1] = 1 << 20                                   # info of the first bucket's header
+    hp = cl.HotPath(P)
+    with pytest.raises(RuntimeError, match="malformed"):
+        hp.load_contig_raw(0, rec)
+    hp.close()
+    f.close()
+
+
 def test_two_rounds_through_remain_fastq_files(ds_tiny2r, tmp_path):
     """the reference's way of carrying pairs between rounds (remain FASTQ + 23-token header,
     src/filter.cpp:413-455 -> src/fastq_parser.cpp:200-269) gives the same final states as the resident batch."""

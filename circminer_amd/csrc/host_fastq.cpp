@@ -13,6 +13,7 @@
 // Deliberately defined where the reference has undefined behaviour: names shorter than 2 characters are not
 // inspected for the "/x" suffix, header lines with more than 23 tokens are treated like fresh reads.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <sys/stat.h>
 #include <zlib.h>
@@ -174,6 +175,18 @@ struct Stream {
 
 // The part of std::vector the parser uses, without the zero-fill of resize(): the batch arrays are tens of MB and every byte
 // is overwritten by the (parallel) copies right after they are sized.
+// Batch arrays of hundreds of MB are filled once per batch: as transparent huge pages their first fill costs 512 times fewer
+// page faults (the parser's first batches ran at a third of its steady rate).
+inline void advise_huge(void *p, size_t bytes) {
+#if defined(MADV_HUGEPAGE)
+    if (!p || bytes < (8u << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+    if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+#else
+    (void)p;
+    (void)bytes;
+#endif
+}
 template <class T> struct RawVec {
     T *p = nullptr;
     size_t n = 0, cap = 0;
@@ -194,6 +207,7 @@ template <class T> struct RawVec {
         while (nc < c) nc *= 2;
         p = (T *)realloc(p, nc * sizeof(T));
         cap = nc;
+        advise_huge(p, nc * sizeof(T));
     }
     void resize(size_t k) {                 // contents of new elements are unspecified
         reserve(k);
@@ -402,7 +416,10 @@ size_t fill_and_index(Stream &s, std::vector<size_t> &nl, size_t want, size_t by
         if (lines / 4 >= want || s.eof) return lines / 4;
         // more input: room for the rest of the estimate (at least one block)
         size_t need = std::max<size_t>(BLOCK, bytes_hint > s.end ? bytes_hint - s.end : BLOCK);
-        if (s.end + need > s.buf.size()) s.buf.resize(s.end + need);
+        if (s.end + need > s.buf.size()) {
+            s.buf.resize(s.end + need);
+            advise_huge(s.buf.data(), s.buf.size());
+        }
         while (need > 0) {
             const int got = s.read_some(s.buf.data() + s.end, need);
             if (got <= 0) {

@@ -1,4 +1,5 @@
 """GPU parity tests proper: HIP path through the C-ABI vs the CPU oracle (bit-exact)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -249,7 +250,10 @@ def test_index_table_flattened_on_the_device(ds_small, ds_tiny2r, tmp_path):
             assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
         assert res[False][1][0].tobytes() == res[True][1][0].tobytes() and (res[False][1][2] == res[True][1][2]).all()
     # compact format: no table in the file
-    idx2 = cl.write_index(packed, kmer=ds.kmer, compact=True, n_threads=4)
+    import shutil
+    packed2 = packed + ".compact.fa"                   # (write_index names the index after the packed FASTA)
+    shutil.copy(packed, packed2)
+    idx2 = cl.write_index(packed2, kmer=ds.kmer, compact=True, n_threads=4)
     f = cl.IndexFile(idx2, n_threads=2, raw=True)
     with pytest.raises(RuntimeError):
         next(f)

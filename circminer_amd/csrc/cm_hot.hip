@@ -1459,6 +1459,7 @@ struct cm_ctx {
     uint8_t *d_ones = nullptr;                // all-active flags of a fresh batch
     uint64_t ones_cap = 0;
     unsigned long long *h_pin = nullptr;          // page-locked landing zone of the scalar read-backs (cell total, error flags, counts)
+    uint32_t h_pin_nt = 0;                        // pairs of the tile whose heavy load was last sent to h_pin[4] (0: none yet)
     std::string err = "";
     Slot slots[MAX_SLOTS];
     // reads
@@ -1881,6 +1882,7 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         delete ctx;
         return CM_ENOMEM;
     }
+    memset(ctx->h_pin, 0, 64);
     (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);
     (void)hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), ctx->stream);
     if (getenv("CM_ONE_STREAM")) {           // diagnostic: no concurrency between the light and the heavy kernels
@@ -2407,6 +2409,9 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             load = ctx->d_heavy_load;
             HIPCHK(ctx, hipMemsetAsync(load, 0, sizeof(unsigned long long), sp));
             hipLaunchKernelGGL(k_pair_cost, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, rb.nchain, act_in, p0, nt, HEAVY_COST, load);
+            // the host learns the load of a tile one or two items late (no wait): good enough to size the next heavy grid
+            HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 4), load, sizeof(unsigned long long), hipMemcpyDeviceToHost, sp));
+            ctx->h_pin_nt = nt;
         }
         hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, core, rb.chains, rb.resid, rb.nchain, act_in, p0, nt, ctx->d_cls,
                            ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2, act_out, (const unsigned long long *)load);
@@ -2442,10 +2447,15 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         // both pair kernels are persistent: together they fill `pair_waves` wave slots per SIMD (256 CUs x 4 SIMDs), half each
         static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
         const unsigned cap = 256u * 4u * slots_per_simd;
-        // heavy grid = the whole wave capacity since round 3 (half of it until then): on the dense genome the heavy kernel is the
-        // one with work for every slot (19.9 vs 18.9 M pairs/s; chr21 and the round-2 genome do not care)
-        static const unsigned heavy_div = getenv("CM_HEAVY_DIV") ? (unsigned)atoi(getenv("CM_HEAVY_DIV")) : 1u;      // tuning knob
-        const unsigned heavy_cap = cap / (heavy_div ? heavy_div : 1u);
+        // Heavy grid: half the wave capacity, or all of it when the tiles of this run carry a large heavy load (the value
+        // k_pair_cost left for an earlier item, read without waiting): on the dense genome the heavy kernel has work for every
+        // slot (19.9 vs 18.9 M pairs/s); with little heavy work the extra waves only sit on registers the next item's chain
+        // stage is waiting for (round-2 genome: 43.3 vs 44.4 M pairs/s).
+        static const unsigned heavy_div_env = getenv("CM_HEAVY_DIV") ? (unsigned)atoi(getenv("CM_HEAVY_DIV")) : 0u;      // tuning knob
+        const volatile unsigned long long *seen = (const volatile unsigned long long *)(ctx->h_pin + 4);
+        const bool loaded_run = ctx->h_pin_nt && *seen > HEAVY_LOAD * (unsigned long long)ctx->h_pin_nt;
+        const unsigned heavy_div = heavy_div_env ? heavy_div_env : (loaded_run ? 1u : 2u);
+        const unsigned heavy_cap = cap / heavy_div;
         static const unsigned heavy_fix = getenv("CM_HEAVY_GRID") ? (unsigned)atoi(getenv("CM_HEAVY_GRID")) : 0u;    // tuning knob
         const unsigned heavy_lim = std::min(heavy_fix ? heavy_fix : heavy_cap, HEAVY_GRID_MAX);     // d_hres is sized for HEAVY_GRID_MAX blocks
         const unsigned heavy_grid = nt < heavy_lim ? (nt ? nt : 1u) : heavy_lim;

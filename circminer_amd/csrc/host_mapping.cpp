@@ -293,6 +293,9 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
                 } else ++it;
             }
             if (have) continue;
+            // (the parser reuses its four generations of arrays, so there are 16 live ranges; if they kept moving -- batches that
+            // keep growing -- stale registrations would pile up: past 64 the copies simply go through pageable staging)
+            if (pinned.size() >= 64) continue;
             if (cm_host_register(cm, (void *)ptr[j], bytes[j]) == CM_OK) pinned.emplace_back((void *)ptr[j], bytes[j]);
             // (a failed registration is not an error: the copy is then a staged pageable one)
         }

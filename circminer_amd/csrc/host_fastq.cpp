@@ -255,7 +255,7 @@ struct cm_fastq {
         RawVec<cm_mapped_read> prior;
     } gen[4];
     int cur = 3;
-    int n_threads = 0;                       // tokeniser threads of the plain-text path (0 = hardware concurrency, at most 32)
+    int n_threads = 0;                       // tokeniser threads of the plain-text path (0 = hardware concurrency, at most 16; CM_FASTQ_THREADS overrides, at most 32)
     std::vector<size_t> nl1, nl2;            // newline index of the two block buffers (plain-text path)
     std::vector<std::string> chr_names;
     int max_ed = 4;
@@ -510,6 +510,9 @@ bool build_side(cm_fastq *f, Stream &s, const std::vector<size_t> &nl, size_t n,
 // cm_fastq_next for two plain-text files; *n_out pairs
 int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_out, uint64_t *n2_out) {
     int nt = f->n_threads > 0 ? f->n_threads : (int)std::thread::hardware_concurrency();
+    // more threads than this only fight over the page-cache copies and the writer's bandwidth: file to file on a 256-CPU box,
+    // 32 M chr21-like pairs: 10.1 / 14.4 / 13.1 / 11.7 / 9.0 M pairs/s with 8 / 16 / 24 / 32 / 64 threads (tests/diag/e2e_reports.py)
+    if (nt > 16) nt = 16;
     if (const char *e = getenv("CM_FASTQ_THREADS")) nt = atoi(e);
     nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
     const int half = nt > 1 ? nt / 2 : 1;

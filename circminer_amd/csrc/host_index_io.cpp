@@ -333,20 +333,48 @@ int cm_host_write_index(const char *packed_fa_path, const char *index_path, int3
             if (rc != CM_OK) break;
             const uint32_t memsz = (uint32_t)mem;
             ok = put(f, memsz);
-            std::vector<Entry> slab;
-            slab.reserve(1u << 16);
-            for (uint64_t h = 0; h < nb && ok; ++h) {
-                if (!cnt14[h]) continue;
-                const uint32_t a = iv.bucket_off[h], b = iv.bucket_off[h + 1];
-                slab.push_back(Entry{0, 0, (int32_t)(b - a)});
-                for (uint32_t i = a; i < b; ++i) slab.push_back(Entry{iv.checksum[i], 0, (int32_t)iv.pos[i]});
-                for (uint32_t i = b - a; i < cnt14[h]; ++i) slab.push_back(Entry{0, 0, 0});
-                if (slab.size() >= (1u << 16)) {
-                    ok = fwrite(slab.data(), sizeof(Entry), slab.size(), f) == slab.size();
-                    slab.clear();
-                }
+            // The table (per non-empty bucket: a header slot with the number of valid entries, the entries, zeroed slack up to
+            // count14): bucket ranges are laid out side by side into one buffer -- a range's first slot is the sum of
+            // (count14 + 1) over the non-empty buckets in front of it -- and written with one call.
+            const int T = std::max(1, std::min(n_threads, 32));
+            std::vector<uint64_t> first((size_t)T + 1, 0);
+            {
+                std::vector<std::thread> th;
+                auto sum = [&](int t) {
+                    uint64_t acc = 0;
+                    for (uint64_t h = nb * (uint64_t)t / T, e = nb * (uint64_t)(t + 1) / T; h < e; ++h)
+                        if (cnt14[h]) acc += (uint64_t)cnt14[h] + 1;
+                    first[(size_t)t + 1] = acc;
+                };
+                for (int t = 1; t < T; ++t) th.emplace_back(sum, t);
+                sum(0);
+                for (auto &x : th) x.join();
+                for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
             }
-            if (ok && !slab.empty()) ok = fwrite(slab.data(), sizeof(Entry), slab.size(), f) == slab.size();
+            Entry *tab = (Entry *)big_alloc(((size_t)memsz + 1) * sizeof(Entry));
+            if (!tab) {
+                cm_host_free_index(&iv);
+                rc = CM_ENOMEM;
+                break;
+            }
+            {
+                std::vector<std::thread> th;
+                auto fill = [&](int t) {
+                    Entry *w = tab + first[(size_t)t];
+                    for (uint64_t h = nb * (uint64_t)t / T, e = nb * (uint64_t)(t + 1) / T; h < e; ++h) {
+                        if (!cnt14[h]) continue;
+                        const uint32_t x0 = iv.bucket_off[h], x1 = iv.bucket_off[h + 1];
+                        *w++ = Entry{0, 0, (int32_t)(x1 - x0)};
+                        for (uint32_t i = x0; i < x1; ++i) *w++ = Entry{iv.checksum[i], 0, (int32_t)iv.pos[i]};
+                        for (uint32_t i = x1 - x0; i < cnt14[h]; ++i) *w++ = Entry{0, 0, 0};
+                    }
+                };
+                for (int t = 1; t < T; ++t) th.emplace_back(fill, t);
+                fill(0);
+                for (auto &x : th) x.join();
+            }
+            ok = ok && (memsz == 0 || fwrite(tab, sizeof(Entry), memsz, f) == memsz);
+            free(tab);
             cm_host_free_index(&iv);
         }
     }

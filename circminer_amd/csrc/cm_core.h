@@ -31,6 +31,9 @@
 #endif
 
 // test-only work counters (defined by tests/hostemu.cpp when it wants them)
+#if !defined(CM_HOOK_DP)          // host emulation only (tests/diag/dp_dup.py): every X-drop DP request, before its fast path
+#define CM_HOOK_DP(kind, s, n, t, m) ((void)0)
+#endif
 #if defined(CM_STATS) && !defined(__HIPCC__)
 extern "C" unsigned long long cm_stats[16];
 #define CM_STAT(i, n) (cm_stats[i] += (unsigned long long)(n))
@@ -1278,6 +1281,7 @@ inline int local_alignment_sc_edit(const Core &c, const LBuf &s, int n, const LB
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
     CM_TICK(sm, 24);
+    CM_HOOK_DP(0, s, n, t, m);
 #if defined(CM_STAGE2_HOST)
     if (sm.edit) {
         if (!dp_fits(sm, n, m)) { sc_len = c.P.max_sc + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
@@ -1297,6 +1301,7 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
     CM_TICK(sm, 26);
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
     const bool w3 = c.P.band == 3;
+    CM_HOOK_DP(1, s, n, t, m);
     stage(s, n, sm.a, 4);
     stage(w3 ? t.rev(m) : t, m, sm.b, 5);                     // the band-3 DP walks the read residual from its far end
     CM_STAT(11 + (m > 16) + (m > 32) + (m > 64), 1);          // X-drop DPs by read-residual length (test-only counters)
@@ -2216,6 +2221,8 @@ CM_HD inline int process_mates(const Core &c, const DpMem &sm, const ChainSet &f
     for (int x = 0; x < n_ptype; ++x) ptype[x] = 0;
     uint32_t fpaired = 0, bpaired = 0;
     uint32_t tids[MAX_TID];
+    CM_STAT(1, fwd.n * bwd.n);
+    CM_STAT(6, 1);
     for (int i = 0; i < fwd.n; ++i)
         for (int j = 0; j < bwd.n; ++j) {
             const CHEnds F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};

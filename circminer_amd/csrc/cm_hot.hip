@@ -999,176 +999,64 @@ __global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t
     }
 }
 
-struct HRes {            // outcome of one mate-pair task, handed from the computing lane to lane 0
+struct HRes {            // outcome of one mate-pair task, handed from the computing lane to the pair's owner lane
     cmc::MM r1, r2;
     int32_t row;
     int32_t pair_type;
     uint8_t ok, is_left, pad[2];
 };
-constexpr int HEAVY_SCRATCH = 912 * 3;   // bytes of per-block global scratch behind HRes[64]: list[912] (u16) + codes[912]
-struct HeavyLds {
-    CM_G uint8_t *codes;     // pairing predicate per (i, j), i-major          [900]   (global: see res)
-    CM_G uint16_t *list;     // accepted (i, j) in order                        [900]   (global: see res)
-    CM_L int *fe, *re;       // exon interval of each chain's first fragment    [32] + [32]
-    CM_G HRes *res;          // [64], this block's slice of a global buffer.  LDS is what limits this kernel's occupancy: with the
-                             // two DP strings + fe/re only (< 10 KB per wave) four waves per SIMD fit, with codes/list in LDS three
+// k_pair_heavy maps HG heavy pairs per wave side by side.  A heavy pair has hundreds of pairing-predicate evaluations but few
+// accepted mate pairs (section-8(d) genome: 5.5 per process_mates call, tests/diag/heavy_shape.py): one pair per wave left 55 of
+// the 64 lanes idle through the extensions, which are four fifths of the kernel (7.9 lanes per VALU instruction, VALU issue
+// saturated).  Here every phase of process_mates runs over ONE work list of the whole wave -- chain ends, predicate evaluations,
+// accepted mate pairs, unpaired chains of all HG pairs, one item per lane -- and lane g < HG (the "owner" of slot g) keeps pair g's
+// MatchedRead and folds its outcomes in the reference's order.  What a lane needs of a pair it reads from the pair's slot in LDS.
+#ifndef CM_HEAVY_G
+#define CM_HEAVY_G 8
+#endif
+constexpr int HG = CM_HEAVY_G;
+static_assert(HG >= 1 && HG <= 16, "the task list packs the slot in 4 bits");
+constexpr int HEAVY_LIST = HG * CM_BESTCHAINLIM * CM_BESTCHAINLIM;      // accepted (i, j) of all slots, worst case
+constexpr int HEAVY_SCRATCH = HEAVY_LIST * 2;     // bytes of per-block global scratch behind HRes[64]: the task list (u16)
+struct HSlot {           // one pair in flight (LDS).  Written by its owner lane unless noted.
+    cmc::g_chain fch, bch;               // chain lists of this attempt: forward read's, backward read's
+    cmc::g_u8 fseq, bseq;                // the two reads (forward read: as stored; backward read: reverse complement)
+    cmc::g_err perr;                     // capacity-limit word of the pair (RetryArgs)
+    int flen, blen;
+    int nf, nb;                          // chains; 0 / 0 while the slot sits an attempt out
+    unsigned int inv_nb;                 // ceil(65536 / nb): idx / nb = idx * inv_nb >> 16 for idx < 900
+    int saved_type;                      // MatchedRead.type at the start of the attempt (pairing predicate)
+    unsigned int fp, bp;                 // chains that found a mate (atomicOr by the predicate lanes)
+    int ntask;                           // accepted mate pairs (atomicAdd by the predicate lanes)
+    int done;                            // the fold returned CONCRD: the slot's remaining tasks are dead
+    unsigned int fun, bun;               // unpaired chains to extend
+    int nfu, nbu;
+    int exf, exb, gf, gb;                // outcome of the unpaired-chain extensions (atomicMin / written by the k == 0 lane)
+    int fe[32], re[32];                  // exon interval of each chain's first fragment (written by the chain-end lanes)
+    uint32_t r0[64], rend[64];           // reference span of the chains: [0, 32) forward, [32, 64) backward
 };
 
 __device__ inline int nth_set_bit(uint32_t m, int k) {
     for (int x = 0; x < k; ++x) m &= m - 1;
     return __ffs((int)m) - 1;
 }
-template <class T> __device__ inline T wave_min(T v) {
-    for (int o = 32; o >= 1; o >>= 1) { const T u = __shfl_xor(v, o); v = u < v ? u : v; }
-    return v;
-}
-
-// process_mates (src/filter.cpp:244-395) for one pair, executed by one wave.  `mr` is authoritative on
-// lane 0; mr.type is kept in sync on every lane (it is the saved_type of the pairing predicate).
-__device__ int mates_wave(const Core &c, const cmc::DpMem &sm, const cmc::ChainSet &fwd, const cmc::Read &frd, const cmc::ChainSet &bwd,
-                          const cmc::Read &brd, cm_mapped_read &mr, bool r1_forward, cmc::g_err err, const HeavyLds &H, int lane) {
-    const int kmer = c.P.kmer;
-    const int saved_type = mr.type;
-    const cmc::Ext ext(c, sm);
-    uint32_t tids[cmc::MAX_TID];
-    // lane i < 32 keeps the span of forward chain i, lane 32 + j that of backward chain j: the T = n x m predicate evaluations
-    // below fetch them with shuffles instead of 6 global loads each
-    uint32_t my_r0 = 0, my_rend = 0;
-    if (lane < fwd.n) {
-        const cmc::CHEnds e{fwd.ch + lane, kmer};
-        my_r0 = e.r0;
-        my_rend = e.rend;
-        H.fe[lane] = cmc::overlap(c, e.r0);
+// item x of a work list that concatenates the slots' items: pre[g] = items before slot g's, pre[HG] = all
+__device__ inline void locate(const int (&pre)[HG + 1], int x, int &g, int &k) {
+    g = 0;
+    int b = 0;
+#pragma unroll
+    for (int s = 1; s < HG; ++s) {
+        const bool ge = x >= pre[s];
+        g += ge ? 1 : 0;
+        b = ge ? pre[s] : b;
     }
-    if (lane >= 32 && lane - 32 < bwd.n) {
-        const cmc::CHEnds e{bwd.ch + (lane - 32), kmer};
-        my_r0 = e.r0;
-        my_rend = e.rend;
-        H.re[lane - 32] = cmc::overlap(c, e.r0);
-    }
-    __syncthreads();
-    const int T = fwd.n * bwd.n;
-    uint32_t fp = 0, bp = 0;
-    for (int base = 0; base < T; base += 64) {            // uniform trip count: the shuffles need every lane
-        const int idx = base + lane;
-        const int ic = idx < T ? idx / bwd.n : 0, jc = idx < T ? idx - ic * bwd.n : 0;
-        const uint32_t f0 = (uint32_t)__shfl((int)my_r0, ic), f1 = (uint32_t)__shfl((int)my_rend, ic);
-        const uint32_t b0 = (uint32_t)__shfl((int)my_r0, 32 + jc), b1 = (uint32_t)__shfl((int)my_rend, 32 + jc);
-        if (idx >= T) continue;
-        const int i = ic, j = jc;
-        const cmc::CHEnds F{f0, f1}, R{b0, b1};
-        const uint32_t code = cmc::pair_code(c, F, R, H.fe[i], H.re[j], saved_type);
-        H.codes[idx] = (uint8_t)code;
-        if (code) {
-            fp |= 1u << i;
-            bp |= 1u << j;
-        }
-    }
-    for (int o = 32; o >= 1; o >>= 1) {
-        fp |= __shfl_xor(fp, o);
-        bp |= __shfl_xor(bp, o);
-    }
-    __syncthreads();
-    CM_TICK(sm, 29);
-    int ntask = 0;
-    for (int base = 0; base < T; base += 64) {
-        const int idx = base + lane;
-        const uint32_t code = idx < T ? H.codes[idx] : 0u;
-        const unsigned long long m = __ballot(code != 0);
-        if (code) H.list[ntask + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)idx;
-        ntask += __popcll(m);
-    }
-    __syncthreads();
-    int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN, g1 = 0, g2 = 0;          // meaningful on lane 0
-    for (int b0 = 0; b0 < ntask; b0 += 64) {
-        const int x = b0 + lane;
-        if (x < ntask) {
-            const int idx = H.list[x];
-            const int i = idx / bwd.n, j = idx - i * bwd.n;
-            const uint32_t code = H.codes[idx];
-            const cmc::TidList tl = (code == 1) ? cmc::common_tids(c, H.fe[i], H.re[j], tids) : cmc::TidList{tids, 0, -1, -1, false};
-            const cmc::CH F{fwd.ch + i, kmer}, R{bwd.ch + j, kmer};
-            cmc::MM r1, r2;
-            bool il, ok;
-            int row;
-            cmc::extend_task(c, ext, F, R, tl, frd, brd, r1, r2, il, ok, row);
-            H.res[lane].r1 = r1;
-            H.res[lane].r2 = r2;
-            H.res[lane].row = row;
-            H.res[lane].pair_type = (int)code - 1;
-            H.res[lane].ok = ok;
-            H.res[lane].is_left = il;
-        }
-        __syncthreads();
-        CM_TICK(sm, 30);
-        int early = 0;
-        if (lane == 0) {
-            const int cnt = (ntask - b0 < 64) ? ntask - b0 : 64;
-            for (int y = 0; y < cnt; ++y) {
-                const cmc::MM r1 = H.res[y].r1, r2 = H.res[y].r2;
-                if (cmc::fold_task(c, r1, r2, H.res[y].is_left != 0, H.res[y].ok != 0, H.res[y].row, H.res[y].pair_type, r1_forward, mr)) {
-                    early = 1;
-                    break;
-                }
-                min_ret1 = r1.type < min_ret1 ? r1.type : min_ret1;
-                min_ret2 = r2.type < min_ret2 ? r2.type : min_ret2;
-                g1 = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
-                g2 = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
-            }
-        }
-        early = __shfl(early, 0);
-        __syncthreads();
-        CM_TICK(sm, 31);
-        if (early) return CM_CONCRD;
-    }
-    mr.type = __shfl(mr.type, 0);
-    if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) return mr.type;
-    min_ret1 = __shfl(min_ret1, 0);
-    min_ret2 = __shfl(min_ret2, 0);
-    g1 = __shfl(g1, 0);
-    g2 = __shfl(g2, 0);
-    // unpaired-chain extensions: forward chains on lanes 0..31, backward chains on lanes 32..63.  The
-    // reference reuses one MatchedMate for all chains of a side, so only the first chain's exon lookups
-    // ever happen (stale looked_up_* flags, filter.cpp:356-385): lane 0 / lane 32 compute the genic flag.
-    const uint32_t fun = ~fp & (fwd.n >= 32 ? 0xffffffffu : ((1u << fwd.n) - 1u));
-    const uint32_t bun = ~bp & (bwd.n >= 32 ? 0xffffffffu : ((1u << bwd.n) - 1u));
-    const bool do_f = min_ret1 != CM_CONCRD && fun != 0, do_b = min_ret2 != CM_CONCRD && bun != 0;
-    if (!cmc::leftovers_matter(mr.type, min_ret1, do_f, min_ret2, do_b)) return mr.type;
-    int ex = 99, genic = 0;
-    {
-        const bool back = lane >= 32;
-        const int k = back ? lane - 32 : lane;
-        const uint32_t un = back ? bun : fun;
-        if ((back ? do_b : do_f) && k < __popc(un)) {
-            const int ci = nth_set_bit(un, k);
-            const cmc::CH ch{(back ? bwd.ch : fwd.ch) + ci, kmer};
-            cmc::MM m = cmc::mm_init(c);
-            ex = ext.chain_both_sides(ch, back ? brd : frd, m, back ? -1 : 1);
-            if (k == 0) {
-                cmc::overlap_to_spos(c, m);
-                cmc::overlap_to_epos(c, m);
-                genic = (m.exons_spos >= 0) || (m.exons_epos >= 0);
-            }
-        }
-    }
-    CM_TICK(sm, 15);
-    const int exf = wave_min(lane < 32 ? ex : 99), exb = wave_min(lane >= 32 ? ex : 99);
-    const int gf = __shfl(genic, 0), gb = __shfl(genic, 32);
-    if (do_f) {
-        min_ret1 = exf < min_ret1 ? exf : min_ret1;
-        g1 = gf;
-    }
-    if (do_b) {
-        min_ret2 = exb < min_ret2 ? exb : min_ret2;
-        g2 = gb;
-    }
-    cmc::mr_update_type(mr, cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0));
-    return mr.type;
+    k = x - b;
 }
 
 #ifndef CM_HEAVY_WAVES
 #define CM_HEAVY_WAVES CM_PAIR_WAVES
 #endif
+// process_read (src/filter.cpp:124-241) + process_mates (src/filter.cpp:244-395) for HG pairs per wave iteration.
 __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore kc, ReadsDev rd, uint64_t pair0, const uint32_t *hlist, const unsigned int *hcount,
                                                          const cm_chain *chains, const int32_t *nchain, const int32_t *high, cm_mapped_read *state,
                                                          uint8_t *active, int32_t *cat, int is_last, int *err, unsigned long long *counters,
@@ -1192,69 +1080,259 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
 #else
     cmc::DpMem sm{cmc::LBuf{lane_base, str_cap}, cmc::LBuf{lane_base + str_stride, str_cap}, (cmc::g_err)err};
 #endif
-    CM_L uint8_t *q = base + lds_stage_bytes;
-    HeavyLds H;
-    H.res = (CM_G HRes *)(hres + (size_t)blockIdx.x * 64);
-    H.fe = (CM_L int *)q;
-    H.re = H.fe + 32;
-    {
-        CM_G uint8_t *g = (CM_G uint8_t *)(hres + (size_t)gridDim.x * 64) + (size_t)blockIdx.x * HEAVY_SCRATCH;
-        H.list = (CM_G uint16_t *)g;
-        H.codes = g + 912 * sizeof(uint16_t);
-    }
+    CM_L HSlot *S = (CM_L HSlot *)(base + lds_stage_bytes);
+    CM_G HRes *res = (CM_G HRes *)(hres + (size_t)blockIdx.x * 64);
+    CM_G uint16_t *list = (CM_G uint16_t *)((CM_G uint8_t *)(hres + (size_t)gridDim.x * 64) + (size_t)blockIdx.x * HEAVY_SCRATCH);
     const Core c = cmc::to_core(kc);
+    const cmc::Ext ext(c, sm);
+    const int kmer = c.P.kmer;
     const unsigned int n_heavy = *hcount;
-    // one pair at a time from a shared cursor (the list starts with the most expensive pairs)
-    auto take = [&]() { return (unsigned int)__shfl((int)(lane == 0 ? atomicAdd(next_pair, 1u) : 0u), 0); };
-    for (unsigned int h = take(); h < n_heavy; h = take()) {
-        const uint32_t t = hlist[h];
-        const uint64_t p = pair0 + t;
-        const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
-        const int len1 = (int)(a1 - a0), len2 = (int)(b1 - b0);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t tids[cmc::MAX_TID];
+    // HG pairs at a time from a shared cursor (the list starts with the most expensive pairs; neighbours cost about the same)
+    auto take = [&]() { return (unsigned int)__shfl((int)(lane == 0 ? atomicAdd(next_pair, (unsigned int)HG) : 0u), 0); };
+    for (unsigned int h0 = take(); h0 < n_heavy; h0 = take()) {
+        // ---- owners: lane g holds pair h0 + g -------------------------------------------------------------------------
+        const bool owner = lane < HG && h0 + (unsigned int)lane < n_heavy;
+        uint32_t t = 0;
+        uint64_t p = 0;
+        int len1 = 0, len2 = 0, st = -1;
         cmc::ChainSet sets[4];
-        int hh[4];
-        for (int x = 0; x < 4; ++x) {
-            const uint64_t r = (uint64_t)t * 4 + x;
-            sets[x].ch = (cmc::g_chain)(chains + r * CM_BESTCHAINLIM);
-            sets[x].n = nchain[r];
-            hh[x] = high[r];
-        }
-        cm_mapped_read mr = state[p];
-        int st = -1;
-#if defined(CM_AB_GLOBAL_ERR)
-        int *perr = err;
-#else
-        int *perr = (int *)(ra.pair_err + t);        // capacity limits of this pair (see RetryArgs): every lane of the wave flags the same word
-        sm.err = (cmc::g_err)perr;
-#endif
-        const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
-        if (n1 + n2 <= 0) {             // unreachable for a pair classified heavy; kept for completeness
-            st = ((hh[0] + hh[1] > 0) && (hh[2] + hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
-            cmc::mr_update_type(mr, st);
-        } else if (n1 <= 0 || n2 <= 0) {
-            st = CM_OEANCH;
-            cmc::mr_update_type(mr, st);
-        } else {
-            const float fc1 = sets[0].n > 0 ? sets[0].ch[0].score : 0.f, bc1 = sets[1].n > 0 ? sets[1].ch[0].score : 0.f;
-            const float fc2 = sets[2].n > 0 ? sets[2].ch[0].score : 0.f, bc2 = sets[3].n > 0 ? sets[3].ch[0].score : 0.f;
-            const float lhs = fc1 + bc2, rhs = fc2 + bc1;
-            const cmc::g_u8 s1 = (cmc::g_u8)(rd.seq1 + a0), s2 = (cmc::g_u8)(rd.seq2 + b0);
-            const cmc::Read r1f{s1, len1, 0}, r1b{s1, len1, 1}, r2f{s2, len2, 0}, r2b{s2, len2, 1};
-            const bool first = lhs >= rhs;
-            for (int attempt = 0; attempt < 2 && st < 0; ++attempt) {
-                int a;
-                if ((attempt == 0) == first) a = mates_wave(c, sm, sets[0], r1f, sets[3], r2b, mr, true, (cmc::g_err)perr, H, lane);
-                else a = mates_wave(c, sm, sets[2], r2f, sets[1], r1b, mr, false, (cmc::g_err)perr, H, lane);
-                if (c.P.scan_level == 0 && a == CM_CONCRD) st = CM_CONCRD;
-                __syncthreads();
+        cmc::g_u8 s1 = nullptr, s2 = nullptr;
+        cm_mapped_read mr{};
+        bool first = true;
+        for (int x = 0; x < 4; ++x) { sets[x].ch = nullptr; sets[x].n = 0; }
+        if (owner) {
+            t = hlist[h0 + lane];
+            p = pair0 + t;
+            const uint64_t a0 = rd.off1[p], a1 = rd.off1[p + 1], b0 = rd.off2[p], b1 = rd.off2[p + 1];
+            len1 = (int)(a1 - a0);
+            len2 = (int)(b1 - b0);
+            s1 = (cmc::g_u8)(rd.seq1 + a0);
+            s2 = (cmc::g_u8)(rd.seq2 + b0);
+            int hh[4];
+            for (int x = 0; x < 4; ++x) {
+                const uint64_t r = (uint64_t)t * 4 + x;
+                sets[x].ch = (cmc::g_chain)(chains + r * CM_BESTCHAINLIM);
+                sets[x].n = nchain[r];
+                hh[x] = high[r];
             }
-            if (st < 0) st = __shfl(mr.type, 0);
+            mr = state[p];
+            const int n1 = sets[0].n + sets[1].n, n2 = sets[2].n + sets[3].n;
+            if (n1 + n2 <= 0) {             // unreachable for a pair classified heavy; kept for completeness
+                st = ((hh[0] + hh[1] > 0) && (hh[2] + hh[3] > 0)) ? CM_NOPROC_MANYHIT : CM_NOPROC_NOMATCH;
+                cmc::mr_update_type(mr, st);
+            } else if (n1 <= 0 || n2 <= 0) {
+                st = CM_OEANCH;
+                cmc::mr_update_type(mr, st);
+            } else {
+                const float fc1 = sets[0].n > 0 ? sets[0].ch[0].score : 0.f, bc1 = sets[1].n > 0 ? sets[1].ch[0].score : 0.f;
+                const float fc2 = sets[2].n > 0 ? sets[2].ch[0].score : 0.f, bc2 = sets[3].n > 0 ? sets[3].ch[0].score : 0.f;
+                first = (fc1 + bc2) >= (fc2 + bc1);
+            }
         }
-        // the wave's own atomicOr's on the pair's word have reached the L2 after this (a workgroup-scope fence = s_waitcnt for a
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            // ---- owners publish the attempt of their pair (process_read's loop: forward R1 / backward R2, or the other way) ----
+            const bool on = owner && st < 0;
+            const bool r1_fwd = (attempt == 0) == first;
+            if (lane < HG) {
+                CM_L HSlot &s = S[lane];
+                const cmc::ChainSet &F = r1_fwd ? sets[0] : sets[2], &B = r1_fwd ? sets[3] : sets[1];
+                s.fch = F.ch;
+                s.bch = B.ch;
+                s.fseq = r1_fwd ? s1 : s2;
+                s.bseq = r1_fwd ? s2 : s1;
+                s.flen = r1_fwd ? len1 : len2;
+                s.blen = r1_fwd ? len2 : len1;
+                s.perr = (cmc::g_err)(ra.pair_err + t);
+                s.nf = on ? F.n : 0;
+                s.nb = on ? B.n : 0;
+                s.inv_nb = (on && B.n > 0) ? (65536u + (unsigned int)B.n - 1u) / (unsigned int)B.n : 0u;
+                s.saved_type = mr.type;
+                s.fp = 0u;
+                s.bp = 0u;
+                s.ntask = 0;
+                s.done = 0;
+                s.nfu = 0;
+                s.nbu = 0;
+            }
+            if (__ballot(on) == 0ull) break;                   // uniform: every pair of this iteration is settled
+            __syncthreads();
+            int pre[HG + 1];
+            // ---- chain ends: reference span + exon interval of the first fragment, one chain per lane -------------------------
+            pre[0] = 0;
+#pragma unroll
+            for (int g = 0; g < HG; ++g) pre[g + 1] = pre[g] + S[g].nf + S[g].nb;
+            for (int x = lane; x < pre[HG]; x += 64) {
+                int g, k;
+                locate(pre, x, g, k);
+                CM_L HSlot &s = S[g];
+                const int nf = s.nf;
+                const bool back = k >= nf;
+                const int ci = back ? k - nf : k;
+                const cmc::CHEnds e{(back ? s.bch : s.fch) + ci, kmer};
+                s.r0[(back ? 32 : 0) + ci] = e.r0;
+                s.rend[(back ? 32 : 0) + ci] = e.rend;
+                (back ? s.re : s.fe)[ci] = cmc::overlap(c, e.r0);
+            }
+            __syncthreads();
+            // ---- pairing predicate of every (i, j) of every slot; the accepted ones go to the task list in (slot, i, j) order ----
+            pre[0] = 0;
+#pragma unroll
+            for (int g = 0; g < HG; ++g) pre[g + 1] = pre[g] + S[g].nf * S[g].nb;
+            int n_task = 0;
+            for (int b0 = 0; b0 < pre[HG]; b0 += 64) {
+                const int x = b0 + lane;
+                uint32_t code = 0;
+                int g = 0, idx = 0;
+                if (x < pre[HG]) {
+                    locate(pre, x, g, idx);
+                    CM_L HSlot &s = S[g];
+                    const int i = (int)(((unsigned int)idx * s.inv_nb) >> 16), j = idx - i * s.nb;
+                    const cmc::CHEnds F{s.r0[i], s.rend[i]}, R{s.r0[32 + j], s.rend[32 + j]};
+                    code = cmc::pair_code(c, F, R, s.fe[i], s.re[j], s.saved_type);
+                    if (code) {
+                        atomicOr((unsigned int *)&s.fp, 1u << i);
+                        atomicOr((unsigned int *)&s.bp, 1u << j);
+                        atomicAdd((int *)&s.ntask, 1);
+                    }
+                }
+                const unsigned long long m = __ballot(code != 0);
+                if (code) list[n_task + __popcll(m & lt_mask)] = (uint16_t)((unsigned int)idx | (code << 10) | ((unsigned int)g << 12));
+                n_task += __popcll(m);
+            }
+            __syncthreads();
+            CM_TICK(sm, 29);
+            // ---- mate-pair tasks: one per lane, 64 at a time; each owner folds its slot's outcomes in order --------------------
+            int t_lo = 0, t_hi = 0;                                     // the owner's slice of the task list
+            if (lane < HG) {
+                for (int g = 0; g < HG; ++g) t_lo += g < lane ? S[g].ntask : 0;
+                t_hi = t_lo + S[lane].ntask;
+            }
+            int min_ret1 = CM_ORPHAN, min_ret2 = CM_ORPHAN, g1 = 0, g2 = 0;          // meaningful on the owners
+            bool early = false;
+            for (int b0 = 0; b0 < n_task; b0 += 64) {
+                const int x = b0 + lane;
+                if (x < n_task) {
+                    const unsigned int e = list[x];
+                    CM_L HSlot &s = S[e >> 12];
+                    if (!s.done) {
+                        const uint32_t code = (e >> 10) & 3u;
+                        const int idx = (int)(e & 1023u);
+                        const int i = (int)(((unsigned int)idx * s.inv_nb) >> 16), j = idx - i * s.nb;
+                        sm.err = s.perr;
+                        const cmc::TidList tl = (code == 1) ? cmc::common_tids(c, s.fe[i], s.re[j], tids) : cmc::TidList{tids, 0, -1, -1, false};
+                        const cmc::CH F{s.fch + i, kmer}, R{s.bch + j, kmer};
+                        const cmc::Read frd{s.fseq, s.flen, 0}, brd{s.bseq, s.blen, 1};
+                        cmc::MM r1, r2;
+                        bool il, ok;
+                        int row;
+                        cmc::extend_task(c, ext, F, R, tl, frd, brd, r1, r2, il, ok, row);
+                        res[lane].r1 = r1;
+                        res[lane].r2 = r2;
+                        res[lane].row = row;
+                        res[lane].pair_type = (int)code - 1;
+                        res[lane].ok = ok;
+                        res[lane].is_left = il;
+                    }
+                }
+                __syncthreads();
+                CM_TICK(sm, 30);
+                if (on && !early) {
+                    const int lo = t_lo > b0 ? t_lo : b0, hi = t_hi < b0 + 64 ? t_hi : b0 + 64;
+                    for (int y = lo; y < hi; ++y) {
+                        const cmc::MM r1 = res[y - b0].r1, r2 = res[y - b0].r2;
+                        if (cmc::fold_task(c, r1, r2, res[y - b0].is_left != 0, res[y - b0].ok != 0, res[y - b0].row, res[y - b0].pair_type, r1_fwd, mr)) {
+                            early = true;
+                            S[lane].done = 1;
+                            break;
+                        }
+                        min_ret1 = r1.type < min_ret1 ? r1.type : min_ret1;
+                        min_ret2 = r2.type < min_ret2 ? r2.type : min_ret2;
+                        g1 = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
+                        g2 = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
+                    }
+                }
+                __syncthreads();
+                CM_TICK(sm, 31);
+            }
+            // ---- owners: does the pair go on to the unpaired-chain extensions? (src/filter.cpp:344-393) ------------------------
+            int a = -1;                                                 // what process_mates returns
+            bool do_f = false, do_b = false;
+            if (on) {
+                CM_L HSlot &s = S[lane];
+                if (early) a = CM_CONCRD;
+                else if (mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ) a = mr.type;
+                else {
+                    const uint32_t fun = ~s.fp & (s.nf >= 32 ? 0xffffffffu : ((1u << s.nf) - 1u));
+                    const uint32_t bun = ~s.bp & (s.nb >= 32 ? 0xffffffffu : ((1u << s.nb) - 1u));
+                    do_f = min_ret1 != CM_CONCRD && fun != 0;
+                    do_b = min_ret2 != CM_CONCRD && bun != 0;
+                    if (!cmc::leftovers_matter(mr.type, min_ret1, do_f, min_ret2, do_b)) a = mr.type;
+                    else {
+                        s.fun = fun;
+                        s.bun = bun;
+                        s.nfu = do_f ? __popc(fun) : 0;
+                        s.nbu = do_b ? __popc(bun) : 0;
+                        s.exf = 99;
+                        s.exb = 99;
+                        s.gf = 0;
+                        s.gb = 0;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- unpaired chains: one full-length extension per lane.  The reference reuses one MatchedMate for all chains of a
+            // side, so only the first chain's exon lookups ever happen (stale looked_up_* flags, filter.cpp:356-385): the lane
+            // with k == 0 computes the genic flag of its side.
+            pre[0] = 0;
+#pragma unroll
+            for (int g = 0; g < HG; ++g) pre[g + 1] = pre[g] + S[g].nfu + S[g].nbu;
+            for (int x = lane; x < pre[HG]; x += 64) {
+                int g, u;
+                locate(pre, x, g, u);
+                CM_L HSlot &s = S[g];
+                const bool back = u >= s.nfu;
+                const int k = back ? u - s.nfu : u;
+                const int ci = nth_set_bit(back ? s.bun : s.fun, k);
+                const cmc::CH ch{(back ? s.bch : s.fch) + ci, kmer};
+                const cmc::Read frd{s.fseq, s.flen, 0}, brd{s.bseq, s.blen, 1};
+                cmc::MM m = cmc::mm_init(c);
+                sm.err = s.perr;
+                const int ex = ext.chain_both_sides(ch, back ? brd : frd, m, back ? -1 : 1);
+                atomicMin((int *)(back ? &s.exb : &s.exf), ex);
+                if (k == 0) {
+                    cmc::overlap_to_spos(c, m);
+                    cmc::overlap_to_epos(c, m);
+                    (back ? s.gb : s.gf) = (m.exons_spos >= 0) || (m.exons_epos >= 0);
+                }
+            }
+            __syncthreads();
+            CM_TICK(sm, 15);
+            if (on) {
+                if (a < 0) {
+                    CM_L HSlot &s = S[lane];
+                    if (do_f) {
+                        min_ret1 = s.exf < min_ret1 ? s.exf : min_ret1;
+                        g1 = s.gf;
+                    }
+                    if (do_b) {
+                        min_ret2 = s.exb < min_ret2 ? s.exb : min_ret2;
+                        g2 = s.gb;
+                    }
+                    cmc::mr_update_type(mr, cmc::leftover_type(min_ret1, min_ret2, g1 != 0, g2 != 0));
+                    a = mr.type;
+                }
+                if (c.P.scan_level == 0 && a == CM_CONCRD) st = CM_CONCRD;
+            }
+            __syncthreads();                                           // the slots are rewritten at the top of the next attempt
+        }
+        // the wave's own atomicOr's on the pairs' words have reached the L2 after this (a workgroup-scope fence = s_waitcnt for a
         // one-wave block; an agent-scope __threadfence() here invalidated the CU's vector L1 once per heavy pair and cost every
         // kernel on the chip 10 - 15 %)
         __threadfence_block();
-        if (lane == 0) {
+        if (owner) {
+            if (st < 0) st = mr.type;
             if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 ra.list[atomicAdd(ra.count, 1u)] = t;          // left as it was; the re-run launch of k_pair maps it (one lane, exact)
             } else {
@@ -2387,10 +2465,10 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     const size_t lds_need = (size_t)2 * lbuf_bytes(str_cap) * BLK_PAIR;
     size_t lds_bytes = lds_need;
     if (pair_waves >= 1 && pair_waves <= 3) {
-        const size_t want = ((size_t)160 * 1024 / (size_t)(4 * pair_waves)) - 64 * sizeof(int) - 256;      // heavy adds 64 ints; keep clear of the next step
+        const size_t want = ((size_t)160 * 1024 / (size_t)(4 * pair_waves)) - HG * sizeof(HSlot) - 256;      // heavy adds its slots; keep clear of the next step
         if (want > lds_bytes && want <= 60 * 1024) lds_bytes = want;
     }
-    const size_t lds_heavy = lds_bytes + 64 * sizeof(int);
+    const size_t lds_heavy = lds_bytes + HG * sizeof(HSlot);
     // the re-run launch of k_pair (RetryArgs): staging buffers for strings of any length a read of this batch can produce
     const int cap2 = std::min(((2 * ctx->max_len + 64 + 7) / 8) * 8, 1016);      // 1016: 64 KB of LDS per wave
     const size_t lds2 = (size_t)2 * lbuf_bytes(cap2) * BLK_PAIR;

@@ -11,11 +11,24 @@
 
 #include "circminer_hot.h"
 #define CM_STATS 1
+// diagnostic (tests/diag/dp_dup.py): every X-drop DP request of a pair (kind 0) and every one that runs the recurrence (kind 1)
+static void emu_hook_dp(int kind, const void *sp, int soff, int sstep, int smode, int n, const void *tp, int toff, int tstep, int tmode, int m);
+#define CM_HOOK_DP(kind, s, n, t, m) emu_hook_dp(kind, (const void *)(s).p, (s).off, (s).step, (s).mode, n, (const void *)(t).p, (t).off, (t).step, (t).mode, m)
 #include "cm_core.h"
 #include "cm_aos.h"
 extern "C" { unsigned long long cm_stats[16]; }
 
 using cmc::Core;
+#include <array>
+#include <set>
+static std::set<std::array<long long, 10>> g_dp_seen[2];
+static uint32_t g_dp_n[2];
+static bool g_dp_on = false;
+static void emu_hook_dp(int kind, const void *sp, int soff, int sstep, int smode, int n, const void *tp, int toff, int tstep, int tmode, int m) {
+    if (!g_dp_on) return;
+    ++g_dp_n[kind];
+    g_dp_seen[kind].insert({(long long)(size_t)sp, soff, sstep, smode, n, (long long)(size_t)tp, toff, tstep, tmode, m});
+}
 
 namespace {
 struct Emu {
@@ -155,6 +168,10 @@ int emu_chain_batch(const cm_params *P, const cm_index_view *X, const cm_annot_v
 }
 
 // diagnostic (tests/diag/lane_cost.py): when set, emu_map_round writes the CPU time of each pair's pair stage (ns) here
+static unsigned long long *g_pair_stats = nullptr;      // per pair: the 16 cm_stats counters of its pair stage
+void emu_set_stats_out(unsigned long long *out) { g_pair_stats = out; }
+static uint32_t *g_dp_dup = nullptr;        // per pair: requests, distinct requests, recurrences run, distinct recurrences
+void emu_set_dp_dup_out(uint32_t *out) { g_dp_dup = out; g_dp_on = out != nullptr; }
 static double *g_pair_ns = nullptr;
 static uint32_t *g_pair_dps = nullptr;      // number of real DPs (cmc::stage calls) of each pair
 void emu_set_cost_out(double *out) { g_pair_ns = out; }
@@ -200,11 +217,20 @@ int emu_map_round_spill(const cm_params *P, const cm_index_view *X, const cm_ann
             sm.spill = spill.data();
             sm.spill_cap = spill_cap;
         }
+        if (g_dp_dup) { g_dp_seen[0].clear(); g_dp_seen[1].clear(); g_dp_n[0] = g_dp_n[1] = 0; }
+        unsigned long long st0[16];
+        memcpy(st0, cm_stats, sizeof st0);
         const auto t0 = std::chrono::steady_clock::now();
         const unsigned long long dp0 = cm_stats[8];
         const int st = cmc::process_read(e.core, sm, R->seq1 + R->off1[p], l1, R->seq2 + R->off2[p], l2, sets, hh, state[p], &e.err);
         if (g_pair_ns) g_pair_ns[p] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
         if (g_pair_dps) g_pair_dps[p] = (uint32_t)(cm_stats[8] - dp0);
+        if (g_pair_stats)
+            for (int x = 0; x < 16; ++x) g_pair_stats[p * 16 + x] = cm_stats[x] - st0[x];
+        if (g_dp_dup) {
+            g_dp_dup[p * 4 + 0] = g_dp_n[0]; g_dp_dup[p * 4 + 1] = (uint32_t)g_dp_seen[0].size();
+            g_dp_dup[p * 4 + 2] = g_dp_n[1]; g_dp_dup[p * 4 + 3] = (uint32_t)g_dp_seen[1].size();
+        }
         cmc::finish_round(e.core, st, is_last, l1, l2, state[p], active[p]);
         category[p] = st;
     }

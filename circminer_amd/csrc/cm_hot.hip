@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -847,7 +848,7 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
 // (7 .. 48) fill whole waves of the light kernel with their like (they are sorted by cost): threshold 48 (16.7 vs 15.0 M pairs/s).
 // k_pair_cost adds up the cost beyond HEAVY_COST over the tile; k_pair_cls takes the wide threshold when that sum exceeds
 // HEAVY_LOAD per pair of the tile.  Results never depend on the split.
-constexpr int HEAVY_COST_WIDE = 48;
+constexpr int HEAVY_COST_WIDE = 16;
 constexpr unsigned long long HEAVY_LOAD = 16;
 __global__ void __launch_bounds__(BLK) k_pair_cost(const int32_t *nchain, const uint8_t *active, uint64_t pair0, uint32_t n_tile, int base_cost,
                                                   unsigned long long *sum) {
@@ -1524,6 +1525,23 @@ struct cm_ctx {
     // The pair stage of round r runs on its own pair of streams while `stream` / `stream2` already seed and chain round r + 1
     // (cm_map_rounds): seeds and chains are functions of (read, contig) only, the carried state enters in the pair stage.
     hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_p3 = nullptr;      // p3: the re-run launch of the pair stage (RetryArgs)
+    // The re-run launch of a pair stage (RetryArgs), decided late: see settle_pair.
+    struct Rerun {
+        bool deferred = false;
+        cmc::KCore core;
+        ReadsDev rd;
+        uint64_t p0 = 0;
+        uint32_t nt = 0;
+        cm_chain *chains = nullptr;
+        int32_t *nchain = nullptr, *high = nullptr;
+        uint8_t *act_out = nullptr;
+        int is_last = 0, cap2 = 0;
+        size_t lds2 = 0;
+        uint32_t *pair_err = nullptr, *retry_list = nullptr;
+        unsigned int *retry_ctr = nullptr;
+    } rerun[2];
+    hipStream_t stream_s = nullptr;           // seeding of the NEXT item, issued while the chain stage of this one runs (map_rounds_issue)
+    hipEvent_t ev_seed[2] = {nullptr, nullptr};       // seeds + cell offsets of a seed set are complete
     hipEvent_t ev_first[2] = {nullptr, nullptr};      // an item's two pair kernels are done (set b): its re-run may start
     hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
     bool pair_pending[2] = {false, false};
@@ -1564,6 +1582,13 @@ struct cm_ctx {
     uint32_t *d_sstart = nullptr, *d_scnt = nullptr, *d_sraw = nullptr, *d_cells = nullptr;
     unsigned long long *d_celloff = nullptr, *d_bsum = nullptr;
     unsigned int *d_bmax = nullptr;
+    // second seed set (SeedBufs): item i + 1 is seeded into it while the chain stage of item i reads the first, and vice versa
+    uint32_t *d_sstart_b = nullptr, *d_scnt_b = nullptr, *d_sraw_b = nullptr;
+    unsigned long long *d_celloff_b = nullptr, *d_bsum_b = nullptr;
+    unsigned int *d_bmax_b = nullptr;
+    unsigned int *d_cctr_b = nullptr, *d_cblk_b = nullptr;
+    int8_t *d_cls4_b = nullptr;
+    uint32_t *d_perm4_b = nullptr;
     double *d_dpscore = nullptr;
     int32_t *d_dpprev = nullptr;
     unsigned long long cells_cap = 0;
@@ -1667,6 +1692,8 @@ void free_reads(cm_ctx *c) {
     dfree(c->d_state); dfree(c->d_active); dfree(c->d_active_b); dfree(c->d_cat);
     dfree(c->d_chains_b); dfree(c->d_nchain_b); dfree(c->d_high_b); dfree(c->d_resid_b); dfree(c->d_cctr); dfree(c->d_cblk);
     dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum); dfree(c->d_bmax);
+    dfree(c->d_sstart_b); dfree(c->d_scnt_b); dfree(c->d_sraw_b); dfree(c->d_celloff_b); dfree(c->d_bsum_b); dfree(c->d_bmax_b);
+    dfree(c->d_cctr_b); dfree(c->d_cblk_b); dfree(c->d_cls4_b); dfree(c->d_perm4_b);
     dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
     dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
     dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist); dfree(c->d_retry_ctr); dfree(c->d_heavy_load);
@@ -1736,42 +1763,99 @@ RoundBufs round_bufs(cm_ctx *c, int b) {
 
 ReadsDev current_reads(const cm_ctx *ctx) { return ReadsDev{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2}; }
 
-int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const uint8_t *act) {
+// What the seeding of a tile leaves for its chain stage: the seed ranges of every probe, the DP-cell offsets of every chaining
+// problem (+ total and largest problem, also copied to h_pin[8 + 2 s ..]).  Two sets: see map_rounds_issue.
+// The work classes of the tile's chaining problems and their sorted list (k_chain_cls + counting sort), the zeroed cursors of the
+// chain kernels (improvement-log pool, heavy work list) -- everything the chain kernels need but the chain records themselves.
+struct SeedBufs {
+    uint32_t *sstart, *scnt, *sraw;
+    unsigned long long *celloff, *bsum;
+    unsigned int *bmax;
+    int8_t *cls4;
+    unsigned int *cblk, *cctr;
+    uint32_t *perm4;
+    unsigned long long *pool_cursor;
+};
+SeedBufs seed_bufs(cm_ctx *c, int s) {
+    return s ? SeedBufs{c->d_sstart_b, c->d_scnt_b, c->d_sraw_b, c->d_celloff_b, c->d_bsum_b, c->d_bmax_b, c->d_cls4_b, c->d_cblk_b, c->d_cctr_b, c->d_perm4_b,
+                        c->d_pool_cursor + 1}
+             : SeedBufs{c->d_sstart, c->d_scnt, c->d_sraw, c->d_celloff, c->d_bsum, c->d_bmax, c->d_cls4, c->d_cblk, c->d_cctr, c->d_perm4, c->d_pool_cursor};
+}
+static unsigned long long chain_light_w() {
+    static const unsigned long long v = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 256ull;
+    return v;
+}
+static unsigned int chain_light_cells() {
+    static const unsigned int v = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 96u;
+    return v;
+}
+
+// seeds of one tile into seed set s, on stream st: k_seed, the scan of the problems' DP cells, the two totals to the host; with
+// rb (the chain records the tile's chain stage will fill: their per-problem counters are initialised here) also the work
+// classes + sorted lists of the chaining problems and the zeroed cursors.  ev_seed[s] is recorded behind them.
+int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st,
+                  const RoundBufs *rb) {
     const int S = ctx->n_seeds;
     const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
     if (total == 0) return CM_OK;
-    Timer t(ctx, 0);
-    hipLaunchKernelGGL(k_seed, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, core, rd, act, pair0, n_tile, S,
-                       ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_counters);
-    ++ctx->launches[0];
+    const SeedBufs sb = seed_bufs(ctx, s);
+    {
+        Timer t(ctx, 0, st);
+        hipLaunchKernelGGL(k_seed, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, st, core, rd, act, pair0, n_tile, S,
+                           sb.sstart, sb.scnt, sb.sraw, ctx->d_counters);
+        ++ctx->launches[0];
+    }
+    const uint32_t n_prob = n_tile * 4u;
+    {
+        Timer t(ctx, 3, st);
+        const uint32_t nb = (n_prob + SCAN_ELEMS - 1) / SCAN_ELEMS;
+        hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(SCAN_T), 0, st, sb.scnt, S, n_prob, sb.celloff, sb.bsum, sb.bmax);
+        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, st, sb.bsum, nb, sb.celloff + n_prob, (const unsigned int *)sb.bmax);
+        hipLaunchKernelGGL(k_scan_c, dim3((n_prob + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, st, sb.celloff, sb.bsum, n_prob);
+        ctx->launches[3] += 3;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 8 + 2 * s, sb.celloff + n_prob, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (rb) {
+        // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy), heaviest class
+        // first.  (Used by run_chain_tile when it takes the split path; computed here because these five small launches, queued
+        // behind the persistent pair kernels of the previous item, took 6 ms of the chain stage's critical path.)
+        Timer t(ctx, 5, st);
+        const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
+        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, rb->high,
+                           chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
+                           (const unsigned int *)nullptr);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
+                           (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
+        ctx->launches[5] += 4;
+        HIPCHK(ctx, hipMemsetAsync(sb.pool_cursor, 0, sizeof(unsigned long long), st));
+        HIPCHK(ctx, hipMemsetAsync(sb.cctr + 48, 0, sizeof(unsigned int), st));       // spare word of the class counters: work cursor of k_chain_heavy
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_seed[s], st));
     HIPCHK(ctx, hipGetLastError());
     return CM_OK;
 }
 
+// chains of one tile from seed set s (run_seed_tile) into the chain records rb.  `after_launch` (may be empty) is called once, when
+// the chain kernels of the tile have been launched and before the host waits for them.
 int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, bool parallel_ok, const uint8_t *act,
-                   const RoundBufs &rb) {
+                   const RoundBufs &rb, int s, const std::function<int()> &after_launch = {}) {
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
-    if (n_prob == 0 || S == 0) return CM_OK;
-    {
-        Timer t(ctx, 3);
-        const uint32_t nb = (n_prob + SCAN_ELEMS - 1) / SCAN_ELEMS;
-        hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(SCAN_T), 0, ctx->stream, ctx->d_scnt, S, n_prob, ctx->d_celloff, ctx->d_bsum, ctx->d_bmax);
-        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_bsum, nb, ctx->d_celloff + n_prob, (const unsigned int *)ctx->d_bmax);
-        hipLaunchKernelGGL(k_scan_c, dim3((n_prob + SCAN_T - 1) / SCAN_T), dim3(SCAN_T), 0, ctx->stream, ctx->d_celloff, ctx->d_bsum, n_prob);
-        ctx->launches[3] += 3;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_celloff + n_prob, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long total = ctx->h_pin[0];
-    const unsigned long long max_cells = ctx->h_pin[1];       // of one problem
+    if (n_prob == 0 || S == 0) return after_launch ? after_launch() : CM_OK;
+    const SeedBufs sb = seed_bufs(ctx, s);
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_seed[s], 0));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_seed[s]));
+    const unsigned long long total = ctx->h_pin[8 + 2 * s];
+    const unsigned long long max_cells = ctx->h_pin[9 + 2 * s];       // of one problem
     // problem ranges whose DP cells fit the workspace
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
     if (total <= ctx->cells_cap) {
         ranges.push_back({0u, n_prob});
     } else {
         ctx->h_celloff.resize((size_t)n_prob + 1);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_celloff.data(), ctx->d_celloff, ((size_t)n_prob + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_celloff.data(), sb.celloff, ((size_t)n_prob + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                    ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t a = 0;
@@ -1784,36 +1868,25 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
             a = b;
         }
     }
-    // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy),
-    // heaviest class first.  CM_CHAIN_SPLIT=0 keeps everything on the sequential kernel.
+    // CM_CHAIN_SPLIT=0 keeps everything on the sequential kernel (the class lists of run_seed_tile go unused).
     static const char *split_env = getenv("CM_CHAIN_SPLIT");
-    static const unsigned long long light_w = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 256ull;
-    static const unsigned int light_cells = getenv("CM_CHAIN_LIGHT_CELLS") ? (unsigned)atoi(getenv("CM_CHAIN_LIGHT_CELLS")) : 96u;
     // k_chain_heavy keeps a problem's hit positions in LDS: sized for the largest problem of this tile (a multiple of 2 KB, so
     // that launches of similar tiles share a configuration), not for the n_seeds x seed_lim a problem could have in theory --
     // the kernel waits on memory most of the time and the LDS request decides how many waves a CU holds.
     const size_t heavy_lds = std::min<size_t>((size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t),
                                               ((size_t)max_cells * sizeof(uint32_t) + 2047) / 2048 * 2048 + 2048);
     const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;
-    if (split) {
-        Timer t(ctx, 5);
-        const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
-        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, ctx->d_scnt, ctx->d_sraw, S, n_prob, ctx->d_cls4, rb.high,
-                           light_w, light_cells, rb.nchain, rb.resid, act, pair0);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_cblk, nbk, (const uint32_t *)nullptr,
-                           (const unsigned int *)nullptr);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cblk, nbk, ctx->d_cctr, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_cls4, n_prob, ctx->d_cblk, nbk, ctx->d_cctr, ctx->d_perm4,
-                           (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
-        ctx->launches[5] += 4;
-    }
+    bool fresh = true;            // the cursors are still as run_seed_tile zeroed them
     // one launch group over problems [a, b) whose DP cells start at `base`: the improvement log of every problem comes out of the
     // shared pool, whose cursor starts at 0 for every group
     auto launch_group = [&](uint32_t a, uint32_t b, unsigned long long base, bool use_split) -> int {
         const uint32_t n = b - a;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
+        if (!fresh) {
+            HIPCHK(ctx, hipMemsetAsync(sb.pool_cursor, 0, sizeof(unsigned long long), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(sb.cctr + 48, 0, sizeof(unsigned int), ctx->stream));       // spare word of the class counters: work cursor
+        }
+        fresh = false;
         if (use_split) {          // the few long problems run on the second stream, concurrently with the bulk
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_cctr + 48, 0, sizeof(unsigned int), ctx->stream));       // spare word of the class counters: work cursor
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             {
@@ -1822,9 +1895,9 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
             const uint32_t hb = n < 8192u ? n : 8192u;
             static const size_t heavy_pad = getenv("CM_CHEAVY_LDS_PAD") ? (size_t)atoi(getenv("CM_CHEAVY_LDS_PAD")) : 0;     // occupancy experiment
-            hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, ctx->d_sstart, ctx->d_scnt, ctx->d_celloff,
-                               ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, ctx->d_err,
-                               rb.resid, ctx->d_perm4, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + 48, ctx->d_counters);
+            hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, sb.sstart, sb.scnt, sb.celloff,
+                               ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool, ctx->pool_bytes, sb.pool_cursor, rb.chains, rb.nchain, ctx->d_err,
+                               rb.resid, sb.perm4, sb.cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, sb.cctr + 48, ctx->d_counters);
             ++ctx->launches[6];
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -1832,9 +1905,9 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
         Timer t(ctx, 1);
         static const size_t light_pad = getenv("CM_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("CM_CHAIN_LDS_PAD")) : 0;       // occupancy experiment
         hipLaunchKernelGGL(k_chain, dim3((n + BLK_CHAIN - 1) / BLK_CHAIN), dim3(BLK_CHAIN), light_pad, ctx->stream, core, rd, act, pair0, a, b, S,
-                           ctx->d_sstart, ctx->d_scnt, ctx->d_sraw, ctx->d_celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
-                           ctx->pool_bytes, ctx->d_pool_cursor, rb.chains, rb.nchain, rb.high, ctx->d_err, rb.resid,
-                           use_split ? ctx->d_perm4 : (const uint32_t *)nullptr, ctx->d_cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, ctx->d_cctr + CTR_SUM);
+                           sb.sstart, sb.scnt, sb.sraw, sb.celloff, base, ctx->d_dpscore, ctx->d_dpprev, ctx->d_pool,
+                           ctx->pool_bytes, sb.pool_cursor, rb.chains, rb.nchain, rb.high, ctx->d_err, rb.resid,
+                           use_split ? sb.perm4 : (const uint32_t *)nullptr, sb.cctr + CTR_BASE + CHAIN_LIGHT_CLS - 1, sb.cctr + CTR_SUM);
         if (use_split) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));       // timed with the light kernel: the stage ends here
         ++ctx->launches[1];
         HIPCHK(ctx, hipGetLastError());
@@ -1853,11 +1926,14 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
         return CM_OK;
     };
     const unsigned long long pool_max = getenv("CM_POOL_MAX") ? strtoull(getenv("CM_POOL_MAX"), nullptr, 10) : (48ull << 30);
+    bool told = false;
     for (auto &rg : ranges) {
         unsigned long long base = 0;
         if (rg.first != 0) base = ctx->h_celloff[rg.first];
         int rc = launch_group(rg.first, rg.second, base, split);
         if (rc) return rc;
+        if (!told && after_launch && (rc = after_launch())) return rc;
+        told = true;
         bool lost = false;
         if ((rc = pool_lost(&lost))) return rc;
         // The reference's score2chain has no capacity limit.  When the log pool ran out: first a larger pool (x4 up to pool_max)
@@ -1937,6 +2013,9 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p3, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_seed[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_seed[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_first[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_first[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork_p, hipEventDisableTiming) != hipSuccess ||
@@ -1953,14 +2032,14 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         delete ctx;
         return CM_EHIP;
     }
-    if (hipMalloc((void **)&ctx->d_pool_cursor, sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&ctx->d_pool_cursor, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_pin, 64, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_pin, 128, hipHostMallocDefault) != hipSuccess) {
         delete ctx;
         return CM_ENOMEM;
     }
-    memset(ctx->h_pin, 0, 64);
+    memset(ctx->h_pin, 0, 128);
     (void)hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream);
     (void)hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), ctx->stream);
     if (getenv("CM_ONE_STREAM")) {           // diagnostic: no concurrency between the light and the heavy kernels
@@ -1979,6 +2058,7 @@ void cm_destroy(cm_ctx *ctx) {
     if (ctx->stream_p) (void)hipStreamSynchronize(ctx->stream_p);
     if (ctx->stream_p2) (void)hipStreamSynchronize(ctx->stream_p2);
     if (ctx->stream_p3) (void)hipStreamSynchronize(ctx->stream_p3);
+    if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
     for (auto e : ctx->ev_free) (void)hipEventDestroy(e);
     ctx->ev_free.clear();
     for (auto &r : ctx->recs) {
@@ -2003,6 +2083,9 @@ void cm_destroy(cm_ctx *ctx) {
                          ctx->ev_first[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream_p3) (void)hipStreamDestroy(ctx->stream_p3);
+    if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
+    for (hipEvent_t e : {ctx->ev_seed[0], ctx->ev_seed[1]})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream_p) (void)hipStreamDestroy(ctx->stream_p);
     if (ctx->stream_p2) (void)hipStreamDestroy(ctx->stream_p2);
     if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
@@ -2263,6 +2346,12 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_celloff, (nprob + 2) * 8));
     HIPCHK(ctx, ensure(ctx, ctx->d_bmax, (nprob / SCAN_ELEMS + 2) * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_bsum, (nprob / SCAN_ELEMS + 2) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_sstart_b, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_scnt_b, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_sraw_b, nprobe * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_celloff_b, (nprob + 2) * 8));
+    HIPCHK(ctx, ensure(ctx, ctx->d_bmax_b, (nprob / SCAN_ELEMS + 2) * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_bsum_b, (nprob / SCAN_ELEMS + 2) * 8));
     // DP cells: room for 64 cells per problem on average, at least 8M (one worst-case problem is
     // n_seeds * seed_lim cells); larger tiles are split into ranges by run_chain_tile.
     unsigned long long cap = (unsigned long long)nprob * 64ull;
@@ -2284,6 +2373,10 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_cls, (size_t)tile));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls4, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm4, (size_t)tile * 4 * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cctr_b, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cblk_b, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls4_b, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm4_b, (size_t)tile * 4 * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
@@ -2441,14 +2534,50 @@ int cm_reads_swap(cm_ctx *ctx) {
     return CM_OK;
 }
 
+// The re-run launch of a pair stage and ev_pair[b] behind it.  Eight blocks that each ask for 47 - 64 KB of LDS behind kernels that
+// fill the chip wait milliseconds for their turn -- on the hg38-like bench until the heavy chaining kernel of the NEXT item had
+// drained, and the item after that (its seeding reads the flags, its chaining rewrites the chain records) behind them -- to find,
+// nearly always, an empty list.  So with several tiles the decision is made late (`defer`): the pair stage copies the length of
+// its re-run list to the host, and whoever first needs the stage to be complete calls settle_pair, which waits for the two pair
+// kernels (ev_first[b]), launches the re-run only if something is queued, and records ev_pair[b].
+static int launch_rerun(cm_ctx *ctx, int b) {
+    const cm_ctx::Rerun &q = ctx->rerun[b];
+    static const bool no_rerun = getenv("CM_NO_RERUN") != nullptr;      // diagnostic: what the launch costs (a queued pair would stay unmapped)
+    if (no_rerun) return CM_OK;
+    const RetryArgs ra2{q.pair_err, q.retry_list, q.retry_ctr, ctx->d_spill, RETRY_SPILL, 0};
+    hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), q.lds2, ctx->stream_p3, q.core, q.rd, q.p0, q.nt, q.chains, q.nchain, q.high,
+                       ctx->d_state, q.act_out, ctx->d_cat, q.is_last, ctx->d_err, ctx->d_counters, q.cap2, (unsigned long long *)nullptr,
+                       (const uint32_t *)q.retry_list, (const unsigned int *)q.retry_ctr, q.retry_ctr + 1, ra2);
+    HIPCHK(ctx, hipGetLastError());
+    return CM_OK;
+}
+// wait = false: without blocking the host (the end of cm_map_rounds, which stays asynchronous): the re-run is launched whatever the count
+static int settle_pair(cm_ctx *ctx, int b, bool wait = true) {
+    if (!ctx->rerun[b].deferred) return CM_OK;
+    ctx->rerun[b].deferred = false;
+    if (wait) HIPCHK(ctx, hipEventSynchronize(ctx->ev_first[b]));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p3, ctx->ev_first[b], 0));
+    if (!wait || *(const volatile unsigned int *)(ctx->h_pin + 12 + b) != 0u) {
+        const int rc = launch_rerun(ctx, b);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], ctx->stream_p3));
+    return CM_OK;
+}
+
 // The pair stage of one tile and round on the pair streams: waits for that item's chains (ev_prep[b]), reads the flags
 // act_in, writes act_out for every pair of the tile, signals ev_pair[b] when the chain buffers of set b are free again.
 // same_tile_as_prev: the previous item was this tile's previous round -- its re-run launch (stream p3) wrote states and flags this
 // item's pair kernels read; every other consumer is ordered behind the re-run through ev_pair[].
 static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t nt, int is_last_round, const uint8_t *act_in, uint8_t *act_out,
-                         const RoundBufs &rb, int b, bool same_tile_as_prev) {
+                         const RoundBufs &rb, int b, bool same_tile_as_prev, bool defer) {
     const ReadsDev rd{ctx->d_seq1, ctx->d_seq2, ctx->d_off1, ctx->d_off2};
     hipStream_t sp = ctx->stream_p, sp2 = ctx->stream_p2, sp3 = ctx->stream_p3;
+    {
+        int rc;
+        if ((rc = settle_pair(ctx, b))) return rc;                       // this set's previous stage (its re-run list is about to be reused)
+        if (same_tile_as_prev && (rc = settle_pair(ctx, b ^ 1))) return rc;
+    }
     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
     if (same_tile_as_prev && ctx->pair_pending[b ^ 1]) HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pair[b ^ 1], 0));
     // (the re-run list, its counters and the per-pair flags exist once per set of chain records, like those: item i + 1 leaves
@@ -2560,16 +2689,22 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     // batch can produce.  On a stream of its own: a launch of 8 blocks behind kernels that fill the chip can wait milliseconds
     // for its turn (2.5 ms on average on the hg38-like bench), and only the consumers of this item's results have to wait for
     // it -- ev_pair[b] (chain records of set b free, flags and states of the tile final) is recorded behind it.
+    HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 12 + b), retry_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, sp));
     HIPCHK(ctx, hipEventRecord(ctx->ev_first[b], sp));
-    HIPCHK(ctx, hipStreamWaitEvent(sp3, ctx->ev_first[b], 0));
-    static const bool no_rerun = getenv("CM_NO_RERUN") != nullptr;      // diagnostic: what the launch costs (a queued pair would stay unmapped)
-    if (!no_rerun) {
-        const RetryArgs ra2{pair_err, retry_list, retry_ctr, ctx->d_spill, RETRY_SPILL, 0};
-        hipLaunchKernelGGL(k_pair_rerun, dim3(RETRY_GRID), dim3(BLK_PAIR), lds2, sp3, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
-                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, cap2, (unsigned long long *)nullptr,
-                           (const uint32_t *)retry_list, (const unsigned int *)retry_ctr, retry_ctr + 1, ra2);
+    {
+        cm_ctx::Rerun &q = ctx->rerun[b];
+        q.core = core; q.rd = rd; q.p0 = p0; q.nt = nt;
+        q.chains = rb.chains; q.nchain = rb.nchain; q.high = rb.high;
+        q.act_out = act_out; q.is_last = is_last_round; q.cap2 = cap2; q.lds2 = lds2;
+        q.pair_err = pair_err; q.retry_list = retry_list; q.retry_ctr = retry_ctr;
+        q.deferred = defer;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp3));
+    if (!defer) {
+        HIPCHK(ctx, hipStreamWaitEvent(sp3, ctx->ev_first[b], 0));
+        int rc;
+        if ((rc = launch_rerun(ctx, b))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pair[b], sp3));
+    }
     ctx->pair_pending[b] = true;
     HIPCHK(ctx, hipGetLastError());
     return CM_OK;
@@ -2583,6 +2718,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // everything queued on the main stream so far (uploads, resets, collects of the previous batch) comes first
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_tail, 0));
     uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
     // The work items: (tile, round).  One tile per batch: its rounds in order.  Several tiles: ROUND-major -- every tile through
     // round r, then every tile through round r + 1 -- so that between the pair stage of (tile, r) and the seeding of (tile, r + 1)
@@ -2610,6 +2746,34 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     ctx->pre_ready = ctx->pre_launched = false;            // the items below reuse both sets of chain records
     if (use_pre) ++ctx->launches[7];
     const ReadsDev rd_cur = current_reads(ctx);
+    // Seeds and chains of round r depend on the reads and the contig only; the flags merely skip pairs that are retired.
+    // Round-major: A[r & 1], what the pair stage of (tile, r - 1) wrote -- item i - n_tiles, complete before item i - 2, for
+    // which this item waits anyway (it reuses its chain records).  One tile: the pair stage of round r - 1 is still writing
+    // A[r & 1], so the flags from before it (pairs it retires get chains nobody looks at).
+    auto prep_flags = [&](int i) -> const uint8_t * {
+        const int r = items[i].r;
+        return round_major ? A[r & 1] : ((r == 0) ? A[0] : A[(r - 1) & 1]);
+    };
+    // Seeding runs one item ahead of chaining.  The chain stage of an item ends with a long tail of a few heavy problems, one
+    // wave each, and the host waits for it (the pair stage must not start on truncated improvement logs); seeding of the next
+    // item used to start after that wait, with the chip nearly idle through the tail and the next chain stage waiting for the
+    // seeds.  Now seeding of item i + 1 is issued (stream_s, seed set (i + 1) & 1) as soon as the chain kernels of item i are
+    // launched: it needs the flags of the pair stage of item i - 1 (two tiles; earlier with more), which ends during that chain
+    // stage, so the seeds are computed under the tail and the next chain stage starts right behind this one.
+    static const bool seed_ahead = !(getenv("CM_SEED_AHEAD") && getenv("CM_SEED_AHEAD")[0] == '0');       // diagnostic: the round-3a order
+    std::vector<char> seeded((size_t)n_items, 0);
+    auto issue_seed = [&](int i, hipStream_t st) -> int {
+        const int b = (ctx->item_base + i) & 1;
+        // flags (and, for the chain stage behind it, the chain records of set b) are final once that pair stage is done; the main
+        // stream queues the same wait before the chain stage and clears the mark
+        int e;
+        if ((e = settle_pair(ctx, b))) return e;
+        if (ctx->pair_pending[b]) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_pair[b], 0));
+        const RoundBufs rbi = round_bufs(ctx, b);
+        e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
+        seeded[(size_t)i] = 1;
+        return e;
+    };
     for (int i = 0; i < n_items; ++i) {
         const uint64_t p0 = items[i].p0;
         const uint32_t nt = items[i].nt;
@@ -2617,35 +2781,39 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         const Slot &sl = ctx->slots[slots[r]];
         const KCore core = make_core(ctx, sl);
         const RoundBufs rb = round_bufs(ctx, b);
-        // Seeds and chains of round r depend on the reads and the contig only; the flags merely skip pairs that are retired.
-        // Round-major: A[r & 1], what the pair stage of (tile, r - 1) wrote -- item i - n_tiles, complete before item i - 2, for
-        // which this item waits anyway (it reuses its chain records).  One tile: the pair stage of round r - 1 is still writing
-        // A[r & 1], so the flags from before it (pairs it retires get chains nobody looks at).
-        const uint8_t *act_prep = round_major ? A[r & 1] : ((r == 0) ? A[0] : A[(r - 1) & 1]);
-        if (!(use_pre && i == 0)) {                                       // else: set b holds this item's chains, ev_prep[b] is recorded
+        const uint8_t *act_prep = prep_flags(i);
+        auto ahead = [&]() -> int { return (seed_ahead && i + 1 < n_items) ? issue_seed(i + 1, ctx->stream_s) : CM_OK; };
+        if (use_pre && i == 0) {                                          // set b holds this item's chains, ev_prep[b] is recorded
+            if ((rc = ahead())) return bail(rc);
+        } else {
+            if (!seeded[(size_t)i] && (rc = issue_seed(i, ctx->stream))) return bail(rc);
+            if ((rc = settle_pair(ctx, b))) return bail(rc);
             if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
                 ctx->pair_pending[b] = false;
             }
-            if ((rc = run_seed_tile(ctx, core, rd_cur, p0, nt, act_prep))) return bail(rc);
             // CM_CHAIN_EXACT=1 (diagnostic, one tile): the chain kernels wait for the pair stage of round r - 1 and use its output
             // flags (chain kernels 8.4 -> 6.7 ms per step, step 24.0 -> 25.1 ms: the wait costs more than the work it saves)
             static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
             const bool wait_exact = exact_flags && !round_major && r > 0;
+            if (wait_exact && (rc = settle_pair(ctx, b ^ 1))) return bail(rc);
             if (wait_exact && ctx->pair_pending[b ^ 1]) {                 // item - 1 = the same tile's round r - 1
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
                 ctx->pair_pending[b ^ 1] = false;
             }
-            if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, wait_exact ? A[r & 1] : act_prep, rb))) return bail(rc);
+            if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, wait_exact ? A[r & 1] : act_prep, rb, i & 1, ahead))) return bail(rc);
             HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         }
         const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
         const bool same_tile = i > 0 && items[i - 1].p0 == p0;
-        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile))) return bail(rc);
+        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile, round_major))) return bail(rc);
         ++*items_done;
         if (++tiles_of_round[(size_t)r] == (int)n_tiles) ++*rounds_done;
         static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
-        if (no_overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+        if (no_overlap) {
+            if ((rc = settle_pair(ctx, b))) return bail(rc);
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
+        }
     }
     ctx->item_base = (ctx->item_base + n_items) & 1;
     *items_done = 0;                                   // accounted for
@@ -2667,13 +2835,15 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
             ctx->ones_cap = ctx->n_pairs;
         }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
+        if ((rc = settle_pair(ctx, b))) return bail(rc);
         if (ctx->pair_pending[b]) {
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
             ctx->pair_pending[b] = false;
         }
+        const RoundBufs rbn = round_bufs(ctx, b);
         const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
-        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones))) return bail(rc);
-        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, round_bufs(ctx, b)))) return bail(rc);
+        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return bail(rc);
+        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, rbn, n_items & 1))) return bail(rc);
         HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         ctx->pre_launched = true;
         ctx->pre_slot = slots[0];
@@ -2682,6 +2852,8 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         ctx->pre_nt = nt;
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
+    // (set item_base ^ 1 = the last item's goes second: stream p3's last entry then waits for stream p's last)
+    if ((rc = settle_pair(ctx, ctx->item_base, false)) || (rc = settle_pair(ctx, ctx->item_base ^ 1, false))) return bail(rc);
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p3));               // (p3's last launch waits for p's last)
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;                     // covered by the wait above
@@ -2709,6 +2881,8 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     (void)hipStreamSynchronize(ctx->stream_p);
     (void)hipStreamSynchronize(ctx->stream_p2);
     (void)hipStreamSynchronize(ctx->stream_p3);
+    (void)hipStreamSynchronize(ctx->stream_s);
+    ctx->rerun[0].deferred = ctx->rerun[1].deferred = false;
     ctx->item_base = (ctx->item_base + items_done) & 1;
     if (rounds_done & 1) std::swap(ctx->d_active, ctx->d_active_b);
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;
@@ -2925,7 +3099,7 @@ int cm_seed_batch(cm_ctx *ctx, int slot, uint32_t *out_start, uint32_t *out_cnt,
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active))) return rc;
+        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active, 0, ctx->stream, nullptr))) return rc;
         const size_t cnt = (size_t)nt * 4 * ctx->n_seeds, o = (size_t)p0 * 4 * ctx->n_seeds;
         HIPCHK(ctx, hipMemcpyAsync(out_start + o, ctx->d_sstart, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(out_cnt + o, ctx->d_scnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2943,9 +3117,10 @@ int cm_chain_batch(cm_ctx *ctx, int slot, cm_chain *out_chains, int32_t *out_nch
     const KCore core = make_core(ctx, ctx->slots[slot]);
     for (uint64_t p0 = 0; p0 < ctx->n_pairs; p0 += ctx->tile) {
         const uint32_t nt = (uint32_t)((ctx->n_pairs - p0 < ctx->tile) ? ctx->n_pairs - p0 : ctx->tile);
-        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_chains, 0, (size_t)nt * 4 * CM_BESTCHAINLIM * sizeof(cm_chain), ctx->stream));
-        if ((rc = run_chain_tile(ctx, core, current_reads(ctx), p0, nt, ctx->slots[slot].chain_parallel_ok, ctx->d_active, round_bufs(ctx, 0)))) return rc;
+        const RoundBufs rb0 = round_bufs(ctx, 0);
+        if ((rc = run_seed_tile(ctx, core, current_reads(ctx), p0, nt, ctx->d_active, 0, ctx->stream, &rb0))) return rc;
+        if ((rc = run_chain_tile(ctx, core, current_reads(ctx), p0, nt, ctx->slots[slot].chain_parallel_ok, ctx->d_active, rb0, 0))) return rc;
         const size_t np = (size_t)nt * 4, o = (size_t)p0 * 4;
         HIPCHK(ctx, hipMemcpyAsync(out_chains + o * CM_BESTCHAINLIM, ctx->d_chains, np * CM_BESTCHAINLIM * sizeof(cm_chain), hipMemcpyDeviceToHost,
                                    ctx->stream));

@@ -1013,7 +1013,7 @@ struct HRes {            // outcome of one mate-pair task, handed from the compu
 // accepted mate pairs, unpaired chains of all HG pairs, one item per lane -- and lane g < HG (the "owner" of slot g) keeps pair g's
 // MatchedRead and folds its outcomes in the reference's order.  What a lane needs of a pair it reads from the pair's slot in LDS.
 #ifndef CM_HEAVY_G
-#define CM_HEAVY_G 8
+#define CM_HEAVY_G 6            // 4 / 6 / 8 / 16: 89.3 / 85.9 / 89.4 / 96 ms per step on the hg38-like bench (33 tasks per 64-lane batch at 6)
 #endif
 constexpr int HG = CM_HEAVY_G;
 static_assert(HG >= 1 && HG <= 16, "the task list packs the slot in 4 bits");

@@ -764,13 +764,13 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
 // ---- light / heavy split of the pair stage -------------------------------------------------
 // A pair whose chain lists can produce many mate pairs and unpaired-chain extensions (reads from
 // repeats: up to 30 x 30 pairs plus 60 full-length extensions) costs 100x the median pair; as one lane
-// it would hold its whole wave for milliseconds.  Such pairs are listed by k_classify and mapped one
-// per *wave* by k_pair_heavy (64 lanes share the pairing predicate, the mate-pair extensions and the
-// unpaired-chain extensions; lane 0 folds the outcomes in the reference's order).  Everything else
-// stays one pair per lane in k_pair.
+// it would hold its whole wave for milliseconds.  Such pairs are listed by k_classify and mapped a
+// few per *wave* by k_pair_heavy (the 64 lanes share the pairing predicates, the mate-pair extensions and
+// the unpaired-chain extensions of HG pairs; an owner lane per pair folds the outcomes in the reference's
+// order).  Everything else stays one pair per lane in k_pair.
 constexpr int HEAVY_COST = 6;             // hg38-like bench, ms per step at 3 / 4 / 5 / 6 / 8 / 12 / 16: 32.1 / 31.3 / 26.5 / 26.6 / 28.0 / 30.1 / 31.7
 constexpr int N_BUCKETS = 7;             // residual-length buckets
-constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_heavy (one wave each)
+constexpr int HEAVY_CLS = 15;            // class of the pairs mapped by k_pair_heavy
 // class of a pair for the pair stage: -2 inactive, HEAVY_CLS heavy (k_pair_heavy), else
 // (genic ? 7 : 0) + bucket of the total residual length of its best chains (bases left to extend).
 // genic: some best chain starts inside an annotated exon, i.e. the pair will walk transcripts during extension
@@ -842,10 +842,12 @@ __device__ inline void block_class_ranks(int k, unsigned int (*wcnt)[N_CLS], uns
 }
 // Where the light / heavy line of the pair stage goes depends on how much heavy work a tile holds.  The two pair kernels run side
 // by side and the stage ends with the later one.  With little heavy work (chr21, the round-2 genome: a few percent of the pairs
-// come from repeats) the heavy kernel is done long before the light one, and every multi-chain pair is best given a wave of its
-// own (threshold 6: 95 vs 57 M pairs/s on chr21 against 48).  On the section-8(d) genome a sixth of the pairs are heavy, most of
-// them with 30 x 30 chain pairs; the heavy kernel is the long pole, the light kernel has slack, and the many mid-cost pairs
-// (7 .. 48) fill whole waves of the light kernel with their like (they are sorted by cost): threshold 48 (16.7 vs 15.0 M pairs/s).
+// come from repeats) the heavy kernel is done long before the light one, and every multi-chain pair is best taken off the light
+// kernel's waves (threshold 6: 95 vs 57 M pairs/s on chr21 against 48).  On the section-8(d) genome a sixth of the pairs are heavy,
+// most of them with 30 x 30 chain pairs; the heavy kernel is the long pole and the light kernel has slack.  With one pair per wave
+// in the heavy kernel the mid-cost pairs (7 .. 48) were best left to the light kernel (threshold 48: 16.7 vs 15.0 M pairs/s);
+// with several pairs per wave (HG) the heavy kernel is the more efficient place for a pair with a dozen chain pairs, and the
+// wide threshold is 16 (92.1 ms per step against 95.5 at 48 and 92.7 at 6).
 // k_pair_cost adds up the cost beyond HEAVY_COST over the tile; k_pair_cls takes the wide threshold when that sum exceeds
 // HEAVY_LOAD per pair of the tile.  Results never depend on the split.
 constexpr int HEAVY_COST_WIDE = 16;

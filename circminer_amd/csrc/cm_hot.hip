@@ -381,6 +381,7 @@ struct HeavyChainCtx {
 #endif
     const Core *c;
     CM_L const uint32_t *LP;     // hit positions of every slot, concatenated (LDS)
+    CM_L const uint32_t *NB;     // near-border bit of every cell of the slots that are evaluated (LDS bitmask, see k_chain_heavy)
     const uint32_t *base, *cnt;  // per slot (uniform)
     int kc, seq_len;
     CM_G double *dps;
@@ -399,9 +400,16 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
     double my_score = (double)kmer;
     int32_t my_prev = -1;
     uint32_t n = 0;
-    // the near-border bit of this hit (one random 8-byte read out of a 130-MB bitset: an HBM round trip) is asked for now and
-    // needed only after the first binary search: nearly every cell of a heavy problem gets that far
-    const bool near = cmc::bit_at(c.A.near_border_bits, c.A.n_bits, seg_start);
+    // cmc::upper_bound of a hit near an exon border was resolved before the DP (k_chain_heavy) and parked in the cell's own score /
+    // back-pointer slots, which nothing reads before this cell has been evaluated; asked for now, needed after the first binary search
+    const uint32_t cell = h.base[ii] + i;
+    const bool near = (h.NB[cell >> 5] >> (cell & 31)) & 1u;
+    uint2 parked = make_uint2(0u, 0u);
+    int parked_ol = -1;
+    if (near) {
+        parked = *(CM_G const uint2 *)(h.dps + cell);
+        parked_ol = h.dpp[cell];
+    }
 #if defined(CM_CHAIN_DIAG)
     if (!ev) h.tk[3] += 1;
 #define CD_T0 const unsigned long long cd_t = wall_clock64()
@@ -428,8 +436,11 @@ __device__ inline uint32_t heavy_cell(const HeavyChainCtx &h, int ii, uint32_t i
         if (cur_info + c.P.max_intron < (int32_t)pp[lo]) continue;      // nothing within maxIntronLen
         if (max_lpos_lim == cmc::MAXUB) {           // cmc::upper_bound with its bit test hoisted (see `near`)
             CD_T0;
-            if (near) max_lpos_lim = cmc::upper_bound_lookup(c, seg_start, (uint32_t)kmer, read_remain, max_exon_end, ol);
-            else {
+            if (near) {
+                max_lpos_lim = parked.x;
+                max_exon_end = parked.y;
+                ol = parked_ol;
+            } else {
                 max_exon_end = 0;
                 ol = -1;
                 max_lpos_lim = seg_start + read_remain + (uint32_t)c.P.max_ed;
@@ -532,15 +543,61 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
         }
         __threadfence_block();
         __syncthreads();
+        // cmc::upper_bound of every hit the DP will evaluate (slots 0 .. kc - 2), ahead of the DP.  One hit in seven lies near an exon
+        // border (60 k genes) and needs the annotation look-up, four or five dependent loads; inside the DP every batch of 64 cells
+        // waited for its few such lanes (51 % of the DP's lane time, DESIGN note 30).  Here the near-border bits of all hits are read
+        // first (one load each, every lane busy; they stay in LDS as a bitmask), the near hits are queued, and the look-ups run 64 to
+        // a batch; the results are parked in the cells' own score / back-pointer slots (see heavy_cell).
+        CM_L uint32_t *NB = LP + ncell;
+        CM_L uint16_t *Q = (CM_L uint16_t *)(NB + 2 * ((ncell + 63) >> 6));
+        {
+            const uint32_t n_pre = kc >= 1 ? base[kc - 1] : 0u;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t qn = 0;
+            auto look_up = [&](uint32_t cnt) {
+                if ((uint32_t)lane < cnt) {
+                    const uint32_t x = Q[lane];
+                    int ii = 0;
+                    for (int s = 1; s < kc; ++s) ii += x >= base[s] ? 1 : 0;
+                    const uint32_t read_remain = (uint32_t)(len - ii * kmer - kmer);
+                    uint32_t mx = 0;
+                    int ol = -1;
+                    const uint32_t lim = cmc::upper_bound_lookup(c, LP[x], (uint32_t)kmer, read_remain, mx, ol);
+                    *(CM_G uint2 *)(dps + x) = make_uint2(lim, mx);
+                    dpp[x] = ol;
+                }
+            };
+            for (uint32_t x0 = 0; x0 < n_pre; x0 += 64) {
+                const uint32_t x = x0 + lane;
+                const bool nr = x < n_pre && cmc::bit_at(c.A.near_border_bits, c.A.n_bits, LP[x]);
+                const unsigned long long m = __ballot(nr);
+                if (lane == 0) NB[x0 >> 5] = (uint32_t)m;
+                if (lane == 32) NB[(x0 >> 5) + 1] = (uint32_t)(m >> 32);
+                if (nr) Q[qn + __popcll(m & lt)] = (uint16_t)x;
+                qn += (uint32_t)__popcll(m);
+                __syncthreads();
+                if (qn >= 64) {
+                    look_up(64);
+                    const uint16_t keep = (uint32_t)lane < qn - 64 ? Q[64 + lane] : (uint16_t)0;
+                    __syncthreads();
+                    if ((uint32_t)lane < qn - 64) Q[lane] = keep;
+                    qn -= 64;
+                    __syncthreads();
+                }
+            }
+            if (qn) look_up(qn);
+        }
+        __threadfence_block();
+        __syncthreads();
 #if defined(CM_CHAIN_DIAG)
         const unsigned long long dg1 = wall_clock64();
 #endif
 #if defined(CM_CHAIN_DIAG)
         unsigned long long tk[5] = {0, 0, 0, 0, 0};
         unsigned long long wv[4] = {0, 0, 0, 0};       // wave time: first evaluation, scan + log growth, store / second evaluation, barrier
-        HeavyChainCtx H{tk, &c, LP, base, cn, kc, len, dps, dpp};
+        HeavyChainCtx H{tk, &c, LP, NB, base, cn, kc, len, dps, dpp};
 #else
-        HeavyChainCtx H{&c, LP, base, cn, kc, len, dps, dpp};
+        HeavyChainCtx H{&c, LP, NB, base, cn, kc, len, dps, dpp};
 #endif
         CM_G cmc::Event *ev = nullptr;
         uint32_t n_ev = 0, cap_ev = 0;
@@ -1875,8 +1932,10 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
     // k_chain_heavy keeps a problem's hit positions in LDS: sized for the largest problem of this tile (a multiple of 2 KB, so
     // that launches of similar tiles share a configuration), not for the n_seeds x seed_lim a problem could have in theory --
     // the kernel waits on memory most of the time and the LDS request decides how many waves a CU holds.
+    // (+ behind the hits: one bit per cell and a queue of 128 hits, see the kernel's upper_bound pass)
+    const size_t lds_extra = ((size_t)max_cells / 64 + 2) * 8 + 256;
     const size_t heavy_lds = std::min<size_t>((size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t),
-                                              ((size_t)max_cells * sizeof(uint32_t) + 2047) / 2048 * 2048 + 2048);
+                                              ((size_t)max_cells * sizeof(uint32_t) + 2047) / 2048 * 2048 + 2048) + (lds_extra + 255) / 256 * 256;
     const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;
     bool fresh = true;            // the cursors are still as run_seed_tile zeroed them
     // one launch group over problems [a, b) whose DP cells start at `base`: the improvement log of every problem comes out of the

@@ -567,20 +567,33 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
                     dpp[x] = ol;
                 }
             };
-            for (uint32_t x0 = 0; x0 < n_pre; x0 += 64) {
-                const uint32_t x = x0 + lane;
-                const bool nr = x < n_pre && cmc::bit_at(c.A.near_border_bits, c.A.n_bits, LP[x]);
-                const unsigned long long m = __ballot(nr);
-                if (lane == 0) NB[x0 >> 5] = (uint32_t)m;
-                if (lane == 32) NB[(x0 >> 5) + 1] = (uint32_t)(m >> 32);
-                if (nr) Q[qn + __popcll(m & lt)] = (uint16_t)x;
-                qn += (uint32_t)__popcll(m);
+            for (uint32_t x0 = 0; x0 < n_pre; x0 += 256) {               // four bit reads in flight per lane
+                bool nr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t x = x0 + 64 * u + lane;
+                    nr[u] = x < n_pre && cmc::bit_at(c.A.near_border_bits, c.A.n_bits, LP[x]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t xb = x0 + 64 * u;
+                    if (xb >= n_pre) break;
+                    const unsigned long long m = __ballot(nr[u]);
+                    if (lane == 0) NB[xb >> 5] = (uint32_t)m;
+                    if (lane == 32) NB[(xb >> 5) + 1] = (uint32_t)(m >> 32);
+                    if (nr[u]) Q[qn + __popcll(m & lt)] = (uint16_t)(xb + lane);
+                    qn += (uint32_t)__popcll(m);
+                }
                 __syncthreads();
-                if (qn >= 64) {
+                while (qn >= 64) {                                       // (at most 63 + 256 entries queued)
                     look_up(64);
-                    const uint16_t keep = (uint32_t)lane < qn - 64 ? Q[64 + lane] : (uint16_t)0;
+                    uint16_t keep[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) keep[u] = 64u * u + (uint32_t)lane < qn - 64 ? Q[64 + 64 * u + lane] : (uint16_t)0;
                     __syncthreads();
-                    if ((uint32_t)lane < qn - 64) Q[lane] = keep;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (64u * u + (uint32_t)lane < qn - 64) Q[64 * u + lane] = keep[u];
                     qn -= 64;
                     __syncthreads();
                 }
@@ -1932,8 +1945,8 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
     // k_chain_heavy keeps a problem's hit positions in LDS: sized for the largest problem of this tile (a multiple of 2 KB, so
     // that launches of similar tiles share a configuration), not for the n_seeds x seed_lim a problem could have in theory --
     // the kernel waits on memory most of the time and the LDS request decides how many waves a CU holds.
-    // (+ behind the hits: one bit per cell and a queue of 128 hits, see the kernel's upper_bound pass)
-    const size_t lds_extra = ((size_t)max_cells / 64 + 2) * 8 + 256;
+    // (+ behind the hits: one bit per cell and a queue of 320 hits, see the kernel's upper_bound pass)
+    const size_t lds_extra = ((size_t)max_cells / 64 + 2) * 8 + 640;
     const size_t heavy_lds = std::min<size_t>((size_t)S * (size_t)ctx->P.seed_lim * sizeof(uint32_t),
                                               ((size_t)max_cells * sizeof(uint32_t) + 2047) / 2048 * 2048 + 2048) + (lds_extra + 255) / 256 * 256;
     const bool split = !(split_env && split_env[0] == '0') && ranges.size() == 1 && parallel_ok && heavy_lds <= 152u * 1024u;

@@ -38,6 +38,7 @@
 #include <chrono>
 #include <memory>
 #include <new>
+#include <functional>
 #include <vector>
 
 #include "circminer_hot.h"
@@ -57,33 +58,48 @@ struct Fasta {
 bool read_fasta(const char *path, Fasta &out) {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
-    std::string line;
-    int ch;
     bool have = false;
-    auto flush_line = [&]() {
-        if (line.empty()) return;
-        if (line[0] == '>') {
-            size_t a = 1, b = 1;
-            while (b < line.size() && !isspace((unsigned char)line[b])) ++b;
-            out.id.push_back(line.substr(a, b - a));
+    auto take_line = [&](const char *p, size_t n) {             // one line without its line feed
+        if (n == 0) return;
+        if (p[0] == '>') {
+            size_t b = 1;
+            while (b < n && !isspace((unsigned char)p[b])) ++b;
+            out.id.emplace_back(p + 1, b - 1);
             out.seq.emplace_back();
             have = true;
         } else if (have) {
             size_t a = 0;
-            while (a < line.size() && isspace((unsigned char)line[a])) ++a;
+            while (a < n && isspace((unsigned char)p[a])) ++a;
             size_t b = a;
-            while (b < line.size() && !isspace((unsigned char)line[b])) ++b;
-            out.seq.back().append(line, a, b - a);
+            while (b < n && !isspace((unsigned char)p[b])) ++b;
+            out.seq.back().append(p + a, b - a);
         }
-        line.clear();
     };
-    while ((ch = fgetc(f)) != EOF) {
-        if (ch == '\n') flush_line();
-        else line.push_back((char)ch);
+    // blocks of 4 MB, lines cut out with memchr (one fgetc per base took a minute of hg38's 136 s); a line that straddles two
+    // blocks is put together in `carry`
+    std::vector<char> buf(4u << 20);
+    std::string carry;
+    size_t got;
+    while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+        const char *p = buf.data(), *e = p + got;
+        while (p < e) {
+            const char *z = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (!z) {
+                carry.append(p, (size_t)(e - p));
+                break;
+            }
+            if (!carry.empty()) {
+                carry.append(p, (size_t)(z - p));
+                take_line(carry.data(), carry.size());
+                carry.clear();
+            } else take_line(p, (size_t)(z - p));
+            p = z + 1;
+        }
     }
-    flush_line();
+    if (!carry.empty()) take_line(carry.data(), carry.size());
+    const bool ok = !ferror(f);
     fclose(f);
-    return true;
+    return ok;
 }
 
 inline int code3(char ch) {
@@ -249,11 +265,28 @@ int cm_host_write_index(const char *packed_fa_path, const char *index_path, int3
     if (!packed_fa_path || !index_path || kmer < CM_WINDOW_SIZE || kmer > CM_WINDOW_SIZE + 8) return CM_EINVAL;
     Fasta fa;
     if (!read_fasta(packed_fa_path, fa) || fa.id.empty()) return CM_EINVAL;
-    for (auto &s : fa.seq)                                   // loadRefGenome contract: upper-case, non-ACGT -> N
-        for (auto &ch : s) {
-            const char u = (char)toupper((unsigned char)ch);
-            ch = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : 'N';
+    // the per-base passes below (case folding, 3-bit packing, the count of the 14-mer windows) ran on one thread: a minute of
+    // hg38's 136 s; they are cut into ranges now (the window count with relaxed atomic increments: the table is shared)
+    const int TP = std::max(1, std::min(n_threads, 32));
+    auto par_ranges = [&](uint64_t n, uint64_t align, const std::function<void(uint64_t, uint64_t)> &fn) {
+        if (TP == 1 || n < (1u << 20)) {
+            fn(0, n);
+            return;
         }
+        std::vector<std::thread> th;
+        for (int t = 0; t < TP; ++t) {
+            uint64_t a = n * (uint64_t)t / TP / align * align, b = t + 1 == TP ? n : n * (uint64_t)(t + 1) / TP / align * align;
+            if (b > a) th.emplace_back(fn, a, b);
+        }
+        for (auto &x : th) x.join();
+    };
+    for (auto &s : fa.seq)                                   // loadRefGenome contract: upper-case, non-ACGT -> N
+        par_ranges(s.size(), 1, [&](uint64_t a, uint64_t b) {
+            for (uint64_t i = a; i < b; ++i) {
+                const char u = (char)toupper((unsigned char)s[i]);
+                s[i] = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : 'N';
+            }
+        });
     FILE *f = fopen(index_path, "wb");
     if (!f) return CM_EINVAL;
     const uint8_t magic = compact ? 2 : 3, W = CM_WINDOW_SIZE;
@@ -281,25 +314,39 @@ int cm_host_write_index(const char *packed_fa_path, const char *index_path, int3
         // compressSequence: 21 bases per word, 3 bits each, first base in bits 62..60, last word left-aligned
         const uint32_t nw = n / 21 + (n % 21 != 0);
         std::vector<uint64_t> packed(nw, 0);
-        for (uint32_t i = 0; i < n; ++i) packed[i / 21] |= (uint64_t)code3(g[i]) << (60 - 3 * (i % 21));
+        par_ranges(nw, 1, [&](uint64_t wa, uint64_t wb) {     // whole words per thread
+            for (uint64_t w = wa; w < wb; ++w) {
+                uint64_t v = 0;
+                const uint64_t i0 = w * 21, i1 = std::min<uint64_t>(i0 + 21, n);
+                for (uint64_t i = i0; i < i1; ++i) v |= (uint64_t)code3(g[i]) << (60 - 3 * (i - i0));
+                packed[w] = v;
+            }
+        });
         ok = ok && (nw == 0 || fwrite(packed.data(), 8, nw, f) == nw);
         // count pass (HashTable.c:317-338): every 14-mer window without N
         std::fill(cnt14.begin(), cnt14.end(), 0u);
         uint32_t nbuckets = 0;
         {
-            uint32_t hv = 0;
-            int run = 0;
             const uint32_t mask = (uint32_t)(nb - 1);
-            for (uint32_t i = 0; i < n; ++i) {
-                const int v = code3(g[i]);
-                if (v == 4) {
-                    run = 0;
-                    hv = 0;
-                    continue;
+            std::atomic<uint32_t> nbk{0};
+            // a range [a, b) counts the windows that END in it: the hash is warmed up over the 13 bases in front of a
+            par_ranges(n, 1, [&](uint64_t a, uint64_t b) {
+                uint32_t hv = 0, mine = 0;
+                int run = 0;
+                for (uint64_t i = a >= (uint64_t)(CM_WINDOW_SIZE - 1) ? a - (CM_WINDOW_SIZE - 1) : 0; i < b; ++i) {
+                    const int v = code3(g[i]);
+                    if (v == 4) {
+                        run = 0;
+                        hv = 0;
+                        continue;
+                    }
+                    hv = ((hv << 2) | (uint32_t)v) & mask;
+                    ++run;
+                    if (i >= a && run >= CM_WINDOW_SIZE && __atomic_fetch_add(&cnt14[hv], 1u, __ATOMIC_RELAXED) == 0) ++mine;
                 }
-                hv = ((hv << 2) | (uint32_t)v) & mask;
-                if (++run >= CM_WINDOW_SIZE && cnt14[hv]++ == 0) ++nbuckets;
-            }
+                nbk += mine;
+            });
+            nbuckets = nbk.load();
         }
         ok = ok && put(f, nbuckets);
         uint64_t mem = 0;

@@ -289,3 +289,30 @@ def test_reader_rejects_garbage(L, tmp_path):
     h = C.c_void_p()
     assert L.cm_host_open_index(str(p).encode(), C.byref(h), None, None, None) != 0
     assert L.cm_host_open_index(str(tmp_path / "missing").encode(), C.byref(h), None, None, None) != 0
+
+
+def test_index_writer_does_not_depend_on_the_thread_count(L, tmp_path):
+    """cm_host_write_index cuts its per-base passes (case folding, 3-bit packing, the count of the 14-mer windows: relaxed atomic
+    increments on the shared table) and the table assembly into thread ranges once a contig has more than 2^20 bases; the small
+    genomes of the other tests stay on one thread.  1.3 Mbp with N runs, lower case, a run of N across a range boundary and FASTA
+    lines of 60 bases: the same bytes with 1 and 5 threads, full and compact format."""
+    rng = np.random.default_rng(3)
+    n = 1_300_003
+    g = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+    g[1000:1500] = ord("N")
+    g[n // 5 - 7:n // 5 + 9] = ord("N")                 # across the first range boundary of the 5-thread run
+    g[700_000:700_020] = ord("n")
+    g[900_001] = ord("a")
+    g[(2 * n) // 5 - 13:(2 * n) // 5 + 13] |= 0x20      # lower case around the second boundary
+    packed = str(tmp_path / "ref.fa.packed.fa")
+    with open(packed, "wb") as f:
+        f.write(b">1 one contig\n")
+        for i in range(0, n, 60):
+            f.write(g[i:i + 60].tobytes() + b"\n")
+    out = {}
+    for compact in (False, True):
+        for nt in (1, 5):
+            idx = cl.write_index(packed, kmer=20, compact=compact, n_threads=nt)
+            out[(compact, nt)] = open(idx, "rb").read()
+        assert out[(compact, 1)] == out[(compact, 5)]
+    assert len(out[(False, 1)]) > len(out[(True, 1)]) > n // 4

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1591,6 +1592,8 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 
 struct cm_ctx {
     cm_params P{};
+    unsigned id = 0;                          // serial number of the context in this process: names it in teardown diagnostics
+    int teardown_errors = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // heavy work of a stage, concurrent with the light kernel on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1726,6 +1729,15 @@ int fail(cm_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, (e_ == hipErrorOutOfMemory) ? CM_ENOMEM : CM_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// A HIP status nobody can return to the caller (teardown, frees inside grow-only buffers).  An asynchronous error -- a fault of a
+// kernel this context launched -- is sticky and would otherwise first show as an abort inside whatever context runs next;
+// reported here it carries the id of the context that raised it.  The first few per context go to stderr.
+void report_hip(cm_ctx *ctx, const char *what, hipError_t e) {
+    if (e == hipSuccess) return;
+    const int k = ctx ? ctx->teardown_errors++ : 0;
+    if (k < 8) fprintf(stderr, "[cmhot] context #%u: %s failed: %s (%d)\n", ctx ? ctx->id : 0u, what, hipGetErrorString(e), (int)e);
+}
+
 template <class T>
 int up(cm_ctx *ctx, std::vector<void *> &allocs, const T *host, size_t n, const T **dev) {
     void *d = nullptr;
@@ -1736,13 +1748,13 @@ int up(cm_ctx *ctx, std::vector<void *> &allocs, const T *host, size_t n, const 
     *dev = (const T *)d;
     return CM_OK;
 }
-void free_all(std::vector<void *> &v) {
-    for (void *p : v) (void)hipFree(p);
+void free_all(cm_ctx *ctx, std::vector<void *> &v) {
+    for (void *p : v) report_hip(ctx, "hipFree", hipFree(p));
     v.clear();
 }
 template <class T>
-void dfree(T *&p) {
-    if (p) (void)hipFree((void *)p);
+void dfree(cm_ctx *ctx, T *&p) {
+    if (p) report_hip(ctx, "hipFree", hipFree((void *)p));
     p = nullptr;
 }
 
@@ -1752,7 +1764,7 @@ template <class T>
 hipError_t ensure(cm_ctx *c, T *&p, size_t bytes) {
     size_t &cap = c->caps[(const void *)&p];
     if (p && cap >= bytes) return hipSuccess;
-    dfree(p);
+    dfree(c, p);
     cap = 0;
     const hipError_t e = hipMalloc((void **)&p, bytes ? bytes : 1);
     if (e == hipSuccess) cap = bytes;
@@ -1760,19 +1772,19 @@ hipError_t ensure(cm_ctx *c, T *&p, size_t bytes) {
 }
 
 void free_reads(cm_ctx *c) {
-    dfree(c->d_seq1_base); dfree(c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c->d_off1); dfree(c->d_off2);
-    dfree(c->d_state); dfree(c->d_active); dfree(c->d_active_b); dfree(c->d_cat);
-    dfree(c->d_chains_b); dfree(c->d_nchain_b); dfree(c->d_high_b); dfree(c->d_resid_b); dfree(c->d_cctr); dfree(c->d_cblk);
-    dfree(c->d_sstart); dfree(c->d_scnt); dfree(c->d_sraw); dfree(c->d_cells); dfree(c->d_celloff); dfree(c->d_bsum); dfree(c->d_bmax);
-    dfree(c->d_sstart_b); dfree(c->d_scnt_b); dfree(c->d_sraw_b); dfree(c->d_celloff_b); dfree(c->d_bsum_b); dfree(c->d_bmax_b);
-    dfree(c->d_cctr_b); dfree(c->d_cblk_b); dfree(c->d_cls4_b); dfree(c->d_perm4_b);
-    dfree(c->d_dpscore); dfree(c->d_dpprev); dfree(c->d_chains); dfree(c->d_nchain); dfree(c->d_high);
-    dfree(c->d_pool); dfree(c->d_lane_clk); dfree(c->d_cls); dfree(c->d_cls4); dfree(c->d_perm4); dfree(c->d_resid); dfree(c->d_perm); dfree(c->d_cls_ctr); dfree(c->d_cls_ctr2); dfree(c->d_cls_sub); dfree(c->d_perm1); dfree(c->d_cls_ctr3); dfree(c->d_cls_sub2); dfree(c->d_perm0); dfree(c->d_blk_cnt); dfree(c->d_hlist); dfree(c->d_hres);
-    dfree(c->d_pair_err); dfree(c->d_retry_list); dfree(c->d_spill); dfree(c->d_type_hist); dfree(c->d_retry_ctr); dfree(c->d_heavy_load);
-    dfree(c->d_col_cls); dfree(c->d_col_perm); dfree(c->d_col_blk); dfree(c->d_col_ctr);
-    if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
-    dfree(c->st_seq1_base); dfree(c->st_seq2_base); dfree(c->st_off1); dfree(c->st_off2); dfree(c->st_prior);
-    dfree(c->d_ones);
+    dfree(c, c->d_seq1_base); dfree(c, c->d_seq2_base); c->d_seq1 = c->d_seq2 = nullptr; dfree(c, c->d_off1); dfree(c, c->d_off2);
+    dfree(c, c->d_state); dfree(c, c->d_active); dfree(c, c->d_active_b); dfree(c, c->d_cat);
+    dfree(c, c->d_chains_b); dfree(c, c->d_nchain_b); dfree(c, c->d_high_b); dfree(c, c->d_resid_b); dfree(c, c->d_cctr); dfree(c, c->d_cblk);
+    dfree(c, c->d_sstart); dfree(c, c->d_scnt); dfree(c, c->d_sraw); dfree(c, c->d_cells); dfree(c, c->d_celloff); dfree(c, c->d_bsum); dfree(c, c->d_bmax);
+    dfree(c, c->d_sstart_b); dfree(c, c->d_scnt_b); dfree(c, c->d_sraw_b); dfree(c, c->d_celloff_b); dfree(c, c->d_bsum_b); dfree(c, c->d_bmax_b);
+    dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b);
+    dfree(c, c->d_dpscore); dfree(c, c->d_dpprev); dfree(c, c->d_chains); dfree(c, c->d_nchain); dfree(c, c->d_high);
+    dfree(c, c->d_pool); dfree(c, c->d_lane_clk); dfree(c, c->d_cls); dfree(c, c->d_cls4); dfree(c, c->d_perm4); dfree(c, c->d_resid); dfree(c, c->d_perm); dfree(c, c->d_cls_ctr); dfree(c, c->d_cls_ctr2); dfree(c, c->d_cls_sub); dfree(c, c->d_perm1); dfree(c, c->d_cls_ctr3); dfree(c, c->d_cls_sub2); dfree(c, c->d_perm0); dfree(c, c->d_blk_cnt); dfree(c, c->d_hlist); dfree(c, c->d_hres);
+    dfree(c, c->d_pair_err); dfree(c, c->d_retry_list); dfree(c, c->d_spill); dfree(c, c->d_type_hist); dfree(c, c->d_retry_ctr); dfree(c, c->d_heavy_load);
+    dfree(c, c->d_col_cls); dfree(c, c->d_col_perm); dfree(c, c->d_col_blk); dfree(c, c->d_col_ctr);
+    if (c->stream_copy) report_hip(c, "hipStreamSynchronize(copy stream)", hipStreamSynchronize(c->stream_copy));
+    dfree(c, c->st_seq1_base); dfree(c, c->st_seq2_base); dfree(c, c->st_off1); dfree(c, c->st_off2); dfree(c, c->st_prior);
+    dfree(c, c->d_ones);
     c->ones_cap = 0;
     c->pre_launched = c->pre_ready = false;
     c->staged = false;
@@ -1965,8 +1977,13 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             {
             Timer t(ctx, 6, ctx->stream2);
-            if (heavy_lds > 64u * 1024u)
+            // (a property of the function, process-wide: only ever raised, so a launch in flight from another context of this
+            // process never sees its limit lowered)
+            static std::atomic<size_t> heavy_attr{64u * 1024u};
+            if (heavy_lds > heavy_attr.load()) {
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
+                heavy_attr.store(heavy_lds);
+            }
             const uint32_t hb = n < 8192u ? n : 8192u;
             static const size_t heavy_pad = getenv("CM_CHEAVY_LDS_PAD") ? (size_t)atoi(getenv("CM_CHEAVY_LDS_PAD")) : 0;     // occupancy experiment
             hipLaunchKernelGGL(k_chain_heavy, dim3(hb), dim3(64), heavy_lds + heavy_pad, ctx->stream2, core, rd, pair0, S, sb.sstart, sb.scnt, sb.celloff,
@@ -2082,6 +2099,10 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     if (hipSetDevice(p->device) != hipSuccess) return CM_ENODEV;
     cm_ctx *ctx = new cm_ctx();
     ctx->P = *p;
+    {
+        static std::atomic<unsigned> serial{0};
+        ctx->id = ++serial;
+    }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
@@ -2103,14 +2124,14 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_retired, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-        delete ctx;
+        cm_destroy(ctx);
         return CM_EHIP;
     }
     if (hipMalloc((void **)&ctx->d_pool_cursor, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_err, sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_pin, 128, hipHostMallocDefault) != hipSuccess) {
-        delete ctx;
+        cm_destroy(ctx);
         return CM_ENOMEM;
     }
     memset(ctx->h_pin, 0, 128);
@@ -2126,47 +2147,43 @@ int cm_create(const cm_params *p, cm_ctx **out) {
 
 void cm_destroy(cm_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->P.device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamSynchronize(ctx->stream2);
-    if (ctx->stream_p) (void)hipStreamSynchronize(ctx->stream_p);
-    if (ctx->stream_p2) (void)hipStreamSynchronize(ctx->stream_p2);
-    if (ctx->stream_p3) (void)hipStreamSynchronize(ctx->stream_p3);
-    if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
-    for (auto e : ctx->ev_free) (void)hipEventDestroy(e);
+    report_hip(ctx, "hipSetDevice", hipSetDevice(ctx->P.device));
+    // Every stream of the context is drained, and its status looked at, before anything it could still touch is released: an
+    // asynchronous error of this context's work is reported here, under this context's id, instead of surfacing as an abort in
+    // whichever context uses the device next.
+    const std::pair<hipStream_t, const char *> streams[] = {{ctx->stream, "hipStreamSynchronize(main)"},        {ctx->stream2, "hipStreamSynchronize(heavy chains)"},
+                                                            {ctx->stream_s, "hipStreamSynchronize(seeding)"},    {ctx->stream_p, "hipStreamSynchronize(pairs)"},
+                                                            {ctx->stream_p2, "hipStreamSynchronize(heavy pairs)"}, {ctx->stream_p3, "hipStreamSynchronize(re-run)"},
+                                                            {ctx->stream_copy, "hipStreamSynchronize(copy)"}};
+    for (const auto &st : streams)
+        if (st.first) report_hip(ctx, st.second, hipStreamSynchronize(st.first));
+    report_hip(ctx, "hipGetLastError at teardown", hipGetLastError());
+    for (auto e : ctx->ev_free) report_hip(ctx, "hipEventDestroy", hipEventDestroy(e));
     ctx->ev_free.clear();
     for (auto &r : ctx->recs) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        report_hip(ctx, "hipEventDestroy", hipEventDestroy(r.a));
+        report_hip(ctx, "hipEventDestroy", hipEventDestroy(r.b));
     }
+    ctx->recs.clear();
     free_reads(ctx);
     for (auto &s : ctx->slots) {
-        free_all(s.idx_allocs);
-        free_all(s.ann_allocs);
+        free_all(ctx, s.idx_allocs);
+        free_all(ctx, s.ann_allocs);
     }
-    dfree(ctx->d_collect_idx);
-    dfree(ctx->d_collect_st);
-    dfree(ctx->d_collect_rec);        // grow-only output staging outlives a batch (collect_cap / collect_rec_cap go with it)
-    dfree(ctx->d_pool_cursor);
-    dfree(ctx->d_err);
-    dfree(ctx->d_counters);
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (hipEvent_t e : {ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail, ctx->ev_first[0],
-                         ctx->ev_first[1]})
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->stream_p3) (void)hipStreamDestroy(ctx->stream_p3);
-    if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
-    for (hipEvent_t e : {ctx->ev_seed[0], ctx->ev_seed[1]})
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->stream_p) (void)hipStreamDestroy(ctx->stream_p);
-    if (ctx->stream_p2) (void)hipStreamDestroy(ctx->stream_p2);
-    if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
-    if (ctx->ev_retired) (void)hipEventDestroy(ctx->ev_retired);
-    if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
-    if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamDestroy(ctx->stream2);
-    (void)hipStreamDestroy(ctx->stream);
+    dfree(ctx, ctx->d_collect_idx);
+    dfree(ctx, ctx->d_collect_st);
+    dfree(ctx, ctx->d_collect_rec);        // grow-only output staging outlives a batch (collect_cap / collect_rec_cap go with it)
+    dfree(ctx, ctx->d_pool_cursor);
+    dfree(ctx, ctx->d_err);
+    dfree(ctx, ctx->d_counters);
+    if (ctx->h_pin) report_hip(ctx, "hipHostFree", hipHostFree(ctx->h_pin));
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail,
+                         ctx->ev_first[0], ctx->ev_first[1], ctx->ev_seed[0], ctx->ev_seed[1], ctx->ev_staged, ctx->ev_retired})
+        if (e) report_hip(ctx, "hipEventDestroy", hipEventDestroy(e));
+    for (hipStream_t st : {ctx->stream_p3, ctx->stream_s, ctx->stream_p, ctx->stream_p2, ctx->stream_copy})
+        if (st) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(st));
+    if (ctx->stream2 && ctx->stream2 != ctx->stream) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(ctx->stream2));
+    if (ctx->stream) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(ctx->stream));
     delete ctx;
 }
 
@@ -2199,7 +2216,7 @@ int cm_load_contig(cm_ctx *ctx, int slot, const cm_index_view *iv) {
     if (!iv->genome || !iv->bucket_off || !iv->checksum || !iv->pos) return fail(ctx, CM_EINVAL, "null index array");
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     Slot &s = ctx->slots[slot];
-    free_all(s.idx_allocs);
+    free_all(ctx, s.idx_allocs);
     s.d_desc = nullptr;
     s.loaded = false;
     ++s.gen;
@@ -2239,7 +2256,7 @@ int cm_load_contig_raw(cm_ctx *ctx, int slot, const cm_index_raw *raw) {
     if (raw->table_slots > 0xffffffffull) return fail(ctx, CM_ELIMIT, "table of %llu slots", (unsigned long long)raw->table_slots);
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     Slot &s = ctx->slots[slot];
-    free_all(s.idx_allocs);
+    free_all(ctx, s.idx_allocs);
     s.d_desc = nullptr;
     s.loaded = false;
     ++s.gen;
@@ -2261,9 +2278,10 @@ int cm_load_contig_raw(cm_ctx *ctx, int slot, const cm_index_raw *raw) {
     // temporaries: the table as in the file, the bucket list, the table offset of every bucket, scan block sums
     std::vector<void *> tmp;
     struct FreeTmp {
+        cm_ctx *c;
         std::vector<void *> &v;
-        ~FreeTmp() { free_all(v); }
-    } free_tmp{tmp};
+        ~FreeTmp() { free_all(c, v); }
+    } free_tmp{ctx, tmp};
     const RawEntry *d_tab = nullptr;
     const uint32_t *d_hv = nullptr, *d_cnt = nullptr;
     if ((rc = up(ctx, tmp, (const RawEntry *)raw->table, (size_t)raw->table_slots, &d_tab))) return rc;
@@ -2316,7 +2334,7 @@ int cm_load_annotation(cm_ctx *ctx, int slot, const cm_annot_view *av) {
     if (av->n_iv == 0 || av->n_chr == 0) return fail(ctx, CM_EINVAL, "annotation needs >= 1 interval and >= 1 chromosome");
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     Slot &s = ctx->slots[slot];
-    free_all(s.ann_allocs);
+    free_all(ctx, s.ann_allocs);
     s.has_annot = false;
     ++s.gen;
     cmc::AnnotAosHost aos;
@@ -2363,8 +2381,8 @@ int cm_unload_contig(cm_ctx *ctx, int slot) {
     if (!ctx || slot < 0 || slot >= MAX_SLOTS) return CM_EINVAL;
     (void)hipSetDevice(ctx->P.device);
     (void)hipStreamSynchronize(ctx->stream);
-    free_all(ctx->slots[slot].idx_allocs);
-    free_all(ctx->slots[slot].ann_allocs);
+    free_all(ctx, ctx->slots[slot].idx_allocs);
+    free_all(ctx, ctx->slots[slot].ann_allocs);
     ctx->slots[slot].loaded = ctx->slots[slot].has_annot = false;
     ctx->slots[slot].d_desc = nullptr;
     ++ctx->slots[slot].gen;
@@ -2675,10 +2693,15 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     // the re-run launch of k_pair (RetryArgs): staging buffers for strings of any length a read of this batch can produce
     const int cap2 = std::min(((2 * ctx->max_len + 64 + 7) / 8) * 8, 1016);      // 1016: 64 KB of LDS per wave
     const size_t lds2 = (size_t)2 * lbuf_bytes(cap2) * BLK_PAIR;
-    if (lds_heavy > 48 * 1024 || lds2 > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_rerun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_pair_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_heavy));
+    {   // dynamic-LDS limits of the three kernels: process-wide properties, only ever raised (see run_chain_tile)
+        static std::atomic<size_t> lim[3] = {{48u * 1024u}, {48u * 1024u}, {48u * 1024u}};
+        const void *fn[3] = {(const void *)k_pair, (const void *)k_pair_rerun, (const void *)k_pair_heavy};
+        const size_t want[3] = {lds_bytes, lds2, lds_heavy};
+        for (int k = 0; k < 3; ++k)
+            if (want[k] > lim[k].load()) {
+                HIPCHK(ctx, hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want[k]));
+                lim[k].store(want[k]);
+            }
     }
     {
         Timer t(ctx, 5, sp);
@@ -2788,7 +2811,6 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
 // *rounds_done counts the rounds whose pair stage was issued for every tile (the flags arrays have swapped roles that often).
 static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final, int *items_done, int *rounds_done) {
     int rc;
-    auto bail = [&](int e) { return e; };
     // everything queued on the main stream so far (uploads, resets, collects of the previous batch) comes first
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
@@ -2858,10 +2880,10 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         const uint8_t *act_prep = prep_flags(i);
         auto ahead = [&]() -> int { return (seed_ahead && i + 1 < n_items) ? issue_seed(i + 1, ctx->stream_s) : CM_OK; };
         if (use_pre && i == 0) {                                          // set b holds this item's chains, ev_prep[b] is recorded
-            if ((rc = ahead())) return bail(rc);
+            if ((rc = ahead())) return rc;
         } else {
-            if (!seeded[(size_t)i] && (rc = issue_seed(i, ctx->stream))) return bail(rc);
-            if ((rc = settle_pair(ctx, b))) return bail(rc);
+            if (!seeded[(size_t)i] && (rc = issue_seed(i, ctx->stream))) return rc;
+            if ((rc = settle_pair(ctx, b))) return rc;
             if (ctx->pair_pending[b]) {                                   // chain buffers of set b: free once their pair stage is done
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
                 ctx->pair_pending[b] = false;
@@ -2870,22 +2892,22 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
             // flags (chain kernels 8.4 -> 6.7 ms per step, step 24.0 -> 25.1 ms: the wait costs more than the work it saves)
             static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';
             const bool wait_exact = exact_flags && !round_major && r > 0;
-            if (wait_exact && (rc = settle_pair(ctx, b ^ 1))) return bail(rc);
+            if (wait_exact && (rc = settle_pair(ctx, b ^ 1))) return rc;
             if (wait_exact && ctx->pair_pending[b ^ 1]) {                 // item - 1 = the same tile's round r - 1
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b ^ 1], 0));
                 ctx->pair_pending[b ^ 1] = false;
             }
-            if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, wait_exact ? A[r & 1] : act_prep, rb, i & 1, ahead))) return bail(rc);
+            if ((rc = run_chain_tile(ctx, core, rd_cur, p0, nt, sl.chain_parallel_ok, wait_exact ? A[r & 1] : act_prep, rb, i & 1, ahead))) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         }
         const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
         const bool same_tile = i > 0 && items[i - 1].p0 == p0;
-        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile, round_major))) return bail(rc);
+        if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile, round_major))) return rc;
         ++*items_done;
         if (++tiles_of_round[(size_t)r] == (int)n_tiles) ++*rounds_done;
         static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
         if (no_overlap) {
-            if ((rc = settle_pair(ctx, b))) return bail(rc);
+            if ((rc = settle_pair(ctx, b))) return rc;
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
         }
     }
@@ -2909,15 +2931,15 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
             ctx->ones_cap = ctx->n_pairs;
         }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
-        if ((rc = settle_pair(ctx, b))) return bail(rc);
+        if ((rc = settle_pair(ctx, b))) return rc;
         if (ctx->pair_pending[b]) {
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
             ctx->pair_pending[b] = false;
         }
         const RoundBufs rbn = round_bufs(ctx, b);
         const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
-        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return bail(rc);
-        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, rbn, n_items & 1))) return bail(rc);
+        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return rc;
+        if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, rbn, n_items & 1))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         ctx->pre_launched = true;
         ctx->pre_slot = slots[0];
@@ -2927,7 +2949,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     }
     // later work on the main stream (downloads, collects, the next batch) is ordered behind the last pair stage on the device
     // (set item_base ^ 1 = the last item's goes second: stream p3's last entry then waits for stream p's last)
-    if ((rc = settle_pair(ctx, ctx->item_base, false)) || (rc = settle_pair(ctx, ctx->item_base ^ 1, false))) return bail(rc);
+    if ((rc = settle_pair(ctx, ctx->item_base, false)) || (rc = settle_pair(ctx, ctx->item_base ^ 1, false))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream_p3));               // (p3's last launch waits for p's last)
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;                     // covered by the wait above
@@ -2969,7 +2991,10 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round) { return cm_map_round
 int cm_sync(cm_ctx *ctx) {
     if (!ctx) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
+    // the main stream is ordered behind every other stream's work at the end of each call (ev_tail); the staging copy of
+    // cm_reads_stage is the one thing a caller can have in flight beside it
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_copy));
     return check_dev_err(ctx);
 }
 
@@ -3030,8 +3055,8 @@ int cm_collect_active(cm_ctx *ctx, uint64_t cap, uint64_t *out_idx, cm_mapped_re
     int rc = compact_active(ctx);
     if (rc) return rc;
     if (cap > ctx->collect_cap) {                 // grow-only output staging
-        dfree(ctx->d_collect_idx);
-        dfree(ctx->d_collect_st);
+        dfree(ctx, ctx->d_collect_idx);
+        dfree(ctx, ctx->d_collect_st);
         ctx->collect_cap = 0;
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_idx, cap * sizeof(unsigned long long)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_st, cap * sizeof(cm_mapped_read)));
@@ -3071,7 +3096,7 @@ int cm_collect_records(cm_ctx *ctx, uint64_t index_base, uint64_t cap, cm_record
     if (!ctx || !out_n || (cap && !out)) return CM_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->P.device));
     if (cap > ctx->collect_rec_cap) {
-        dfree(ctx->d_collect_rec);
+        dfree(ctx, ctx->d_collect_rec);
         ctx->collect_rec_cap = 0;
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_collect_rec, cap * sizeof(cm_record)));
         ctx->collect_rec_cap = cap;

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -190,13 +191,26 @@ inline void advise_huge(void *p, size_t bytes) {
     (void)bytes;
 #endif
 }
+// Called before a block that cm_fastq_next has handed out is freed or moved (see cm_fastq_set_release_hook).
+struct ReleaseHook {
+    void (*fn)(void *user, const void *ptr, uint64_t bytes) = nullptr;
+    void *user = nullptr;
+};
+std::atomic<int> g_raw_oom{0};       // a RawVec could not grow inside a worker thread (reported by the cm_fastq_* call as CM_ENOMEM)
 template <class T> struct RawVec {
     T *p = nullptr;
     size_t n = 0, cap = 0;
+    const ReleaseHook *hook = nullptr;      // set for the arrays a caller may have page-locked
     RawVec() = default;
     RawVec(const RawVec &) = delete;
     RawVec &operator=(const RawVec &) = delete;
-    ~RawVec() { free(p); }
+    ~RawVec() { release(); }
+    void release() {
+        if (p && hook && hook->fn) hook->fn(hook->user, p, (uint64_t)(cap * sizeof(T)));
+        free(p);
+        p = nullptr;
+        n = cap = 0;
+    }
     T *data() { return p; }
     const T *data() const { return p; }
     size_t size() const { return n; }
@@ -204,11 +218,19 @@ template <class T> struct RawVec {
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
     void clear() { n = 0; }
+    // A block never moves behind its owner's back: growth allocates a new block, tells the hook that the old one is going
+    // (a caller that registered it with the GPU runtime unregisters it there) and only then frees it.  Out of memory: the old
+    // block stays as it is and std::bad_alloc is thrown (caught at the C boundary -> CM_ENOMEM).
     void reserve(size_t c) {
         if (c <= cap) return;
         size_t nc = cap ? cap : 1024;
         while (nc < c) nc *= 2;
-        p = (T *)realloc(p, nc * sizeof(T));
+        T *q = (T *)malloc(nc * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        if (n) memcpy(q, p, n * sizeof(T));
+        if (p && hook && hook->fn) hook->fn(hook->user, p, (uint64_t)(cap * sizeof(T)));
+        free(p);
+        p = q;
         cap = nc;
         advise_huge(p, nc * sizeof(T));
     }
@@ -231,6 +253,14 @@ template <class T> struct RawVec {
         for (size_t i = 0; i < k; ++i) p[i] = v;
     }
 };
+// body of a worker thread: an allocation failure inside it must not terminate the process
+template <class F> void guarded(F &&f) {
+    try {
+        f();
+    } catch (const std::bad_alloc &) {
+        g_raw_oom = 1;
+    }
+}
 
 struct Side {
     RawVec<uint8_t> seq, qual;
@@ -249,6 +279,7 @@ struct Side {
 }  // namespace
 
 struct cm_fastq {
+    ReleaseHook hook;                        // cm_fastq_set_release_hook (declared first: the batch arrays below call it when they go)
     Stream s1, s2;
     // four generations of batch storage, used in turn: the batch a call returns stays valid over the next three calls, so a
     // caller can have batch k-1 with its writer thread, batch k on the GPU, batch k+1 staged (its H2D copy in flight) and
@@ -264,6 +295,12 @@ struct cm_fastq {
     int max_ed = 4;
     bool any_prior = false;
     std::string err;
+    cm_fastq() {
+        for (Gen &g : gen) {                 // the arrays cm_fastq_batch::reads / prior point into
+            g.a.seq.hook = g.a.off.hook = g.b.seq.hook = g.b.off.hook = &hook;
+            g.prior.hook = &hook;
+        }
+    }
 };
 
 namespace {
@@ -421,7 +458,8 @@ template <class F> void par_for(int nt, size_t n, F f) {       // f(thread, begi
         return;
     }
     std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back(f, t, n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt);
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&f, t, n, nt]() { guarded([&]() { f(t, n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt); }); });
     for (auto &x : th) x.join();
 }
 
@@ -602,10 +640,15 @@ int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_ou
     const bool trace = getenv("CM_FASTQ_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     {   // the two files are filled and indexed side by side
-        std::thread t2([&]() { a2 = fill_and_index(f->s2, f->nl2, (size_t)max_pairs, hint, half, &tail2); });
-        a1 = fill_and_index(f->s1, f->nl1, (size_t)max_pairs, hint, half, &tail1);
+        std::thread t2([&]() { guarded([&]() { a2 = fill_and_index(f->s2, f->nl2, (size_t)max_pairs, hint, half, &tail2); }); });
+        try {
+            a1 = fill_and_index(f->s1, f->nl1, (size_t)max_pairs, hint, half, &tail1);
+        } catch (const std::bad_alloc &) {
+            g_raw_oom = 1;
+        }
         t2.join();
     }
+    if (g_raw_oom.exchange(0)) return CM_ENOMEM;
     if (f->s1.io_error || f->s2.io_error) return CM_EIO;
     if (a2 < a1 && a2 < max_pairs) return CM_EINVAL;                  // R2 ends before R1
     const size_t n = (size_t)std::min<uint64_t>(a1, max_pairs);      // R1 decides; surplus R2 records at the end of input are ignored
@@ -622,10 +665,15 @@ int next_plain(cm_fastq *f, uint64_t max_pairs, cm_fastq::Gen &G, uint64_t *n_ou
     bool ok1 = true, ok2 = true, any = false;
     const auto t_mid = std::chrono::steady_clock::now();
     {
-        std::thread t2([&]() { ok2 = n2 == 0 || build_side(f, f->s2, f->nl2, n2, G.b, nullptr, nullptr, half); });
-        ok1 = n == 0 || build_side(f, f->s1, f->nl1, n, G.a, &G.prior, &any, half);
+        std::thread t2([&]() { guarded([&]() { ok2 = n2 == 0 || build_side(f, f->s2, f->nl2, n2, G.b, nullptr, nullptr, half); }); });
+        try {
+            ok1 = n == 0 || build_side(f, f->s1, f->nl1, n, G.a, &G.prior, &any, half);
+        } catch (const std::bad_alloc &) {
+            g_raw_oom = 1;
+        }
         t2.join();
     }
+    if (g_raw_oom.exchange(0)) return CM_ENOMEM;
     if (!ok1 || !ok2) return CM_EINVAL;
     f->any_prior = any;
     if (trace) fprintf(stderr, "[fastq] %zu pairs: fill+index %.1f ms, build %.1f ms\n", n, std::chrono::duration<double, std::milli>(t_mid - t0).count(),
@@ -824,8 +872,21 @@ int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_i
     return CM_OK;
 }
 
+static int fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     if (!f || !out) return CM_EINVAL;
+    try {
+        return fastq_next(f, max_pairs, out);
+    } catch (const std::bad_alloc &) {
+        return CM_ENOMEM;
+    }
+}
+void cm_fastq_set_release_hook(cm_fastq *f, void (*fn)(void *user, const void *ptr, uint64_t bytes), void *user) {
+    if (!f) return;
+    f->hook.fn = fn;
+    f->hook.user = user;
+}
+static int fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     f->cur = (f->cur + 1) % 4;
     cm_fastq::Gen &G = f->gen[f->cur];
     G.a.clear();
@@ -844,31 +905,38 @@ int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     uint64_t n = fast ? n_fast : 0, n2 = fast ? n2_fast : 0;
     int bad2 = 0;
     std::thread side_b([&]() {
-        while (!fast && n2 < max_pairs) {
-            const int r2 = parse_record(f, f->s2, G.b, false, nullptr, nullptr);
-            if (r2 == 0) break;
-            if (r2 < 0) {
-                bad2 = 1;
-                break;
+        guarded([&]() {
+            while (!fast && n2 < max_pairs) {
+                const int r2 = parse_record(f, f->s2, G.b, false, nullptr, nullptr);
+                if (r2 == 0) break;
+                if (r2 < 0) {
+                    bad2 = 1;
+                    break;
+                }
+                ++n2;
             }
-            ++n2;
-        }
+        });
     });
     int bad1 = 0;
-    while (!fast && n < max_pairs) {
-        cm_mapped_read st;
-        bool carried = false;
-        const int r1 = parse_record(f, f->s1, G.a, true, &st, &carried);
-        if (r1 == 0) break;
-        if (r1 < 0) {
-            bad1 = 1;
-            break;
+    try {
+        while (!fast && n < max_pairs) {
+            cm_mapped_read st;
+            bool carried = false;
+            const int r1 = parse_record(f, f->s1, G.a, true, &st, &carried);
+            if (r1 == 0) break;
+            if (r1 < 0) {
+                bad1 = 1;
+                break;
+            }
+            G.prior.push_back(st);
+            f->any_prior = f->any_prior || carried;
+            ++n;
         }
-        G.prior.push_back(st);
-        f->any_prior = f->any_prior || carried;
-        ++n;
+    } catch (const std::bad_alloc &) {
+        g_raw_oom = 1;
     }
     side_b.join();
+    if (g_raw_oom.exchange(0)) return CM_ENOMEM;
     if (f->s1.io_error || f->s2.io_error) return CM_EIO;
     if (bad1 || bad2 || n2 < n) return CM_EINVAL;                   // malformed record, or R2 ends before R1
     if (n2 > n) {        // R1 ended first: like the reference, which stops at R1's end, the surplus R2 records are not paired

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -85,20 +86,29 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         uint64_t n_rec = 0;
         cm_fastq_batch batch;
     } res[2];
-    std::vector<std::pair<void *, uint64_t>> pinned;            // parser arrays registered with the runtime (cm_host_register)
-    std::thread writer, parser, gtf_thread, free_thread;
+    // parser arrays registered with the runtime (cm_host_register).  The parser tells us (release hook, on its own thread) before
+    // one of them is freed -- a generation's array that has to grow is allocated anew -- so that no registration outlives its block.
+    struct Pinned {
+        std::mutex mu;
+        std::vector<std::pair<void *, uint64_t>> v;
+        cm_ctx *cm = nullptr;
+    } pin;
+    std::vector<std::pair<void *, uint64_t>> &pinned = pin.v;
+    std::thread writer, parser, gtf_thread;
     int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
-        if (free_thread.joinable()) free_thread.join();
         if (gtf_thread.joinable()) gtf_thread.join();           // it reads chrs
         if (parser.joinable()) parser.join();
         if (writer.joinable()) writer.join();
         if (w_map) cm_writer_close(w_map);
         if (w_rem) cm_writer_close(w_rem);
-        if (cm) (void)cm_sync(cm);                             // no copy out of the parser's arrays is in flight any more
-        for (auto &pr : pinned) (void)cm_host_unregister(cm, pr.first);
-        pinned.clear();
+        if (cm) (void)cm_sync(cm);                             // drains the copy stream too: no copy out of the parser's arrays is in flight any more
+        {
+            std::lock_guard<std::mutex> lk(pin.mu);
+            for (auto &pr : pinned) (void)cm_host_unregister(cm, pr.first);
+            pinned.clear();
+        }
         if (fq) cm_fastq_close(fq);
         if (cm) cm_destroy(cm);
         if (!annots.empty()) cm_host_free_annotation(annots.data(), (uint32_t)annots.size());
@@ -129,6 +139,7 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         return rc;
     }
     MAP_TRY(cm_create(&P, &cm), "cm_create");
+    pin.cm = cm;
 
     // ---- every packed contig into its own slot (loadHashTable + pac2char_whole_contig per round in the reference) ----
     // Contig c + 1 is read and decoded from the index file (host threads) while contig c goes over PCIe and gets its bucket
@@ -251,6 +262,10 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         for (uint32_t c = 0; c < n_con; ++c) MAP_TRY(cm_load_annotation(cm, (int)c, &annots[c]), "cm_load_annotation");
         lap("annotation uploaded", tu);
         views.clear();                                              // (their arrays went back after each upload)
+        // everything is in HBM: the file handle's buffers (two sets of raw records on the full-format path, ~ 19 GB for hg38)
+        // are dead weight from here on -- per process, and there is one process per GPU
+        cm_host_close_index(idx);
+        idx = nullptr;
         lap("load done", t0);
     }
     st.rounds = (int32_t)n_con;
@@ -268,6 +283,18 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         MAP_TRY(cm_writer_open(r1.c_str(), r2.c_str(), chrs, n_chr, &w_rem), "cm_writer_open (remain)");
     }
     MAP_TRY(cm_fastq_open_shard(a->fastq1, a->fastq2, chrs, n_chr, P.max_ed, rank, world, n_threads, &fq, nullptr, nullptr), "cm_fastq_open_shard");
+    cm_fastq_set_release_hook(fq, [](void *user, const void *ptr, uint64_t bytes) {
+        Pinned *pn = (Pinned *)user;
+        std::lock_guard<std::mutex> lk(pn->mu);
+        const char *lo = (const char *)ptr, *hi = lo + bytes;
+        for (auto it = pn->v.begin(); it != pn->v.end();) {
+            const char *a0 = (const char *)it->first, *a1 = a0 + it->second;
+            if (a0 < hi && a1 > lo) {                         // a registration inside the block that is going
+                (void)cm_host_unregister(pn->cm, it->first);
+                it = pn->v.erase(it);
+            } else ++it;
+        }
+    }, &pin);
 
     // ---- batches: write k-1 (worker) | rounds of k (device, driven by this thread) | H2D + first round of k+1 | parse k+2 (worker) ----
     const double t1 = now();
@@ -275,6 +302,7 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
     for (uint32_t c = 0; c < n_con; ++c) all[c] = (int)c;
     // page-lock the parser's arrays of a batch (they are reused every fourth batch; re-registered only when one has moved or grown)
     auto pin_batch = [&](const cm_fastq_batch &b) -> int {
+        std::lock_guard<std::mutex> lk(pin.mu);
         const uint64_t n = b.reads.n_pairs;
         const void *ptr[4] = {b.reads.seq1, b.reads.seq2, b.reads.off1, b.reads.off2};
         const uint64_t bytes[4] = {b.reads.off1[n], b.reads.off2[n], (n + 1) * sizeof(uint64_t), (n + 1) * sizeof(uint64_t)};

@@ -158,6 +158,9 @@ class ReadBatch:
 _lib = None
 
 
+RELEASE_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)      # cm_fastq_set_release_hook: (user, ptr, bytes)
+
+
 def load(path: str = LIB_PATH) -> C.CDLL:
     """Load libcmhot.so and declare every prototype of include/circminer_hot.h."""
     global _lib
@@ -222,6 +225,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         "cm_merge_parts": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
         "cm_fastq_next": (C.c_int, [vp, C.c_uint64, pp(FastqBatch)]),
         "cm_fastq_close": (None, [vp]),
+        "cm_fastq_set_release_hook": (None, [vp, RELEASE_HOOK, vp]),
         "cm_writer_open": (C.c_int, [C.c_char_p, C.c_char_p, pp(ChrInfo), C.c_uint32, pp(vp)]),
         "cm_write_remain": (C.c_int, [vp, pp(FastqBatch), vp, vp, C.c_uint64]),
         "cm_write_remain_records": (C.c_int, [vp, pp(FastqBatch), vp, C.c_uint64]),
@@ -262,7 +266,7 @@ EXPORTED_SYMBOLS = ["cm_create", "cm_destroy", "cm_last_error", "cm_load_contig"
                     "cm_prof_counters", "cm_host_build_index", "cm_host_free_index", "cm_host_index_stats", "cm_host_build_annotation",
                     "cm_host_free_annotation", "cm_host_pack_genome", "cm_host_read_index_info", "cm_host_free_index_info",
                     "cm_host_write_index", "cm_host_open_index", "cm_host_next_contig", "cm_host_next_contig_genome", "cm_host_free_loaded_contig",
-                    "cm_host_close_index", "cm_fastq_open", "cm_fastq_open_shard", "cm_merge_parts", "cm_fastq_next", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
+                    "cm_host_close_index", "cm_fastq_open", "cm_fastq_open_shard", "cm_merge_parts", "cm_fastq_next", "cm_fastq_set_release_hook", "cm_fastq_close", "cm_writer_open", "cm_write_remain",
                     "cm_write_pam", "cm_write_sam_header", "cm_write_sam", "cm_writer_flush", "cm_writer_close", "cm_mapping_run", "cm_sort_remain", "cm_circ_report", "cm_circ_call", "cm_circ_run", "cm_host_gene_overlap", "cm_regional_table_build", "cm_regional_table_free"]
 
 

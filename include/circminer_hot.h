@@ -230,6 +230,8 @@ int cm_reads_download(cm_ctx *ctx, cm_mapped_read *out_state, int32_t *out_categ
 int cm_map_batch(cm_ctx *ctx, int slot, int is_last_round, const cm_reads *reads,
                  const cm_mapped_read *prior, cm_mapped_read *out_state, int32_t *out_category);
 
+/* Waits for everything the context has in flight -- the mapping streams and the staging copy of cm_reads_stage -- and reports
+ * device-side capacity flags (CM_ELIMIT).  After it returns no host array handed to an earlier call is read any more. */
 int cm_sync(cm_ctx *ctx);
 
 /* Put the resident batch back into its first-round state (fill_map_info's "cnt != 23" state,
@@ -394,7 +396,13 @@ int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *c
  * block's position in the whole input.  Every rank of a node can open its share at the same time. */
 int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed,
                         int32_t rank, int32_t world, int n_threads, cm_fastq **out, uint64_t *first_pair, uint64_t *n_pairs);
-int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);   /* out->reads.n_pairs == 0 at the end */
+int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);   /* out->reads.n_pairs == 0 at the end; CM_ENOMEM when a batch array cannot grow */
+/* A caller that page-locks the arrays of a batch (cm_host_register on reads.seq1/seq2/off1/off2, prior) must know when one of
+ * them goes away: `fn(user, ptr, bytes)` is called -- on whichever thread runs cm_fastq_next / cm_fastq_close -- right BEFORE the
+ * block starting at `ptr` is freed (a generation's array that has to grow is allocated anew, never moved in place), so that the
+ * caller can unregister it first.  No copy out of that block may still be in flight then: the block belongs to the generation
+ * handed out four cm_fastq_next calls ago. */
+void cm_fastq_set_release_hook(cm_fastq *f, void (*fn)(void *user, const void *ptr, uint64_t bytes), void *user);
 void cm_fastq_close(cm_fastq *f);
 
 /* Writers.  cm_write_remain = FilterRead::write_read_category PE (src/filter.cpp:413-455) into

@@ -19,6 +19,44 @@ from circminer_amd import _build, lib as cl, synth  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    _install_fault_harness()
+
+
+def _install_fault_harness():
+    """One occurrence of an abort must be enough to name its cause (round 3 lost one: the runtime's message went into pytest's
+    captured stderr and died with the process).  tests/harness/fault_harness.c runs on the faulting thread and leaves
+    gpurun_out/faults/fault_<pid>.txt: native stack of that thread + the captured stderr; Python's faulthandler adds the Python
+    stacks of all threads to gpurun_out/faults/py_<pid>.txt."""
+    import faulthandler
+    out_dir = os.path.join(ROOT, "gpurun_out", "faults")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        so_dir = os.path.join(ROOT, "tests", "_hostemu")
+        os.makedirs(so_dir, exist_ok=True)
+        so = os.path.join(so_dir, "libfaultharness.so")
+        src = os.path.join(ROOT, "tests", "harness", "fault_harness.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-rdynamic", src, "-o", so])
+        H = C.CDLL(so)
+        H.cm_fault_harness_install.argtypes = [C.c_char_p]
+        if H.cm_fault_harness_install(out_dir.encode()) != 0:
+            return
+        global _fault_py_file
+        _fault_py_file = open(os.path.join(out_dir, f"py_{os.getpid()}.txt"), "w")
+        faulthandler.enable(file=_fault_py_file, all_threads=True)        # runs first, then hands the signal on to the C handler
+    except Exception as e:                                                 # the harness must never be the reason a suite fails
+        sys.stderr.write(f"[conftest] fault harness not installed: {e}\n")
+
+
+def pytest_unconfigure(config):
+    f = globals().get("_fault_py_file")
+    if f is not None and f.tell() == 0:                                   # nothing happened: leave no empty files behind
+        name = f.name
+        f.close()
+        try:
+            os.remove(name)
+        except OSError:
+            pass
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -487,3 +487,56 @@ def test_sharded_reader_blocks(built, tmp_path):
         cl.FastqReader(gz, tiny2, CHRS, 4, rank=0, world=2)
     with pytest.raises(RuntimeError):
         cl.FastqReader(tiny1, tiny2, CHRS, 4, rank=2, world=2)
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_batch_arrays_that_grow_are_announced_before_they_go(tmp_path, monkeypatch, serial):
+    """A caller page-locks the arrays of a batch (cm_mapping_run does, with cm_host_register).  A generation's array that has to
+    grow -- reads that get longer from batch to batch -- is allocated anew (never moved in place), and the release hook names the
+    old block before it is freed: every array of a generation is either the block handed out for that generation's previous batch
+    or a new one whose predecessor has been announced; closing announces the rest."""
+    import ctypes as C
+    if serial:
+        monkeypatch.setenv("CM_FASTQ_SERIAL", "1")
+    rng = np.random.default_rng(7)
+    per, nb = 300, 12
+    names, s1, q1, s2, q2 = [], [], [], [], []
+    for b in range(nb):                                      # batch b: reads of (40 + 60 b) bases: capacities are passed several times
+        for i in range(per):
+            L = 40 + 60 * b
+            names.append(f"r{b}_{i}")
+            s1.append("".join(rng.choice(list("ACGT"), L)))
+            s2.append("".join(rng.choice(list("ACGT"), L + 3)))
+            q1.append("I" * L)
+            q2.append("I" * (L + 3))
+    p1, p2 = str(tmp_path / "g1.fq"), str(tmp_path / "g2.fq")
+    _fastq(p1, names, s1, q1)
+    _fastq(p2, names, s2, q2)
+    rd = cl.FastqReader(p1, p2)
+    live = set()                                             # blocks handed out and not announced as going
+    gone = []
+
+    def hook(user, ptr, nbytes):
+        live.discard(ptr)
+        gone.append((ptr, nbytes))
+
+    cb = cl.RELEASE_HOOK(hook)
+    rd.L.cm_fastq_set_release_hook(rd.h, cb, None)
+    seen = 0
+    per_gen = {}
+    for b in range(nb):
+        pb = rd.next_batch(per)
+        assert pb.n == per
+        mine = [C.cast(ptr, C.c_void_p).value for ptr in (pb.c.seq1, pb.c.seq2, pb.c.off1, pb.c.off2)]
+        if b >= 4:                                           # this generation's previous blocks: kept, or announced before the new ones came
+            for old, new in zip(per_gen[b % 4], mine):
+                assert old == new or old not in live
+        per_gen[b % 4] = mine
+        live.update(mine)
+        assert pb.seq(0).decode() == s1[b * per] and pb.seq(per - 1, 2).decode() == s2[b * per + per - 1]
+        seen += pb.n
+    assert rd.next_batch(per) is None or rd.next_batch(per).n == 0
+    assert len(gone) >= 8                                    # four generations x two sequence arrays outgrew their first blocks
+    n_before = len(gone)
+    rd.close()
+    assert len(gone) > n_before and not live                 # closing announces what is left

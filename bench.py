@@ -7,7 +7,7 @@
 Default workload = the configuration the metric is quoted on (BASELINE.json configs[2], scaled to one step): an hg38-sized
 synthetic genome (24 chromosomes with hg38's lengths, 3.09 Gbp -> three packed contigs, all resident in HBM, three mapping
 rounds), k = 20, batches of 2^21 2x150 bp pairs = two launch tiles of 2^20 (with two tiles the library walks them round by
-round, so a tile's seeding sees the flags its previous pair stage wrote: DESIGN.md 5.25).
+round, so a tile's seeding sees the flags its previous pair stage wrote), eight distinct batches taking turns.
 
 A "step" is one batch through the whole hot path:
   * its reads come from (page-locked) host memory: cm_reads_stage copies batch k+1 over PCIe on a copy stream while batch
@@ -97,6 +97,7 @@ def cpu_baseline(P, hi, batch, target_s=12.0):
     dt1 = run(1)                                    # one pass sizes the sample: about target_s seconds of wall time in all
     reps = max(1, min(40, int(round((target_s - dt1) / max(dt1, 1e-3)))))
     dt = run(reps)
+    cpu_baseline.sample = (n, st0[:n].copy(), act0[:n].copy())      # the oracle's final states: what the line's parity check compares
     return {"value": n * reps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"first {n} pairs of one batch of the same workload x {reps} passes, all {hi.n_contigs} rounds, "
                       f"oracle/cm_oracle.cpp on {cores} threads, {dt:.1f}s",
@@ -269,6 +270,7 @@ def main():
     ap.add_argument("--workload", default="hg38like", choices=sorted(WORKLOAD_NOTE))
     ap.add_argument("--pairs", type=int, default=1 << 21, help="pairs per batch (= per step and GPU); the library maps tiles of <= 2^20 pairs")
     ap.add_argument("--seed", type=int, default=38)
+    ap.add_argument("--batches", type=int, default=8, help="distinct batches of --pairs pairs that take turns in the timed region (>= 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", type=int, default=0, metavar="PAIRS",
                     help="also run the file-to-file flow (index file + GTF + FASTQ text -> circ_report) on this many pairs and add an "
@@ -369,6 +371,21 @@ def main():
             shutil.rmtree(sdir, ignore_errors=True)          # mappings of the other ranks stay valid until they drop them
     batches = [hp.pinned_batch(d.seq1[i * args.pairs:(i + 1) * args.pairs], d.seq2[i * args.pairs:(i + 1) * args.pairs]) for i in range(2)]
     load_s = time.time() - t0 - prep_s
+    # more distinct batches (the timed region streams them round-robin): own streams of reads off the same genome, made on host
+    # threads; batches 0 and 1 stay what earlier rounds measured
+    t_more = time.time()
+    n_more = max(0, args.batches - 2)
+    if n_more:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def more(k):
+            rng = np.random.default_rng([args.seed, 7919 + 64 * rank + k])
+            s1, s2 = synth.make_reads(rng, d.chr_seqs, d.genes, args.pairs)[:2]
+            return s1, s2
+        with ThreadPoolExecutor(max_workers=min(n_more, max(1, n_threads // 2))) as ex:
+            for s1, s2 in ex.map(more, range(n_more)):
+                batches.append(hp.pinned_batch(s1, s2))
+    more_s = time.time() - t_more
     base = rank * args.pairs
     gather = cdist.BsjGather(args.pairs, gather_dev) if multi else None
     turn = [0]
@@ -376,7 +393,7 @@ def main():
 
     def step():
         # H2D of the next batch on the copy stream, concurrent with the rounds of the resident one
-        turn[0] ^= 1
+        turn[0] = (turn[0] + 1) % len(batches)
         hp.stage(batches[turn[0]])
         tr = [time.perf_counter()] if trace else None
         hp.map_rounds(list(range(hi.n_contigs)), True)
@@ -472,6 +489,37 @@ def main():
         except Exception:
             traffic = None
         read_bytes = int(batches[0].seq1.size + batches[0].seq2.size + 16 * (args.pairs + 1))
+        # every stage against the HBM roofline, with the counter figures BASELINE.md 4 names (HBM GB/s of the probe phase, LDS
+        # behaviour of the chaining phase) and the lanes a VALU instruction of each kernel carries -- the figure that says what
+        # bounds the pair stage.  Times and algorithmic bytes: this run (HIP events per stage).  Counter figures: separate
+        # rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE; profiles/pmc_mix.json: SQ_* of one 2^20-pair round).
+        mix = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_mix.json")) as f:
+                mix = json.load(f)
+            if mix.get("workload") != args.workload:
+                mix = {}
+        except Exception:
+            mix = {}
+        tdet = {}
+        try:
+            tdet = tj.get("bytes_per_launch", {}) if traffic_src else {}
+        except Exception:
+            tdet = {}
+        stages = {}
+        for name, idx, kernels in (("seed", 0, ["k_seed"]), ("chain", 1, ["k_chain", "k_chain_heavy"]), ("pair", 2, ["k_pair", "k_pair_heavy"])):
+            n_l = max(launches[idx], 1)
+            t_ms = ms[idx] / n_l
+            ach = (ab[idx] / n_l) / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+            tb = tdet.get(KERNELS[idx])
+            stages[name] = {"kernels": kernels, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": ab[idx] / n_l, "achieved_GBps": ach,
+                            "frac_of_hbm_peak": ach / HBM_PEAK_GBS, "counter_bytes_per_launch": tb,
+                            "counter_GBps": (tb / (t_ms * 1e-3) / 1e9) if (tb and t_ms > 0) else None,
+                            "lanes_per_valu_inst": {k: mix.get("kernels", {}).get(k, {}).get("lanes_per_valu_inst") for k in kernels},
+                            "lds_bank_conflict_rate": {k: mix.get("kernels", {}).get(k, {}).get("lds_bank_conflict_rate") for k in kernels},
+                            "bound": {"seed": "hbm (random 64-byte sectors)", "chain": "hbm sectors (light) / latency + LDS (heavy)",
+                                      "pair": "VALU issue under control divergence"}[name]}
+        stages["counter_source"] = mix.get("source") if mix else None
         out = {
             "metric": METRIC,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -481,7 +529,7 @@ def main():
                                    f"{len(d.genes)} genes / {sum(len(g.transcripts) for g in d.genes)} transcripts; indexed 20-mers with > 1 hit "
                                    f"{'/'.join('%.1f%%' % (100.0 * m / max(n, 1)) for n, m, o, _ in hit_stats)}, beyond seedLim "
                                    f"{'/'.join('%.2f%%' % (100.0 * o / max(n, 1)) for n, m, o, _ in hit_stats)} per contig), k=20, {hi.n_contigs} mapping round(s) per batch, batches of {args.pairs} 2x150 bp pairs "
-                                   f"streamed from host memory (H2D inside the timed region, overlapped with the rounds), defaults; "
+                                   f"streamed from host memory ({len(batches)} distinct batches round-robin; H2D inside the timed region, overlapped with the rounds), defaults; "
                                    f"{total_pairs} pairs in the timed region",
                        "scope": "stage 1 hot path (process_read over all rounds + BSJ hand-off); reads start in host memory, "
                                 "FASTQ parsing and stage-2 circ_report are outside the timed region; parity is against the "
@@ -493,20 +541,43 @@ def main():
                        "multi_hit_fraction": [m / max(n, 1) for n, m, o, _ in hit_stats],
                        "beyond_seed_lim_fraction": [o / max(n, 1) for n, m, o, _ in hit_stats],
                        "world_size": world,
-                       "prep_seconds": {"generate": round(gen_s, 1), "index+annotation": round(prep_s - gen_s, 1), "load_to_hbm": round(load_s, 1)}},
+                       "distinct_batches": len(batches),
+                       "prep_seconds": {"generate": round(gen_s, 1), "index+annotation": round(prep_s - gen_s, 1), "load_to_hbm": round(load_s, 1),
+                                        "more_batches": round(more_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_pair_heavy (pair stage: light kernel launch to the join with the heavy kernel)" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": launches[dom],
                          "algorithmic_bytes_per_launch": ab[dom] / max(launches[dom], 1)},
+            "stages": stages,
             "kernels": {KERNELS[i]: {"ms_total": ms[i], "launches": launches[i], "algorithmic_bytes": ab[i]} for i in range(7)},
             "counters": {"probes": counters[0], "search_touches": counters[1], "hits_consumed": counters[2], "pair_rounds": counters[3],
                          "pair_rounds_rerun": counters[4]},
         }
+        # The line's own parity evidence (outside the timed region): batch 0 once more through the same calls the steps make --
+        # staged, swapped in, all rounds in one call, two tiles -- and its final MatchedRead (72 B) + re-queue flag of every pair
+        # kept; the cpu_baseline leg below maps (a prefix of) the same batch with the oracle and the two are compared byte for byte.
+        hp.stage(batches[0])
+        hp.swap()
+        hp.map_rounds(list(range(hi.n_contigs)), True)
+        gpu_st, _, gpu_act = hp.download()
         if args.e2e:
             hp.close()                                          # its HBM goes back before cm_mapping_run makes a context of its own
             out["end_to_end"] = end_to_end(d, args.workload, args.e2e, os.cpu_count() or 8, args.pairs, dev_index)
         # rank 0's host cores, after the timed region (the other ranks are idle at the final barrier by then)
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(P, hi, batches[0])
+        if out["cpu_baseline"] is not None:
+            n_s, o_st, o_act = cpu_baseline.sample
+            eq = bool(gpu_st[:n_s].tobytes() == o_st.tobytes() and (gpu_act[:n_s] == o_act).all())
+            out["parity"] = {"pairs": int(n_s), "equal": eq, "rounds": hi.n_contigs,
+                             "what": "final cm_mapped_read (72 bytes) + re-queue flag of the first `pairs` pairs of batch 0 after all rounds: "
+                                     "HIP path (staged batch, cm_map_rounds, 2^20-pair tiles) vs the CPU oracle (parity unpinned: the oracle is "
+                                     "pinned by planted truth and its own builders, not by reference output)",
+                             "bsj_pairs": int(gpu_act[:n_s].sum())}
+            if not eq:
+                bad = np.nonzero([gpu_st[i].tobytes() != o_st[i].tobytes() for i in range(n_s)])[0]
+                out["parity"]["first_differences"] = [int(x) for x in bad[:8]]
+        else:
+            out["parity"] = None
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -2092,6 +2092,11 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     // Five streams of one context work at the same time (seed / chain, heavy chains, pair stage, heavy pairs, H2D staging); the
     // runtime's default of 4 hardware queues makes two of them share one and serialises them.  Only effective when this is the
     // first HIP call of the process; callers that bring up HIP earlier (PyTorch) set the variable themselves (bench.py does).
+    // When the variable was not set (or set lower) on entry and something else of this process -- PyTorch, an RCCL communicator --
+    // has already brought HIP up, setting it now changes nothing and the schedule runs on the default 4 hardware queues: said
+    // once on stderr (CM_QUIET=1 silences it) and left in cm_last_error() of the new context, instead of silently running slower.
+    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
+    const bool hwq_low = !hwq || atoi(hwq) < 16;
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CM_ENODEV;
@@ -2140,6 +2145,13 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     if (getenv("CM_ONE_STREAM")) {           // diagnostic: no concurrency between the light and the heavy kernels
         (void)hipStreamDestroy(ctx->stream2);
         ctx->stream2 = ctx->stream;
+    }
+    if (hwq_low) {
+        ctx->err = "note: GPU_MAX_HW_QUEUES was " + std::string(hwq ? hwq : "unset") +
+                   " when this context was created; if HIP was initialised earlier in this process the seven streams of a context share the "
+                   "default 4 hardware queues (pipelined rounds run slower). Export GPU_MAX_HW_QUEUES=16 before the first HIP call.";
+        static std::atomic<bool> said{false};
+        if (hwq && !said.exchange(true) && !getenv("CM_QUIET")) fprintf(stderr, "[cmhot] %s\n", ctx->err.c_str());
     }
     *out = ctx;
     return CM_OK;

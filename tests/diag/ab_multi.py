@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 from circminer_amd import lib as cl, synth
-libs = [a.split("=", 1) for a in sys.argv[1:]]
+libs = [a.split("=", 1) for a in sys.argv[1:]]          # name=path.so[@ENV=VALUE[,ENV=VALUE]]: the variables are set while that library runs
 pairs = int(os.environ.get("PAIRS", 1 << 21)); steps = int(os.environ.get("STEPS", "10")); reps = int(os.environ.get("REPS", "2"))
 wl = os.environ.get("WORKLOAD", "hg38like")
 d = synth.generate(wl, n_pairs=2 * pairs, seed=38)
@@ -20,6 +20,9 @@ KN = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_
 res = {}
 for rep in range(reps):
     for name, path in libs:
+        path, _, envs = path.partition("@")
+        envs = dict(e.split("=", 1) for e in envs.split(",") if e)
+        os.environ.update(envs)              # (a library reads its knobs once, when first used: give every setting its own copy of the .so)
         cl._lib = None
         L = default_load(os.path.abspath(path))
         cl.load = lambda path=None, L=L: L
@@ -46,5 +49,6 @@ for rep in range(reps):
             name, rep, pairs * steps / dt / 1e6, dt / steps * 1e3, " ".join("%s %.2f" % (KN[i][2:], ms[i] / max(launches[i], 1)) for i in (0, 1, 6, 2, 4, 5)), len(rec), dig), flush=True)
         res.setdefault(name, []).append(dt / steps * 1e3)
         hp.close(); del hp, batches
+        for k in envs: os.environ.pop(k, None)
 for name, v in res.items():
     print("%-10s best %.2f ms/step  mean %.2f" % (name, min(v), sum(v) / len(v)))

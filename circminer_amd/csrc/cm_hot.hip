@@ -709,7 +709,13 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
             double cur = best_score;
             bool have = true;
             uint32_t n_rep = 0;
+#if defined(CM_CHAIN_DIAG)
+            unsigned long long dg_levels = 0;
+#endif
             while (have && best_count < max_best) {
+#if defined(CM_CHAIN_DIAG)
+                ++dg_levels;
+#endif
                 // (1) + next lower score, one pass over the log
                 uint32_t n_c = 0;
                 double nxt = -1.0;
@@ -798,6 +804,15 @@ __global__ void __launch_bounds__(64, CM_CHEAVY_WAVES) k_chain_heavy(KCore kc_, 
                 have = hv;
                 cur = nxt;
             }
+#if defined(CM_CHAIN_DIAG)      // shape of the back-tracking: events, score levels walked, passes over the log (64 events each)
+            if (lane == 0) {
+                atomicAdd(&counters[20], (unsigned long long)n_ev);
+                atomicAdd(&counters[21], dg_levels);
+                atomicAdd(&counters[22], 1ull);
+                atomicAdd(&counters[23], dg_levels * (unsigned long long)((n_ev + 63) / 64));
+                atomicAdd(&counters[24], (unsigned long long)ncell);
+            }
+#endif
         }
         if (best_count == 0) {          // singletons (lane 0 emits; every lane keeps the count)
             for (int ii = kc - 1; ii >= 0; --ii)

@@ -34,4 +34,6 @@ wv = [raw[16 + k] / 1e5 for k in range(4)]
 print(f"DP, lane time (ms, summed over lanes): binary searches {tk[0] / 1e5:.0f}, upper_bound {tk[1] / 1e5:.0f}, window loops {tk[2] / 1e5:.0f}; "
       f"{tk[3]} cells, {tk[4]} pair evaluations ({tk[4] / max(tk[3], 1):.2f} per cell)")
 print(f"DP, wave time (ms): first evaluation {wv[0]:.0f}, scan + store + second evaluation {wv[2]:.0f}, barriers {wv[3]:.0f}")
+print(f"back-tracking: {raw[22]} problems with a log, {raw[20] / max(raw[22], 1):.0f} events and {raw[24] / max(raw[22], 1):.0f} cells per problem, "
+      f"{raw[21] / max(raw[22], 1):.1f} score levels per problem, {raw[23] / max(raw[22], 1):.0f} 64-event passes per problem")
 hp.close()

@@ -54,7 +54,7 @@ WORKLOAD_NOTE = {
 
 def algorithmic_bytes(counters):
     """SURVEY.md 8(d) per-pair-round figure, split by the kernel that moves the bytes
-    (DESIGN.md 6): probes pay 16 B (bucket offset + count header) + 8 B per binary-search touch
+    (DESIGN.md 5): probes pay 16 B (bucket offset + count header) + 8 B per binary-search touch
     and the two reads come in once (300 B); chaining consumes 8 B per retained hit; pairing /
     extension is charged the survey's upper bound of four 170-byte reference windows (1360 B)
     plus the 96-byte result record."""

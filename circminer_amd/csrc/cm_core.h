@@ -1199,7 +1199,7 @@ CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
     flag_err(sm.err, ERR_BAND);
     return false;
 }
-// Closed forms used below (each provably equal to the DP it replaces):
+// Closed forms used below (each provably equal to the DP it replaces; NOTES.md note 3):
 //  * one-sided DP with w == 0 is the Hamming distance; with w > 0 and s == t[0..n) it is w (= |m - n|);
 //  * banded edit DP with s[0..m) == t: dp[m][m] = 0 beats every other end row (score 0 vs <= -2);
 //  * X-drop DP with s[0..m) == t (all m bases valid): the diagonal is never pruned, cell (m, m) scores m

@@ -43,6 +43,25 @@ def test_sort_remain_equals_gnu_sort_pipeline(built, tmp_path):
     assert open(cl.sort_remain(empty)).read() == ""
 
 
+def test_sort_remain_corner_cases_equal_gnu_sort(built, tmp_path):
+    """What `paste - - - - | sort -k2,2n | tr` does to input the mapping stage never writes but a user file may hold: ties on the
+    key (whole-line byte order decides, line ends compared as the TABs paste makes of them), negative / zero-padded / absent /
+    non-numeric keys, a header of one field (field 2 then starts with the sequence line), an incomplete last group, a last line
+    without a newline."""
+    recs = ["@a 5 x\nACGT\n+\nIIII", "@b 5 x\nACGT\n+\nIIII", "@a 5 w\nACGT\n+\nIIII", "@c -3 y\nAC\n+\nII", "@d 0007 y\nAC\n+\nII",
+            "@e * z\nAC\n+\nII", "@f\nAC\n+\nII", "@g 12abc q\nAC\n+\nII", "@h -0 q\nAC\n+\nII", "@i 7 q\nAC\n+\nII", "@a 5 x\nACGT\n+\nIIIJ",
+            "@j  9 two blanks\nAC\n+\nII", "@k 99999999999999999999 big\nAC\n+\nII", "@l 100000000000000000000 bigger\nAC\n+\nII"]
+    env = dict(os.environ, LC_ALL="C")
+    for tail in ("\n", "", "\n@z 1 partial\nAC\n", "\n@z 1 partial\nAC"):
+        p = str(tmp_path / f"corner{abs(hash(tail))}.fastq")
+        with open(p, "w") as f:
+            f.write("\n".join(recs) + tail)
+        got = cl.sort_remain(p)
+        want = p + ".gnu"
+        subprocess.check_call(f'cat {p} | paste - - - - | sort -S 64M -k2,2n | tr "\\t" "\\n" > {want}', shell=True, env=env)
+        assert open(got, "rb").read() == open(want, "rb").read(), tail
+
+
 def py_consensus(seqs):
     if not seqs or any(len(s) != len(seqs[0]) for s in seqs):
         return ""

@@ -825,6 +825,9 @@ CM_HD inline void load_codes16(const SV &v, int w0, uint8_t other, uint32_t q[4]
 #endif
 CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
     CM_STAT(8, 1);
+#if defined(CM_ABL_NOSTAGE)     // ablation study only: no staging either
+    return;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     CM_S uint32_t *dw = (CM_S uint32_t *)d.b;
     const int nw = (n + 7) >> 3;                   // words of eight codes
@@ -1120,39 +1123,134 @@ CM_HD inline bool xdrop_w3_step(XdropW3 &x, const LBuf &s, int n, const LBuf &tr
     x.pre_optimum = cmax(x.pre_optimum, x.cur_optimum);
     return true;
 }
+// The anti-diagonals k > W of the band-3 DP, in a RELATIVE score domain: slot q holds R = score - (k' >> 1), k' = the anti-diagonal
+// the slot's value belongs to (a dead cell holds -DPTINF itself).  With that offset a match adds nothing (R - 0), a mismatch costs 4,
+// a gap from anti-diagonal k - 1 costs 4 for even k and 3 for odd k -- kept per slot as Rm = R - (what its consumers subtract),
+// so that a cell is one bit-field extract, one subtract and one three-way max; the running optimum and the X-drop threshold are
+// shifted into the same domain once per anti-diagonal.  Exactly the values, ties and pruning of xdrop_w3_step (score = R + (k >> 1)
+// for every live cell, by induction: (k - 2 >> 1) + 1 = k >> 1; (k - 1 >> 1) = (k >> 1) - (k even)); the "last live row" new_ub is
+// only ever compared with -1, so a flag `some cell alive` replaces it.  (VALU instructions per two anti-diagonals on gfx950:
+// 164 -> see DESIGN; the anti-diagonal counter stays scalar because the caller's loop is wave-uniform.)
+struct XdropW3R {
+    int R[9], Rm[9];
+    int pre_optimum, cur_optimum, lb, ub, on_s, on_k;
+    bool alive_prev;
+};
+template <int PAR>
+CM_HD inline bool xdrop_w3_rel(XdropW3R &x, const LBuf &s, int n, const LBuf &tr, int m, int k, int top) {
+    constexpr int W = 3;
+    constexpr int q0 = PAR ? 1 : 2;
+    constexpr int G_OUT = PAR ? 4 : 3;           // what the consumers of this parity's slots subtract for a gap (odd slots feed even k: 4)
+    CM_STAT(4, x.ub - x.lb + 1);
+    const int ck = k >> 1;
+    const int i0 = (k + q0 - W - 1) >> 1;        // row of the first slot
+    const int a = i0 - 1, b = m - k + i0;        // first code of the two windows; a >= 0 here, b >= -3 while a cell is valid
+    const uint32_t S = nib8(s, a > top ? top : a);
+    uint32_t T = nib8(tr, b < 0 ? 0 : (b > top ? top : b));
+    T = b < 0 ? T << (4 * (-b & 7)) : T;
+    uint32_t ne = S ^ T;                         // codes are < 8: three bits tell two of them apart
+    ne = ((ne | (ne >> 1) | (ne >> 2)) & 0x11111111u) << 2;      // 4 where the codes differ, per nibble
+    const int lb = x.lb, ub = x.ub;
+    const int thr = x.pre_optimum - SC_XD - ck;  // a cell below this is dropped
+    int cur = x.cur_optimum - ck;
+    bool took = false;
+    int live = -DPTINF;
+#pragma unroll
+    for (int r = 0; r <= W; ++r) {
+        constexpr int QMAX = 2 * W + 1;
+        const int q = q0 + 2 * r;
+        if (q > QMAX) continue;                  // the even class has only W slots
+        const int i = i0 + r;
+        const bool valid = (i >= lb) && (i <= ub);
+        const int diag = x.R[q] - (int)((ne >> (4 * r)) & 4u);
+        const int nb = x.Rm[q - 1] > x.Rm[q + 1] ? x.Rm[q - 1] : x.Rm[q + 1];
+        const int v = diag > nb ? diag : nb;
+        const bool take = valid && (v >= cur);   // ascending i: a later cell wins a tie, as in the reference
+        cur = take ? v : cur;
+        x.on_s = take ? i : x.on_s;
+        took = took || take;
+        const int nv = (valid && v >= thr) ? v : -DPTINF;
+        x.R[q] = nv;
+        x.Rm[q] = nv - G_OUT;
+        live = live > nv ? live : nv;
+    }
+    x.on_k = took ? k : x.on_k;                  // on_t = on_k - on_s
+    x.cur_optimum = cur + ck;
+    if (PAR) {                                   // k > W, k - W even
+        ++x.lb;
+    } else {                                     // k > W, k - W odd
+        if (k - x.lb == m) ++x.lb;
+        if (x.ub < n) ++x.ub;
+    }
+    const bool alive = live > -DPTINF;
+    if ((!x.alive_prev && !alive) || x.lb > x.ub) return false;
+    x.alive_prev = alive;
+    x.pre_optimum = cmax(x.pre_optimum, x.cur_optimum);
+    return true;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_ANY_LANE(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define CM_ANY_LANE(x) (x)
+#endif
 // Band-3 specialisation of the X-drop DP (the default bandWidth, >85 % of all DP cells).
 // Same recurrence, evaluation order and pruning as local_alignment_sc_impl, restructured for a GPU lane:
 //  * one register per slot, updated in place: anti-diagonal k only owns the slots q == k (mod 2), so
 //    d[q] still holds (k-2, q) when (k, q) is computed and d[q +- 1] hold anti-diagonal k-1;
-//  * the loop is unrolled by two anti-diagonals so the slot class of each half is static;
+//  * the loop is unrolled by two anti-diagonals so the slot class of each half is static, and it runs for as long as ANY lane
+//    of the wave has anti-diagonals left (a lane that is done is masked): the counter k is then a scalar, and with it the
+//    window addresses of the reference string;
 //  * branch-free cells (selects), at most 4 per anti-diagonal instead of a 9-slot loop;
 //  * the substitution scores of an anti-diagonal come from one XOR of two nibble windows (the read residual is staged
-//    reversed for this: `tr`); the best cell is kept as (row, anti-diagonal), its score is cur_optimum.
+//    reversed for this: `tr`); the best cell is kept as (row, anti-diagonal), its score is cur_optimum;
+//  * beyond the first two anti-diagonals (boundary cells) the cells live in a relative score domain (xdrop_w3_rel).
 CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &tr, int m, int &sc_len, int &indel, int &align_score) {
     constexpr int W = 3;
     XdropW3 x;
+    XdropW3R y;
     x.on_s = x.on_k = x.cur_optimum = 0;
+    bool go = false;
+    const int top = (s.cap < tr.cap ? s.cap : tr.cap) - 1;
+    const int kmax = m + n;
     if (m > 0 && n > 0) {
 #pragma unroll
         for (int q = 0; q < 2 * W + 3; ++q) x.d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
         x.pre_optimum = 0;
         x.lb = x.ub = 1;
         x.pre_ub = 0;
-        const int top = (s.cap < tr.cap ? s.cap : tr.cap) - 1;
-        const int kmax = m + n;
-        bool go = xdrop_w3_step<0, true>(x, s, n, tr, m, 2, top) && kmax >= 3 && xdrop_w3_step<1, true>(x, s, n, tr, m, 3, top);
-        for (int k = 4; go && k <= kmax; k += 2) {
-            if (!xdrop_w3_step<0, false>(x, s, n, tr, m, k, top)) break;
-            if (k + 1 > kmax) break;
-            if (!xdrop_w3_step<1, false>(x, s, n, tr, m, k + 1, top)) break;
+        go = xdrop_w3_step<0, true>(x, s, n, tr, m, 2, top) && kmax >= 3 && xdrop_w3_step<1, true>(x, s, n, tr, m, 3, top);
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * W + 3; ++q) {        // into the relative domain: every slot holds anti-diagonal 2 or 3 (offset 1)
+        const int d = (m > 0 && n > 0) ? x.d[q] : -DPTINF;
+        y.R[q] = (q >= 1 && q <= 2 * W + 1 && d > -DPTINF) ? d - 1 : -DPTINF;
+        y.Rm[q] = y.R[q] - ((q & 1) ? 4 : 3);
+    }
+    y.pre_optimum = x.pre_optimum;
+    y.cur_optimum = x.cur_optimum;
+    y.lb = x.lb;
+    y.ub = x.ub;
+    y.on_s = x.on_s;
+    y.on_k = x.on_k;
+    y.alive_prev = x.pre_ub != -1;
+#if defined(CM_ABL_NODP)        // ablation study only (tests/diag/ablate.sh): what the kernels issue without the DP's main loop (results wrong)
+    go = false;
+#endif
+    for (int k = 4;; k += 2) {
+        go = go && k <= kmax;
+        if (!CM_ANY_LANE(go)) break;
+        if (go) {
+            if (!xdrop_w3_rel<0>(y, s, n, tr, m, k, top)) go = false;
+            else if (k + 1 > kmax) go = false;
+            else if (!xdrop_w3_rel<1>(y, s, n, tr, m, k + 1, top)) go = false;
         }
     }
-    const int score = x.cur_optimum, on_s = x.on_s, on_t = x.on_k - x.on_s;
+    const int score = y.cur_optimum, on_s = y.on_s, on_t = y.on_k - y.on_s;
     const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
     Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, W + 1, 0};
     if (ed <= (uint32_t)c.P.max_ed) {
-        Cand y{(int)ed, m - on_t, on_t - on_s, score};
-        best = y;
+        Cand z{(int)ed, m - on_t, on_t - on_s, score};
+        best = z;
     }
     align_score = score;
     sc_len = best.sclen;

@@ -1107,23 +1107,31 @@ constexpr int HG = CM_HEAVY_G;
 static_assert(HG >= 1 && HG <= 16, "the task list packs the slot in 4 bits");
 constexpr int HEAVY_LIST = HG * CM_BESTCHAINLIM * CM_BESTCHAINLIM;      // accepted (i, j) of all slots, worst case
 constexpr int HEAVY_SCRATCH = HEAVY_LIST * 2;     // bytes of per-block global scratch behind HRes[64]: the task list (u16)
-struct HSlot {           // one pair in flight (LDS).  Written by its owner lane unless noted.
-    cmc::g_chain fch, bch;               // chain lists of this attempt: forward read's, backward read's
+// One pair in flight (LDS).  Written by its owner lane unless noted.  Packed: LDS is allocated in steps of 1 280 bytes on this part
+// and this kernel's request (two staging buffers + six slots: 14 552 bytes = 12 steps) must not grow into the next one -- a 13th
+// step costs a resident wave per CU and 6 ms per bench step (NOTES 44).
+struct HSlot {
     cmc::g_u8 fseq, bseq;                // the two reads (forward read: as stored; backward read: reverse complement)
-    cmc::g_err perr;                     // capacity-limit word of the pair (RetryArgs)
-    int flen, blen;
-    int nf, nb;                          // chains; 0 / 0 while the slot sits an attempt out
+    uint32_t fch_i, bch_i;               // chain lists of this attempt (record index into the tile's chain records): forward read's, backward read's
+    uint32_t t;                          // the pair (tile-relative): its capacity-limit word is pair_err[t] (RetryArgs)
     unsigned int inv_nb;                 // ceil(65536 / nb): idx / nb = idx * inv_nb >> 16 for idx < 900
-    int saved_type;                      // MatchedRead.type at the start of the attempt (pairing predicate)
     unsigned int fp, bp;                 // chains that found a mate (atomicOr by the predicate lanes)
     int ntask;                           // accepted mate pairs (atomicAdd by the predicate lanes)
-    int done;                            // the fold returned CONCRD: the slot's remaining tasks are dead
     unsigned int fun, bun;               // unpaired chains to extend
-    int nfu, nbu;
-    int exf, exb, gf, gb;                // outcome of the unpaired-chain extensions (atomicMin / written by the k == 0 lane)
-    int fe[32], re[32];                  // exon interval of each chain's first fragment (written by the chain-end lanes)
-    uint32_t r0[64], rend[64];           // reference span of the chains: [0, 32) forward, [32, 64) backward
+    int exf, exb;                        // outcome of the unpaired-chain extensions (atomicMin)
+    int16_t flen, blen;
+    int16_t nf, nb;                      // chains; 0 / 0 while the slot sits an attempt out
+    int16_t nfu, nbu;
+    int8_t saved_type;                   // MatchedRead.type at the start of the attempt (pairing predicate)
+    int8_t done;                         // the fold returned CONCRD: the slot's remaining tasks are dead
+    int8_t gf, gb;                       // genic flag of each side's first unpaired chain (written by the k == 0 lane)
+    int fe[CM_BESTCHAINLIM], re[CM_BESTCHAINLIM];                        // exon interval of each chain's first fragment (written by the chain-end lanes)
+    uint32_t r0[2 * CM_BESTCHAINLIM], rend[2 * CM_BESTCHAINLIM];         // reference span of the chains: forward, then (from CM_BESTCHAINLIM) backward
 };
+__device__ inline cmc::g_chain slot_fch(CM_L const HSlot &s, const cm_chain *base) { return (cmc::g_chain)(base + s.fch_i); }
+__device__ inline cmc::g_chain slot_bch(CM_L const HSlot &s, const cm_chain *base) { return (cmc::g_chain)(base + s.bch_i); }
+__device__ inline cmc::g_err slot_perr(CM_L const HSlot &s, uint32_t *pair_err) { return (cmc::g_err)(pair_err + s.t); }
+static_assert(sizeof(HSlot) <= 808, "six slots + two staging buffers of 72-byte rows fit 11 LDS allocation steps");
 
 __device__ inline int nth_set_bit(uint32_t m, int k) {
     for (int x = 0; x < k; ++x) m &= m - 1;
@@ -1227,17 +1235,17 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
             if (lane < HG) {
                 CM_L HSlot &s = S[lane];
                 const cmc::ChainSet &F = r1_fwd ? sets[0] : sets[2], &B = r1_fwd ? sets[3] : sets[1];
-                s.fch = F.ch;
-                s.bch = B.ch;
+                s.fch_i = (uint32_t)(F.ch ? F.ch - (cmc::g_chain)chains : 0);
+                s.bch_i = (uint32_t)(B.ch ? B.ch - (cmc::g_chain)chains : 0);
                 s.fseq = r1_fwd ? s1 : s2;
                 s.bseq = r1_fwd ? s2 : s1;
-                s.flen = r1_fwd ? len1 : len2;
-                s.blen = r1_fwd ? len2 : len1;
-                s.perr = (cmc::g_err)(ra.pair_err + t);
-                s.nf = on ? F.n : 0;
-                s.nb = on ? B.n : 0;
+                s.flen = (int16_t)(r1_fwd ? len1 : len2);
+                s.blen = (int16_t)(r1_fwd ? len2 : len1);
+                s.t = t;
+                s.nf = (int16_t)(on ? F.n : 0);
+                s.nb = (int16_t)(on ? B.n : 0);
                 s.inv_nb = (on && B.n > 0) ? (65536u + (unsigned int)B.n - 1u) / (unsigned int)B.n : 0u;
-                s.saved_type = mr.type;
+                s.saved_type = (int8_t)mr.type;
                 s.fp = 0u;
                 s.bp = 0u;
                 s.ntask = 0;
@@ -1259,9 +1267,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
                 const int nf = s.nf;
                 const bool back = k >= nf;
                 const int ci = back ? k - nf : k;
-                const cmc::CHEnds e{(back ? s.bch : s.fch) + ci, kmer};
-                s.r0[(back ? 32 : 0) + ci] = e.r0;
-                s.rend[(back ? 32 : 0) + ci] = e.rend;
+                const cmc::CHEnds e{(back ? slot_bch(s, chains) : slot_fch(s, chains)) + ci, kmer};
+                s.r0[(back ? CM_BESTCHAINLIM : 0) + ci] = e.r0;
+                s.rend[(back ? CM_BESTCHAINLIM : 0) + ci] = e.rend;
                 (back ? s.re : s.fe)[ci] = cmc::overlap(c, e.r0);
             }
             __syncthreads();
@@ -1278,7 +1286,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
                     locate(pre, x, g, idx);
                     CM_L HSlot &s = S[g];
                     const int i = (int)(((unsigned int)idx * s.inv_nb) >> 16), j = idx - i * s.nb;
-                    const cmc::CHEnds F{s.r0[i], s.rend[i]}, R{s.r0[32 + j], s.rend[32 + j]};
+                    const cmc::CHEnds F{s.r0[i], s.rend[i]}, R{s.r0[CM_BESTCHAINLIM + j], s.rend[CM_BESTCHAINLIM + j]};
                     code = cmc::pair_code(c, F, R, s.fe[i], s.re[j], s.saved_type);
                     if (code) {
                         atomicOr((unsigned int *)&s.fp, 1u << i);
@@ -1309,9 +1317,9 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
                         const uint32_t code = (e >> 10) & 3u;
                         const int idx = (int)(e & 1023u);
                         const int i = (int)(((unsigned int)idx * s.inv_nb) >> 16), j = idx - i * s.nb;
-                        sm.err = s.perr;
+                        sm.err = slot_perr(s, ra.pair_err);
                         const cmc::TidList tl = (code == 1) ? cmc::common_tids(c, s.fe[i], s.re[j], tids) : cmc::TidList{tids, 0, -1, -1, false};
-                        const cmc::CH F{s.fch + i, kmer}, R{s.bch + j, kmer};
+                        const cmc::CH F{slot_fch(s, chains) + i, kmer}, R{slot_bch(s, chains) + j, kmer};
                         const cmc::Read frd{s.fseq, s.flen, 0}, brd{s.bseq, s.blen, 1};
                         cmc::MM r1, r2;
                         bool il, ok;
@@ -1361,8 +1369,8 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
                     else {
                         s.fun = fun;
                         s.bun = bun;
-                        s.nfu = do_f ? __popc(fun) : 0;
-                        s.nbu = do_b ? __popc(bun) : 0;
+                        s.nfu = (int16_t)(do_f ? __popc(fun) : 0);
+                        s.nbu = (int16_t)(do_b ? __popc(bun) : 0);
                         s.exf = 99;
                         s.exb = 99;
                         s.gf = 0;
@@ -1384,16 +1392,16 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
                 const bool back = u >= s.nfu;
                 const int k = back ? u - s.nfu : u;
                 const int ci = nth_set_bit(back ? s.bun : s.fun, k);
-                const cmc::CH ch{(back ? s.bch : s.fch) + ci, kmer};
+                const cmc::CH ch{(back ? slot_bch(s, chains) : slot_fch(s, chains)) + ci, kmer};
                 const cmc::Read frd{s.fseq, s.flen, 0}, brd{s.bseq, s.blen, 1};
                 cmc::MM m = cmc::mm_init(c);
-                sm.err = s.perr;
+                sm.err = slot_perr(s, ra.pair_err);
                 const int ex = ext.chain_both_sides(ch, back ? brd : frd, m, back ? -1 : 1);
                 atomicMin((int *)(back ? &s.exb : &s.exf), ex);
                 if (k == 0) {
                     cmc::overlap_to_spos(c, m);
                     cmc::overlap_to_epos(c, m);
-                    (back ? s.gb : s.gf) = (m.exons_spos >= 0) || (m.exons_epos >= 0);
+                    (back ? s.gb : s.gf) = (int8_t)((m.exons_spos >= 0) || (m.exons_epos >= 0));
                 }
             }
             __syncthreads();
@@ -2705,7 +2713,10 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     unsigned int *retry_ctr = ctx->d_retry_ctr + 2 * b;
     // str_cap: chars per staged string (multiple of 8); LDS = 2 strings x lbuf_bytes(str_cap) x 64 lanes
     // a DP string is at most a read minus one seed, plus the band (extend_side: len + band; dp_fits() reports anything longer)
-    const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + 4 + 7) / 8) * 8;
+    // (+ 4 characters of slack: 144 characters = 76-byte rows for 2 x 150 bp at k = 20.  CM_PAIR_LDS_SLACK=0 gives 72-byte rows and
+    // takes k_pair_heavy's LDS per wave from 12 to 11 allocation steps of 1 280 bytes: its kernel time -4 %, the step +1 %: NOTES 44)
+    static const int str_slack = getenv("CM_PAIR_LDS_SLACK") ? atoi(getenv("CM_PAIR_LDS_SLACK")) : 4;
+    const int str_cap = ((ctx->max_len - ctx->P.kmer + ctx->P.band + str_slack + 7) / 8) * 8;
     // The pair kernels' time hardly depends on their occupancy (16.0 / 16.2 / 16.4 ms per step at 4 / 3 / 2 waves per SIMD on the
     // hg38-like bench; 22 ms at 1).  CM_PAIR_OCC = 1..3 pads their LDS request to hold them at that many waves per SIMD, which
     // leaves registers and wave slots to the seeding / chaining of the next round; measured best overall: no padding (4).

@@ -295,6 +295,9 @@ struct cm_fastq {
     int max_ed = 4;
     bool any_prior = false;
     std::string err;
+    // cm_fastq_open_shard on input that cannot be cut at a byte offset (gzip, pipes): this reader inflates the stream from its start,
+    // steps over the first skip_left records and hands out take_left (~0: to the end of the input)
+    uint64_t skip_left = 0, take_left = ~0ull;
     cm_fastq() {
         for (Gen &g : gen) {                 // the arrays cm_fastq_batch::reads / prior point into
             g.a.seq.hook = g.a.off.hook = g.b.seq.hook = g.b.off.hook = &hook;
@@ -845,7 +848,40 @@ int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_i
     };
     // contiguous blocks of pairs need both files cut at the same RECORD: seekable plain text only (gzip members cannot be entered
     // in the middle, a pipe cannot be read twice)
-    if (!f->s1.plain || !f->s2.plain) return world == 1 ? CM_OK : fail(CM_EINVAL);
+    if (!f->s1.plain || !f->s2.plain) {
+        if (world == 1 && !n_pairs) return CM_OK;
+        // gzip members cannot be entered in the middle: the records are counted with one inflate pass over R1 (R1 decides, as
+        // everywhere), every rank then inflates from the start and steps over what belongs to the ranks before it.  Slow by
+        // nature (one zlib stream per file: ~ 0.4 M pairs/s) -- but the same contiguous blocks, hence the same output bytes after
+        // cm_merge_parts, as plain-text input.  A pipe cannot be read twice: refused.
+        struct stat sa;
+        if (stat(r1_path, &sa) != 0 || !S_ISREG(sa.st_mode)) return world == 1 ? CM_OK : fail(CM_EINVAL);
+        gzFile g = gzopen(r1_path, "rb");
+        if (!g) return fail(CM_EIO);
+        gzbuffer(g, 1u << 20);
+        std::vector<char> buf(4u << 20);
+        uint64_t lines = 0;
+        char last = '\n';
+        for (;;) {
+            const int got = gzread(g, buf.data(), (unsigned)buf.size());
+            if (got < 0) {
+                gzclose(g);
+                return fail(CM_EIO);
+            }
+            if (got == 0) break;
+            lines += (uint64_t)std::count(buf.data(), buf.data() + got, '\n');
+            last = buf[(size_t)got - 1];
+        }
+        gzclose(g);
+        if (last != '\n') ++lines;                    // a last line without a newline still is a line
+        const uint64_t n1 = lines / 4;
+        const uint64_t lo = n1 * (uint64_t)rank / (uint64_t)world, hi = n1 * (uint64_t)(rank + 1) / (uint64_t)world;
+        f->skip_left = lo;
+        f->take_left = rank == world - 1 ? ~0ull : hi - lo;      // the last rank reads on: what follows the last whole record is seen (and refused) as in one process
+        if (first_pair) *first_pair = lo;
+        if (n_pairs) *n_pairs = hi - lo;
+        return CM_OK;
+    }
     struct stat sa, sb;
     if (fstat(fileno(f->s1.plain), &sa) != 0 || fstat(fileno(f->s2.plain), &sb) != 0) return fail(CM_EIO);
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
@@ -904,6 +940,14 @@ static int fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     // serial section (src/circminer.cpp:373-379), which is its ingest ceiling.
     uint64_t n = fast ? n_fast : 0, n2 = fast ? n2_fast : 0;
     int bad2 = 0;
+    if (!fast && f->skip_left) {                       // a shard of gzip input: the records of the ranks before this one
+        const char *lp;
+        size_t ll;
+        for (; f->skip_left; --f->skip_left)
+            for (int k = 0; k < 4; ++k)
+                if (!f->s1.line(lp, ll) || !f->s2.line(lp, ll)) return (f->s1.io_error || f->s2.io_error) ? CM_EIO : CM_EINVAL;
+    }
+    if (!fast && f->take_left < max_pairs) max_pairs = f->take_left;
     std::thread side_b([&]() {
         guarded([&]() {
             while (!fast && n2 < max_pairs) {
@@ -939,6 +983,7 @@ static int fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out) {
     if (g_raw_oom.exchange(0)) return CM_ENOMEM;
     if (f->s1.io_error || f->s2.io_error) return CM_EIO;
     if (bad1 || bad2 || n2 < n) return CM_EINVAL;                   // malformed record, or R2 ends before R1
+    if (!fast && f->take_left != ~0ull) f->take_left -= n;
     if (n2 > n) {        // R1 ended first: like the reference, which stops at R1's end, the surplus R2 records are not paired
         G.b.off.resize(n + 1);
         G.b.seq.resize(G.b.off[n]);

@@ -94,10 +94,11 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         cm_ctx *cm = nullptr;
     } pin;
     std::vector<std::pair<void *, uint64_t>> &pinned = pin.v;
-    std::thread writer, parser, gtf_thread;
+    std::thread writer, parser, gtf_thread, free_thread;
     int writer_rc = CM_OK, parser_rc = CM_OK;
     int rc = CM_OK;
     auto cleanup = [&]() {
+        if (free_thread.joinable()) free_thread.join();
         if (gtf_thread.joinable()) gtf_thread.join();           // it reads chrs
         if (parser.joinable()) parser.join();
         if (writer.joinable()) writer.join();
@@ -264,7 +265,8 @@ extern "C" int cm_mapping_run(const cm_mapping_args *a, cm_mapping_stats *stats,
         views.clear();                                              // (their arrays went back after each upload)
         // everything is in HBM: the file handle's buffers (two sets of raw records on the full-format path, ~ 19 GB for hg38)
         // are dead weight from here on -- per process, and there is one process per GPU
-        cm_host_close_index(idx);
+        // (on a thread of its own: returning that much memory takes about a second, and nothing waits for it)
+        free_thread = std::thread([h = idx]() { cm_host_close_index(h); });
         idx = nullptr;
         lap("load done", t0);
     }

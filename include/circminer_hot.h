@@ -392,8 +392,10 @@ int cm_fastq_open(const char *r1_path, const char *r2_path, const cm_chr_info *c
                   cm_fastq **out);
 /* One rank's contiguous block of pairs of a paired FASTQ ("rank r gets pairs [r*N/W, (r+1)*N/W)"): both files
  * are cut at the same record, found by counting the newlines of the files in blocks on n_threads threads (no parsing).
- * Needs seekable plain-text input when world > 1 (CM_EINVAL for gzip / pipes).  first_pair / n_pairs (nullable): the
- * block's position in the whole input.  Every rank of a node can open its share at the same time. */
+ * gzip files (the reference reads .gz everywhere, src/fastq_parser.cpp:84-98) cannot be entered in the middle: their records are
+ * counted with one inflate pass over R1 and every rank inflates from the start, stepping over the blocks of the ranks before it --
+ * the same blocks and output bytes as plain text, at zlib's speed.  A pipe cannot be read twice: CM_EINVAL when world > 1.
+ * first_pair / n_pairs (nullable): the block's position in the whole input.  Every rank of a node can open its share at the same time. */
 int cm_fastq_open_shard(const char *r1_path, const char *r2_path, const cm_chr_info *chrs, uint32_t n_chr, int32_t max_ed,
                         int32_t rank, int32_t world, int n_threads, cm_fastq **out, uint64_t *first_pair, uint64_t *n_pairs);
 int cm_fastq_next(cm_fastq *f, uint64_t max_pairs, cm_fastq_batch *out);   /* out->reads.n_pairs == 0 at the end; CM_ENOMEM when a batch array cannot grow */

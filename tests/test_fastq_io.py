@@ -435,7 +435,7 @@ def test_fifo_and_gzip_fifo_input(built, tmp_path):
 def test_sharded_reader_blocks(built, tmp_path):
     """cm_fastq_open_shard: rank r of W gets the pairs [r*N/W, (r+1)*N/W) of both files, cut at the same record
     although the two files have different record sizes; the blocks of all ranks, in rank order, are the unsharded input.  Ragged
-    reads, last record without a newline, R2 longer than R1, more ranks than pairs; gzip input cannot be sharded."""
+    reads, last record without a newline, R2 longer than R1, more ranks than pairs; gzip input gives the same blocks."""
     import gzip
     rng = np.random.default_rng(3)
     n = 4001
@@ -480,13 +480,27 @@ def test_sharded_reader_blocks(built, tmp_path):
         sizes.append(0 if b is None else b.n)
         rd.close()
     assert sum(sizes) == 2 and max(sizes) == 1
-    gz = str(tmp_path / "g_1.fq.gz")
-    with gzip.open(gz, "wb") as f:
-        f.write(open(tiny1, "rb").read())
-    with pytest.raises(RuntimeError):
-        cl.FastqReader(gz, tiny2, CHRS, 4, rank=0, world=2)
     with pytest.raises(RuntimeError):
         cl.FastqReader(tiny1, tiny2, CHRS, 4, rank=2, world=2)
+    # gzip input (the reference reads .gz everywhere): the same blocks, found by counting R1's records with an inflate pass; a mix
+    # of one gzip and one plain file works too (both then go through the record-by-record parser)
+    g1, g2 = str(tmp_path / "s_1.fq.gz"), str(tmp_path / "s_2.fq.gz")
+    for src, dst in ((p1, g1), (p2, g2)):
+        with gzip.open(dst, "wb") as f:
+            f.write(open(src, "rb").read())
+    p1_plain, p2_plain = p1, p2
+    for a, b in ((g1, g2), (g1, p2_plain)):
+        p1, p2 = a, b
+        for world in (1, 3):
+            got, at = [], 0
+            for r in range(world):
+                part, first, cnt = block(r, world)
+                if world > 1:
+                    assert first == at == n * r // world and cnt == len(part) == n * (r + 1) // world - n * r // world
+                got += part
+                at += len(part)
+            assert got == whole, (a, b, world)
+    p1, p2 = p1_plain, p2_plain
 
 
 @pytest.mark.parametrize("serial", [False, True])

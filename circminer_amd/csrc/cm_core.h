@@ -831,11 +831,17 @@ CM_HD inline void stage(const SV &v, int n, const LBuf &d, uint8_t other) {
 #if defined(__HIP_DEVICE_COMPILE__)
     CM_S uint32_t *dw = (CM_S uint32_t *)d.b;
     const int nw = (n + 7) >> 3;                   // words of eight codes
-    for (int w0 = 0; w0 < nw; w0 += 2) {
-        uint32_t q[4];
-        load_codes16(v, 2 * w0, other, q);         // characters 8*w0 .. 8*w0+15
-        dw[w0 * LSTRIDE] = pack_nibbles(q[0]) | (pack_nibbles(q[1]) << 16);
-        if (w0 + 1 < nw) dw[(w0 + 1) * LSTRIDE] = pack_nibbles(q[2]) | (pack_nibbles(q[3]) << 16);
+    for (int w0 = 0; w0 < nw; w0 += 8) {           // four 16-character loads in flight per trip to memory (they used to go one by one)
+        uint32_t q[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (w0 + 2 * u < nw) load_codes16(v, 2 * (w0 + 2 * u), other, q[u]);         // characters 8*w .. 8*w+15, w = w0 + 2u
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w0 + 2 * u;
+            if (w < nw) dw[w * LSTRIDE] = pack_nibbles(q[u][0]) | (pack_nibbles(q[u][1]) << 16);
+            if (w + 1 < nw) dw[(w + 1) * LSTRIDE] = pack_nibbles(q[u][2]) | (pack_nibbles(q[u][3]) << 16);
+        }
     }
 #else
     for (int i = 0; i < n; ++i) d.put(i, v.mode == 2 ? other : code1(v.p[v.off + i * v.step], v.mode == 1, other));
@@ -867,6 +873,29 @@ CM_HD inline int prefix_mismatches(const SV &a, const SV &b, int len) {
     }
 #endif
     return mm;
+}
+// prefix_mismatches(a, b, len) == 0, leaving at the first 16 bases that differ
+CM_HD inline bool prefix_equal(const SV &a, const SV &b, int len) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int w0 = 0; 4 * w0 < len; w0 += 4) {
+        uint32_t qa[4], qb[4];
+        load_codes16(a, w0, 4, qa);
+        load_codes16(b, w0, 5, qb);
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int base = 4 * (w0 + k);
+            uint32_t x = qa[k] ^ qb[k];
+            if (base >= len) x = 0;
+            else if (len - base < 4) x &= (1u << (8 * (len - base))) - 1u;
+            any |= x;
+        }
+        if (any) return false;
+    }
+    return true;
+#else
+    return prefix_mismatches(a, b, len) == 0;
+#endif
 }
 CM_HD inline int ldiff(uint8_t a, uint8_t b) { return a == b ? 0 : 1; }
 CM_HD inline int lscore(uint8_t a, uint8_t b) { return a == b ? SC_MAT : SC_MIS; }
@@ -1204,22 +1233,31 @@ CM_HD inline bool xdrop_w3_rel(XdropW3R &x, const LBuf &s, int n, const LBuf &tr
 //  * the substitution scores of an anti-diagonal come from one XOR of two nibble windows (the read residual is staged
 //    reversed for this: `tr`); the best cell is kept as (row, anti-diagonal), its score is cur_optimum;
 //  * beyond the first two anti-diagonals (boundary cells) the cells live in a relative score domain (xdrop_w3_rel).
-CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &tr, int m, int &sc_len, int &indel, int &align_score) {
+// One band-3 DP in flight, resumable two anti-diagonals at a time: local_alignment_sc_w3 runs one to its end; the DP engine of
+// k_pair_heavy keeps one per lane and hands a lane the next queued request as soon as its DP has ended.
+struct XdropLane {
+    XdropW3R y;
+    int k, kmax, n, m;
+    bool go;                 // anti-diagonals left
+};
+CM_HD inline void xdrop_w3_begin(XdropLane &L, const LBuf &s, int n, const LBuf &tr, int m, int top) {
     constexpr int W = 3;
     XdropW3 x;
-    XdropW3R y;
     x.on_s = x.on_k = x.cur_optimum = 0;
-    bool go = false;
-    const int top = (s.cap < tr.cap ? s.cap : tr.cap) - 1;
-    const int kmax = m + n;
+    x.pre_optimum = 0;
+    x.lb = x.ub = 1;
+    x.pre_ub = 0;
+    L.go = false;
+    L.n = n;
+    L.m = m;
+    L.kmax = m + n;
+    L.k = 4;
     if (m > 0 && n > 0) {
 #pragma unroll
         for (int q = 0; q < 2 * W + 3; ++q) x.d[q] = (q == W + 1) ? 0 : ((q == W + 2 || q == W) ? SC_IND : -DPTINF);
-        x.pre_optimum = 0;
-        x.lb = x.ub = 1;
-        x.pre_ub = 0;
-        go = xdrop_w3_step<0, true>(x, s, n, tr, m, 2, top) && kmax >= 3 && xdrop_w3_step<1, true>(x, s, n, tr, m, 3, top);
+        L.go = xdrop_w3_step<0, true>(x, s, n, tr, m, 2, top) && L.kmax >= 3 && xdrop_w3_step<1, true>(x, s, n, tr, m, 3, top);
     }
+    XdropW3R &y = L.y;
 #pragma unroll
     for (int q = 0; q < 2 * W + 3; ++q) {        // into the relative domain: every slot holds anti-diagonal 2 or 3 (offset 1)
         const int d = (m > 0 && n > 0) ? x.d[q] : -DPTINF;
@@ -1233,23 +1271,24 @@ CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n,
     y.on_s = x.on_s;
     y.on_k = x.on_k;
     y.alive_prev = x.pre_ub != -1;
-#if defined(CM_ABL_NODP)        // ablation study only (tests/diag/ablate.sh): what the kernels issue without the DP's main loop (results wrong)
-    go = false;
-#endif
-    for (int k = 4;; k += 2) {
-        go = go && k <= kmax;
-        if (!CM_ANY_LANE(go)) break;
-        if (go) {
-            if (!xdrop_w3_rel<0>(y, s, n, tr, m, k, top)) go = false;
-            else if (k + 1 > kmax) go = false;
-            else if (!xdrop_w3_rel<1>(y, s, n, tr, m, k + 1, top)) go = false;
-        }
-    }
-    const int score = y.cur_optimum, on_s = y.on_s, on_t = y.on_k - y.on_s;
+    L.go = L.go && L.k <= L.kmax;
+}
+// anti-diagonals k, k + 1 of a DP that has some left (L.go)
+CM_HD inline void xdrop_w3_advance(XdropLane &L, const LBuf &s, const LBuf &tr, int top) {
+    const int k = L.k;
+    if (!xdrop_w3_rel<0>(L.y, s, L.n, tr, L.m, k, top)) L.go = false;
+    else if (k + 1 > L.kmax) L.go = false;
+    else if (!xdrop_w3_rel<1>(L.y, s, L.n, tr, L.m, k + 1, top)) L.go = false;
+    L.k = k + 2;
+    L.go = L.go && L.k <= L.kmax;
+}
+CM_HD inline int xdrop_w3_end(const Core &c, const XdropLane &L, int &sc_len, int &indel, int &align_score) {
+    constexpr int W = 3;
+    const int score = L.y.cur_optimum, on_s = L.y.on_s, on_t = L.y.on_k - L.y.on_s;
     const uint32_t ed = (uint32_t)((SC_MAT * cmax(on_s, on_t) - score) / (SC_MAT - SC_MIS));
-    Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, m) + 1, W + 1, 0};
+    Cand best{c.P.max_ed + 1, cmax(c.P.max_sc, L.m) + 1, W + 1, 0};
     if (ed <= (uint32_t)c.P.max_ed) {
-        Cand z{(int)ed, m - on_t, on_t - on_s, score};
+        Cand z{(int)ed, L.m - on_t, on_t - on_s, score};
         best = z;
     }
     align_score = score;
@@ -1257,13 +1296,52 @@ CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n,
     indel = best.indel;
     return best.ed;
 }
+CM_HD CM_NOINLINE int local_alignment_sc_w3(const Core &c, const LBuf &s, int n, const LBuf &tr, int m, int &sc_len, int &indel, int &align_score) {
+    const int top = (s.cap < tr.cap ? s.cap : tr.cap) - 1;
+    XdropLane L;
+    xdrop_w3_begin(L, s, n, tr, m, top);
+#if defined(CM_ABL_NODP)        // ablation study only (tests/diag/ablate.sh): what the kernels issue without the DP's main loop (results wrong)
+    L.go = false;
+#endif
+    // (every lane of the wave starts at k = 4 here, so the counter is wave-uniform -- a scalar -- for as long as any lane runs)
+    for (int k = 4; CM_ANY_LANE(L.go); k += 2) {
+        if (L.go) {
+            L.k = k;
+            xdrop_w3_advance(L, s, tr, top);
+        }
+    }
+    return xdrop_w3_end(c, L, sc_len, indel, align_score);
+}
 
+// A soft-clip X-drop DP computed ahead of the code that asks for it (k_pair_heavy: the DPs of a whole wave's tasks are collected,
+// sorted by length and run 64 at a time, instead of every lane running its own whenever its control flow arrives there).
+// The DP is a pure function of its two strings; an entry carries the identity of the request it answers -- reference window
+// (offset, direction, length), read residual (offset inside the read, which of the pair's two read views, length) -- and
+// local_alignment_sc() takes an entry only if every field matches the call, so a request nobody predicted, or predicted
+// differently, is simply computed in place: results never depend on what the table holds.
+struct PreDP {
+    uint32_t s_off;          // SV::off of the reference window (as passed: the far end for a reversed window)
+    uint32_t key;            // n | m << 10 | t.off << 20 | (s.step < 0) << 30 | (t.mode == 1) << 31
+    uint32_t res;            // ed | sclen << 8 | (indel + 64) << 20 | 1 << 31 (valid)
+    int32_t score;
+};
+typedef CM_G const PreDP *g_pre;          // the table lives in the wave's slice of a global scratch area (L2-resident)
+CM_HD inline bool pre_keyable(const SV &s, int n, const SV &t, int m) {
+    return n >= 0 && n < 1024 && m >= 0 && m < 1024 && t.off >= 0 && t.off < 1024 && s.mode == 0 && t.mode != 2;
+}
+CM_HD inline uint32_t pre_key(const SV &s, int n, const SV &t, int m) {
+    return (uint32_t)n | ((uint32_t)m << 10) | ((uint32_t)t.off << 20) | (s.step < 0 ? 1u << 30 : 0u) | (t.mode == 1 ? 1u << 31 : 0u);
+}
+CM_HD inline uint32_t pre_pack(int ed, int sclen, int indel) { return (uint32_t)ed | ((uint32_t)sclen << 8) | ((uint32_t)(indel + 64) << 20) | (1u << 31); }
 // Staging + dispatch on the (wave-uniform) band.  `sm` = the lane's two staging buffers.
+#if !(defined(CM_DIAG) && defined(CM_DIAG_CNT) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__))
+#define CM_CNT(sm_, k) ((void)0)      // event counts of a diagnostic build (-DCM_DIAG -DCM_DIAG_CNT; contended atomics: not together with the timers)
+#endif
 #if defined(CM_DIAG) && defined(__HIPCC__)
 // Diagnostic section timers.  acc[]: per-lane time between ticks (includes waiting for other lanes).
 // w (LDS, one per wave): w[0] = time of the wave's last tick, w[1+id] += wave time attributed to section id,
 // w[33+id] += that time x lanes arriving at the tick together.
-struct Tick { unsigned long long last; unsigned long long acc[32]; CM_L unsigned long long *w; int wave_on; };
+struct Tick { unsigned long long last; unsigned long long acc[32]; CM_L unsigned long long *w; int wave_on; unsigned long long *ctr; };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline void cm_tick(Tick *tk, int id) {
     const unsigned long long n_ = wall_clock64();
@@ -1281,16 +1359,19 @@ __device__ inline void cm_tick(Tick *tk, int id) {
     }
 }
 #define CM_TICK(sm_, id) cm_tick((sm_).tk, id)
+#if defined(CM_DIAG_CNT)
+#define CM_CNT(sm_, k) do { if ((sm_).tk->ctr) atomicAdd(&(sm_).tk->ctr[k], 1ull); } while (0)      // event counts (cm_debug_counters)
+#endif
 #else
 #define CM_TICK(sm_, id) ((void)0)
 #endif
-struct DpMem { LBuf a, b; g_err err; Tick *tk; g_spill spill; int spill_cap; };
+struct DpMem { LBuf a, b; g_err err; Tick *tk; g_spill spill; int spill_cap; g_pre pre; int n_pre; };
 #elif defined(CM_STAGE2_HOST)
 #define CM_TICK(sm_, id) ((void)0)
-struct DpMem { LBuf a, b; g_err err; bool edit; g_spill spill; int spill_cap; };      // edit: EditDistAlignment instead of DropAlignment (ProcessCirc, src/process_circ.cpp:25)
+struct DpMem { LBuf a, b; g_err err; bool edit; g_spill spill; int spill_cap; g_pre pre; int n_pre; };      // edit: EditDistAlignment instead of DropAlignment (ProcessCirc, src/process_circ.cpp:25)
 #else
 #define CM_TICK(sm_, id) ((void)0)
-struct DpMem { LBuf a, b; g_err err; g_spill spill; int spill_cap; };   // spill: see Memo (null in the first pass of a pair)
+struct DpMem { LBuf a, b; g_err err; g_spill spill; int spill_cap; g_pre pre; int n_pre; };   // spill: see Memo (null in the first pass of a pair); pre: see PreDP
 #endif
 CM_HD inline bool dp_fits(const DpMem &sm, int n, int m) {
     if (n <= sm.a.cap && m <= sm.b.cap && n >= 0 && m >= 0) return true;
@@ -1376,6 +1457,22 @@ inline int local_alignment_sc_edit(const Core &c, const LBuf &s, int n, const LB
     return best.ed;
 }
 #endif
+// The two halves of local_alignment_sc (below), also called one after the other on other lanes by the DP pool of k_pair_heavy.
+// sc_closed_form: the read residual equals the start of the reference window base for base (closed form, see above).
+CM_HD inline bool sc_closed_form(const SV &s, int n, const SV &t, int m) { return m >= 1 && n >= m && prefix_equal(s, t, m); }
+// sc_run_dp: staging + the DP proper (the strings fit the staging buffers: dp_fits)
+CM_HD inline int sc_run_dp(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
+    const bool w3 = c.P.band == 3;
+    CM_HOOK_DP(1, s, n, t, m);
+    stage(s, n, sm.a, 4);
+    stage(w3 ? t.rev(m) : t, m, sm.b, 5);                     // the band-3 DP walks the read residual from its far end
+    CM_STAT(11 + (m > 16) + (m > 32) + (m > 64), 1);          // X-drop DPs by read-residual length (test-only counters)
+    CM_TICK(sm, 27);
+    const int r = w3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
+                     : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
+    CM_TICK(sm, 28);
+    return r;
+}
 // the caller passes already-reversed views for the left variant
 CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s, int n, const SV &t, int m, int &sc_len, int &indel, int &align_score) {
     CM_TICK(sm, 24);
@@ -1388,7 +1485,22 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
         return local_alignment_sc_edit(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
     }
 #endif
-    if (m >= 1 && n >= m && prefix_mismatches(s, t, m) == 0) {
+    if (sm.pre && pre_keyable(s, n, t, m)) {                  // computed ahead (PreDP)?
+        // the entries of an item sit in a fixed order -- [forward read: left end, right end][backward read: left, right] (n_pre = 4)
+        // or [left end, right end] (n_pre = 2) -- so the call's own views say which one could be its answer: one load
+        const uint32_t key = pre_key(s, n, t, m);
+        const int at = (s.step < 0 ? 0 : 1) + (sm.n_pre == 4 && t.mode == 1 ? 2 : 0);
+        const PreDP e = sm.pre[at];
+        if ((e.res >> 31) && e.key == key && e.s_off == (uint32_t)s.off) {
+            CM_CNT(sm, 10);
+            sc_len = (int)((e.res >> 8) & 0xFFFu);
+            indel = (int)((e.res >> 20) & 0x7Fu) - 64;
+            align_score = e.score;
+            return (int)(e.res & 0xFFu);
+        }
+    }
+    if (sc_closed_form(s, n, t, m)) {
+        CM_CNT(sm, 13);
         CM_STAT(9, 1);
         sc_len = 0;
         indel = 0;
@@ -1398,16 +1510,8 @@ CM_HD inline int local_alignment_sc(const Core &c, const DpMem &sm, const SV &s,
     }
     CM_TICK(sm, 26);
     if (!dp_fits(sm, n, m)) { sc_len = cmax(c.P.max_sc, m) + 1; indel = c.P.band + 1; align_score = 0; return c.P.max_ed + 1; }
-    const bool w3 = c.P.band == 3;
-    CM_HOOK_DP(1, s, n, t, m);
-    stage(s, n, sm.a, 4);
-    stage(w3 ? t.rev(m) : t, m, sm.b, 5);                     // the band-3 DP walks the read residual from its far end
-    CM_STAT(11 + (m > 16) + (m > 32) + (m > 64), 1);          // X-drop DPs by read-residual length (test-only counters)
-    CM_TICK(sm, 27);
-    const int r = w3 ? local_alignment_sc_w3(c, sm.a, n, sm.b, m, sc_len, indel, align_score)
-                     : local_alignment_sc_impl<0>(c, sm.a, n, sm.b, m, sc_len, indel, align_score);
-    CM_TICK(sm, 28);
-    return r;
+    CM_CNT(sm, 11);
+    return sc_run_dp(c, sm, s, n, t, m, sc_len, indel, align_score);
 }
 
 
@@ -2014,6 +2118,19 @@ struct Ext {
         end_step(memo, key, lepos, (uint32_t)remain_ref_len, q, qlen - covered, ed_th, best, curr, exon_res, false);
     }
 
+    // The genome fall-back of extend_right / extend_left (src/extend.cpp:334-343, 410-419): the window of len + band bases next to
+    // orig_pos against the whole residual q (len chars), as local_alignment_sc takes them.  Shared with the DP pool of k_pair_heavy,
+    // which must predict exactly these views.
+    CM_HD bool fallback_views(uint32_t orig_pos, int len, const SV &q, bool right, SV &s, int &n, SV &t, int &m) const {
+        const int ref_len = len + c.P.band;
+        SV ref;
+        if (!pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) return false;
+        s = right ? ref : ref.rev(ref_len);
+        t = right ? q : q.rev(len);
+        n = ref_len;
+        m = len;
+        return true;
+    }
     // extend_right / extend_left, src/extend.cpp:285-432; q = the residual (len chars)
     CM_HD bool extend_side(const TidList &tl, const SV &q, uint32_t &pos, int len, int ed_th, uint32_t bound, AlignRes &best,
                            bool right) const {
@@ -2049,11 +2166,11 @@ struct Ext {
             pos = right ? best.pos - sclen_best : best.pos + sclen_best;
             if (best.qcovlen >= seq_len && sclen_best <= c.P.max_sc) return true;
         }
-        SV ref;
-        if (!consecutive && pac2char(c, right ? orig_pos + 1 : orig_pos - ref_len, ref_len, ref)) {
+        SV fs, ft;
+        int fn, fm;
+        if (!consecutive && fallback_views(orig_pos, len, q, right, fs, fn, ft, fm)) {
             int indel, sc;
-            if (right) min_ed = local_alignment_sc(c, sm, ref, ref_len, q, seq_len, sclen_best, indel, sc);
-            else min_ed = local_alignment_sc(c, sm, ref.rev(ref_len), ref_len, q.rev(seq_len), seq_len, sclen_best, indel, sc);
+            min_ed = local_alignment_sc(c, sm, fs, fn, ft, fm, sclen_best, indel, sc);
             CM_TICK(sm, 12);
             if (min_ed <= ed_th && sclen_best <= c.P.max_sc) {
                 const uint32_t np = right ? orig_pos + seq_len - indel : orig_pos - seq_len + indel;

@@ -1450,6 +1450,8 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
 #endif
 }
 
+#include "cm_heavy_pipe.h"
+
 __global__ void __launch_bounds__(BLK) k_active_cls(const uint8_t *active, uint64_t n, int8_t *cls) {
     const uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     if (i < n) cls[i] = active[i] ? 0 : -2;
@@ -1716,6 +1718,16 @@ struct cm_ctx {
     unsigned int *d_col_blk = nullptr, *d_col_ctr = nullptr;
     uint32_t *d_hlist = nullptr;
     HRes *d_hres = nullptr;          // task outcomes of k_pair_heavy: 64 per resident block
+    // the heavy pairs as a pipeline of kernels (cm_heavy_pipe.h)
+    HPair *d_hp = nullptr;
+    uint32_t *d_hp_list2 = nullptr, *d_hp_fall = nullptr, *d_hp_q = nullptr, *d_hp_q2 = nullptr;
+    HTask *d_hp_T = nullptr;
+    HUnp *d_hp_U = nullptr;
+    cmc::PreDP *d_hp_pre = nullptr, *d_hp_pre2 = nullptr;
+    HRes *d_hp_res = nullptr;
+    uint16_t *d_hp_lists = nullptr;
+    unsigned int *d_hp_ctr = nullptr;
+    uint32_t hp_tasks_cap = 0, hp_unp_cap = 0;
     unsigned long long *d_type_hist = nullptr;
     unsigned int *d_retry_ctr = nullptr;                          // [set][count, cursor]
     unsigned long long *d_heavy_load = nullptr;                   // cost beyond HEAVY_COST summed over the tile in the pair stage (k_pair_cost)
@@ -1803,6 +1815,8 @@ void free_reads(cm_ctx *c) {
     dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b);
     dfree(c, c->d_dpscore); dfree(c, c->d_dpprev); dfree(c, c->d_chains); dfree(c, c->d_nchain); dfree(c, c->d_high);
     dfree(c, c->d_pool); dfree(c, c->d_lane_clk); dfree(c, c->d_cls); dfree(c, c->d_cls4); dfree(c, c->d_perm4); dfree(c, c->d_resid); dfree(c, c->d_perm); dfree(c, c->d_cls_ctr); dfree(c, c->d_cls_ctr2); dfree(c, c->d_cls_sub); dfree(c, c->d_perm1); dfree(c, c->d_cls_ctr3); dfree(c, c->d_cls_sub2); dfree(c, c->d_perm0); dfree(c, c->d_blk_cnt); dfree(c, c->d_hlist); dfree(c, c->d_hres);
+    dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_U);
+    dfree(c, c->d_hp_pre); dfree(c, c->d_hp_pre2); dfree(c, c->d_hp_res); dfree(c, c->d_hp_lists); dfree(c, c->d_hp_ctr);
     dfree(c, c->d_pair_err); dfree(c, c->d_retry_list); dfree(c, c->d_spill); dfree(c, c->d_type_hist); dfree(c, c->d_retry_ctr); dfree(c, c->d_heavy_load);
     dfree(c, c->d_col_cls); dfree(c, c->d_col_perm); dfree(c, c->d_col_blk); dfree(c, c->d_col_ctr);
     if (c->stream_copy) report_hip(c, "hipStreamSynchronize(copy stream)", hipStreamSynchronize(c->stream_copy));
@@ -1887,6 +1901,12 @@ SeedBufs seed_bufs(cm_ctx *c, int s) {
     return s ? SeedBufs{c->d_sstart_b, c->d_scnt_b, c->d_sraw_b, c->d_celloff_b, c->d_bsum_b, c->d_bmax_b, c->d_cls4_b, c->d_cblk_b, c->d_cctr_b, c->d_perm4_b,
                         c->d_pool_cursor + 1}
              : SeedBufs{c->d_sstart, c->d_scnt, c->d_sraw, c->d_celloff, c->d_bsum, c->d_bmax, c->d_cls4, c->d_cblk, c->d_cctr, c->d_perm4, c->d_pool_cursor};
+}
+constexpr unsigned HP_PLAN_GRID = 2048;      // workgroups of k_hp_plan (each with its own task-list scratch)
+// CM_HEAVY_PIPELINE=0: the heavy pairs of a tile through k_pair_heavy alone (the round-3 path)
+static bool heavy_pipeline() {
+    static const bool v = !(getenv("CM_HEAVY_PIPELINE") && getenv("CM_HEAVY_PIPELINE")[0] == '0');
+    return v;
 }
 static unsigned long long chain_light_w() {
     static const unsigned long long v = getenv("CM_CHAIN_LIGHT_W") ? strtoull(getenv("CM_CHAIN_LIGHT_W"), nullptr, 10) : 256ull;
@@ -2508,6 +2528,25 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)HEAVY_GRID_MAX * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
+    if (heavy_pipeline()) {
+        // the pipeline's arrays: per heavy pair, per mate-pair task (~ 10 per heavy pair on the dense workload, room for 6 per pair of
+        // the tile), per unpaired chain (room for 4 per pair of the tile); what does not fit goes to k_pair_heavy
+        const size_t tc = std::max<size_t>((size_t)tile * 6, 4096), uc = std::max<size_t>((size_t)tile * 4, 4096);
+        ctx->hp_tasks_cap = (uint32_t)tc;
+        ctx->hp_unp_cap = (uint32_t)uc;
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp, (size_t)tile * sizeof(HPair)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_list2, (size_t)tile * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_fall, (size_t)tile * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_T, tc * sizeof(HTask)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_pre, tc * 4 * sizeof(cmc::PreDP)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_q, tc * 4 * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_res, tc * sizeof(HRes)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_U, uc * sizeof(HUnp)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_pre2, uc * 2 * sizeof(cmc::PreDP)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_q2, uc * 2 * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_lists, (size_t)HP_PLAN_GRID * HEAVY_LIST * 2));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_ctr, HC_WORDS * sizeof(unsigned int)));
+    }
     {
         const uint32_t *before = ctx->d_pair_err;
         HIPCHK(ctx, ensure(ctx, ctx->d_pair_err, (size_t)tile * 4 * 2));      // one set per set of chain records (run_pair_tile)
@@ -2801,11 +2840,44 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         static const unsigned heavy_fix = getenv("CM_HEAVY_GRID") ? (unsigned)atoi(getenv("CM_HEAVY_GRID")) : 0u;    // tuning knob
         const unsigned heavy_lim = std::min(heavy_fix ? heavy_fix : heavy_cap, HEAVY_GRID_MAX);     // d_hres is sized for HEAVY_GRID_MAX blocks
         const unsigned heavy_grid = nt < heavy_lim ? (nt ? nt : 1u) : heavy_lim;
+        if (heavy_pipeline() && ctx->P.band == 3) {
+            // the heavy pairs as a pipeline of full-width kernels (cm_heavy_pipe.h); what does not fit its arrays comes back in a
+            // fall-back list and goes through k_pair_heavy behind it
+            const HPipe hp{ctx->d_hp, ctx->d_hp_list2, ctx->d_hp_fall, ctx->d_hp_T, ctx->d_hp_pre, ctx->d_hp_q, ctx->d_hp_res, ctx->d_hp_U, ctx->d_hp_pre2,
+                           ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap};
+            const unsigned int *n_heavy = ctx->d_cls_ctr + HEAVY_CLS, *n_list2 = ctx->d_hp_ctr + HC_LIST2;
+            static const unsigned pipe_grid = getenv("CM_HP_GRID") ? (unsigned)atoi(getenv("CM_HP_GRID")) : 2048u;        // tuning knob: workgroups of the item kernels
+            const size_t lds_slots = HG * sizeof(HSlot);
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_hp_ctr, 0, HC_WORDS * sizeof(unsigned int), sp2));
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (attempt) hipLaunchKernelGGL(k_hp_reset, dim3(1), dim3(64), 0, sp2, ctx->d_hp_ctr);
+                hipLaunchKernelGGL(k_hp_plan, dim3(HP_PLAN_GRID), dim3(BLK_PAIR), lds_slots, sp2, core, rd, p0, (const uint32_t *)ctx->d_hlist, n_heavy,
+                                   (const uint32_t *)ctx->d_hp_list2, n_list2, attempt, (const cm_chain *)rb.chains, (const int32_t *)rb.nchain,
+                                   (const int32_t *)rb.high, (const cm_mapped_read *)ctx->d_state, hp, ctx->d_hp_lists, str_cap);
+                hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 0, str_cap);
+                hipLaunchKernelGGL(k_hp_tasks, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains,
+                                   (const int32_t *)rb.nchain, hp, pair_err, str_cap);
+                hipLaunchKernelGGL(k_hp_fold, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp);
+                hipLaunchKernelGGL(k_hp_unp_req, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, str_cap);
+                hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 1, str_cap);
+                hipLaunchKernelGGL(k_hp_unp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, pair_err,
+                                   str_cap);
+                hipLaunchKernelGGL(k_hp_finish, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
+                                   ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_counters, ra1);
+            }
+            // (k_pair_heavy's own work cursor, d_cls_ctr + CTR_NEXT + 1, is zeroed with the light kernel's)
+            hipLaunchKernelGGL(k_pair_heavy, dim3(std::min(heavy_grid, 256u)), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, (const uint32_t *)ctx->d_hp_fall,
+                               (const unsigned int *)(ctx->d_hp_ctr + HC_FALL), rb.chains, rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat,
+                               is_last_round, ctx->d_err, ctx->d_counters, str_cap, (unsigned long long *)nullptr, ctx->d_hres, ctx->d_cls_ctr + CTR_NEXT + 1,
+                               ra1);
+            ctx->launches[4] += 18;
+        } else {
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
                            ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres,
                            ctx->d_cls_ctr + CTR_NEXT + 1, ra1);
         ++ctx->launches[4];
+        }
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join_p, sp2));
     {

@@ -1625,6 +1625,8 @@ struct cm_ctx {
     // The pair stage of round r runs on its own pair of streams while `stream` / `stream2` already seed and chain round r + 1
     // (cm_map_rounds): seeds and chains are functions of (read, contig) only, the carried state enters in the pair stage.
     hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_p3 = nullptr;      // p3: the re-run launch of the pair stage (RetryArgs)
+    hipStream_t stream_o = nullptr;           // work classes + ordered lists of a pair stage, computed under the pair stage of the item before
+    hipEvent_t ev_order[2] = {nullptr, nullptr};      // ... of set b are complete
     // The re-run launch of a pair stage (RetryArgs), decided late: see settle_pair.
     struct Rerun {
         bool deferred = false;
@@ -2151,12 +2153,20 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         static std::atomic<unsigned> serial{0};
         ctx->id = ++serial;
     }
+    // CM_STREAM_PRIO (tuning knob): bit 0 = seeding and pair-ordering streams at the highest priority, bit 1 = the heavy-pair stream too
+    static const int prio_mask = getenv("CM_STREAM_PRIO") ? atoi(getenv("CM_STREAM_PRIO")) : 0;
+    int prio_lo = 0, prio_hi = 0;
+    if (prio_mask) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    auto mk_stream = [&](hipStream_t *st, bool high) { return high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_p2, hipStreamNonBlocking) != hipSuccess ||
+        mk_stream(&ctx->stream_p2, (prio_mask & 2) != 0) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p3, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess ||
+        mk_stream(&ctx->stream_o, (prio_mask & 1) != 0) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_order[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_order[1], hipEventDisableTiming) != hipSuccess ||
+        mk_stream(&ctx->stream_s, (prio_mask & 1) != 0) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_seed[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_seed[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_first[0], hipEventDisableTiming) != hipSuccess ||
@@ -2208,7 +2218,7 @@ void cm_destroy(cm_ctx *ctx) {
     // whichever context uses the device next.
     const std::pair<hipStream_t, const char *> streams[] = {{ctx->stream, "hipStreamSynchronize(main)"},        {ctx->stream2, "hipStreamSynchronize(heavy chains)"},
                                                             {ctx->stream_s, "hipStreamSynchronize(seeding)"},    {ctx->stream_p, "hipStreamSynchronize(pairs)"},
-                                                            {ctx->stream_p2, "hipStreamSynchronize(heavy pairs)"}, {ctx->stream_p3, "hipStreamSynchronize(re-run)"},
+                                                            {ctx->stream_p2, "hipStreamSynchronize(heavy pairs)"}, {ctx->stream_p3, "hipStreamSynchronize(re-run)"}, {ctx->stream_o, "hipStreamSynchronize(pair ordering)"},
                                                             {ctx->stream_copy, "hipStreamSynchronize(copy)"}};
     for (const auto &st : streams)
         if (st.first) report_hip(ctx, st.second, hipStreamSynchronize(st.first));
@@ -2233,9 +2243,9 @@ void cm_destroy(cm_ctx *ctx) {
     dfree(ctx, ctx->d_counters);
     if (ctx->h_pin) report_hip(ctx, "hipHostFree", hipHostFree(ctx->h_pin));
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail,
-                         ctx->ev_first[0], ctx->ev_first[1], ctx->ev_seed[0], ctx->ev_seed[1], ctx->ev_staged, ctx->ev_retired})
+                         ctx->ev_first[0], ctx->ev_first[1], ctx->ev_order[0], ctx->ev_order[1], ctx->ev_seed[0], ctx->ev_seed[1], ctx->ev_staged, ctx->ev_retired})
         if (e) report_hip(ctx, "hipEventDestroy", hipEventDestroy(e));
-    for (hipStream_t st : {ctx->stream_p3, ctx->stream_s, ctx->stream_p, ctx->stream_p2, ctx->stream_copy})
+    for (hipStream_t st : {ctx->stream_p3, ctx->stream_o, ctx->stream_s, ctx->stream_p, ctx->stream_p2, ctx->stream_copy})
         if (st) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(st));
     if (ctx->stream2 && ctx->stream2 != ctx->stream) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(ctx->stream2));
     if (ctx->stream) report_hip(ctx, "hipStreamDestroy", hipStreamDestroy(ctx->stream));
@@ -2525,8 +2535,8 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_cls4_b, (size_t)tile * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm4_b, (size_t)tile * 4 * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
-    HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4));
-    HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4 * 2));          // x 2: one per set of chain records, like the re-run list (run_pair_tile)
+    HIPCHK(ctx, ensure(ctx, ctx->d_hlist, (size_t)tile * 4 * 2));
     HIPCHK(ctx, ensure(ctx, ctx->d_hres, (size_t)HEAVY_GRID_MAX * (64 * sizeof(HRes) + HEAVY_SCRATCH)));
     if (heavy_pipeline()) {
         // the pipeline's arrays: per heavy pair, per mate-pair task (~ 10 per heavy pair on the dense workload, room for 6 per pair of
@@ -2556,7 +2566,7 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_retry_ctr, 4 * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_heavy_load, sizeof(unsigned long long)));
     HIPCHK(ctx, ensure(ctx, ctx->d_spill, (size_t)RETRY_GRID * BLK_PAIR * RETRY_SPILL * sizeof(cmc::MemoSpill)));
-    HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, CTR_WORDS * sizeof(unsigned int)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr, 2 * CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_ctr2, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls_sub, (size_t)tile));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm1, (size_t)tile * 4));
@@ -2744,8 +2754,15 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         if ((rc = settle_pair(ctx, b))) return rc;                       // this set's previous stage (its re-run list is about to be reused)
         if (same_tile_as_prev && (rc = settle_pair(ctx, b ^ 1))) return rc;
     }
-    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
-    if (same_tile_as_prev && ctx->pair_pending[b ^ 1]) HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_pair[b ^ 1], 0));
+    // The work classes and ordered lists of this stage (ten small launches) go to a stream of their own, so -- every array the pair
+    // kernels read from them existing once per set of chain records -- they are computed while the pair stage of the item before
+    // still runs, as soon as this item's chains are complete; behind that stage on the pair stream they were 1.7 ms per item with
+    // nothing else on the chip but the next item's seeding (12 % of the hg38-like step).
+    hipStream_t so = ctx->stream_o;
+    HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_prep[b], 0));
+    if (same_tile_as_prev && ctx->pair_pending[b ^ 1]) HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_pair[b ^ 1], 0));
+    uint32_t *const perm = ctx->d_perm + (size_t)b * ctx->tile, *const hlist = ctx->d_hlist + (size_t)b * ctx->tile;
+    unsigned int *const cls_ctr = ctx->d_cls_ctr + (size_t)b * CTR_WORDS;
     // (the re-run list, its counters and the per-pair flags exist once per set of chain records, like those: item i + 1 leaves
     // item i's alone, item i + 2 starts after ev_pair[b])
     uint32_t *pair_err = ctx->d_pair_err + (size_t)b * ctx->tile, *retry_list = ctx->d_retry_list + (size_t)b * ctx->tile;
@@ -2781,42 +2798,45 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             }
     }
     {
-        Timer t(ctx, 5, sp);
+        Timer t(ctx, 5, so);
         const uint32_t nbk = (nt + CLS_T - 1) / CLS_T;
         static const bool fixed_cost = getenv("CM_HEAVY_COST") != nullptr;             // tuning knob: no adaptive threshold
         static const int heavy_cost = fixed_cost ? atoi(getenv("CM_HEAVY_COST")) : HEAVY_COST;
         unsigned long long *load = nullptr;
         if (!fixed_cost) {
             load = ctx->d_heavy_load;
-            HIPCHK(ctx, hipMemsetAsync(load, 0, sizeof(unsigned long long), sp));
-            hipLaunchKernelGGL(k_pair_cost, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, rb.nchain, act_in, p0, nt, HEAVY_COST, load);
+            HIPCHK(ctx, hipMemsetAsync(load, 0, sizeof(unsigned long long), so));
+            hipLaunchKernelGGL(k_pair_cost, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, so, rb.nchain, act_in, p0, nt, HEAVY_COST, load);
             // the host learns the load of a tile one or two items late (no wait): good enough to size the next heavy grid
-            HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 4), load, sizeof(unsigned long long), hipMemcpyDeviceToHost, sp));
+            HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 4), load, sizeof(unsigned long long), hipMemcpyDeviceToHost, so));
             ctx->h_pin_nt = nt;
         }
-        hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, sp, core, rb.chains, rb.resid, rb.nchain, act_in, p0, nt, ctx->d_cls,
+        hipLaunchKernelGGL(k_pair_cls, dim3((nt + BLK - 1) / BLK), dim3(BLK), 0, so, core, rb.chains, rb.resid, rb.nchain, act_in, p0, nt, ctx->d_cls,
                            ctx->d_cat, heavy_cost, ctx->d_cls_sub, ctx->d_cls_sub2, act_out, (const unsigned long long *)load);
         // three-pass LSD radix sort, 16 x 16 x 16 classes: by the longest residual, by the set of extensions a pair needs,
         // then (stable) by its class
         const uint32_t *no_order = nullptr;
         const unsigned int *no_count = nullptr;
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
                            (uint32_t *)nullptr, no_order, no_count);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
                            (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
                            (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
                            (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, 1 << HEAVY_CLS, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, sp, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr, ctx->d_perm,
-                           ctx->d_hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, cls_ctr, 1 << HEAVY_CLS, N_CLS);
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, cls_ctr, perm,
+                           hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), sp));     // both work cursors
+    HIPCHK(ctx, hipMemsetAsync(cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), so));     // both work cursors
+    HIPCHK(ctx, hipEventRecord(ctx->ev_order[b], so));
+    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
+    HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_order[b], 0));
     HIPCHK(ctx, hipMemsetAsync(retry_ctr, 0, 2 * sizeof(unsigned int), sp));                     // re-run count + cursor of this set
     const RetryArgs ra1{pair_err, retry_list, retry_ctr, nullptr, 0, 1};
     // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
@@ -2845,13 +2865,13 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             // fall-back list and goes through k_pair_heavy behind it
             const HPipe hp{ctx->d_hp, ctx->d_hp_list2, ctx->d_hp_fall, ctx->d_hp_T, ctx->d_hp_pre, ctx->d_hp_q, ctx->d_hp_res, ctx->d_hp_U, ctx->d_hp_pre2,
                            ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap};
-            const unsigned int *n_heavy = ctx->d_cls_ctr + HEAVY_CLS, *n_list2 = ctx->d_hp_ctr + HC_LIST2;
+            const unsigned int *n_heavy = cls_ctr + HEAVY_CLS, *n_list2 = ctx->d_hp_ctr + HC_LIST2;
             static const unsigned pipe_grid = getenv("CM_HP_GRID") ? (unsigned)atoi(getenv("CM_HP_GRID")) : 2048u;        // tuning knob: workgroups of the item kernels
             const size_t lds_slots = HG * sizeof(HSlot);
             HIPCHK(ctx, hipMemsetAsync(ctx->d_hp_ctr, 0, HC_WORDS * sizeof(unsigned int), sp2));
             for (int attempt = 0; attempt < 2; ++attempt) {
                 if (attempt) hipLaunchKernelGGL(k_hp_reset, dim3(1), dim3(64), 0, sp2, ctx->d_hp_ctr);
-                hipLaunchKernelGGL(k_hp_plan, dim3(HP_PLAN_GRID), dim3(BLK_PAIR), lds_slots, sp2, core, rd, p0, (const uint32_t *)ctx->d_hlist, n_heavy,
+                hipLaunchKernelGGL(k_hp_plan, dim3(HP_PLAN_GRID), dim3(BLK_PAIR), lds_slots, sp2, core, rd, p0, (const uint32_t *)hlist, n_heavy,
                                    (const uint32_t *)ctx->d_hp_list2, n_list2, attempt, (const cm_chain *)rb.chains, (const int32_t *)rb.nchain,
                                    (const int32_t *)rb.high, (const cm_mapped_read *)ctx->d_state, hp, ctx->d_hp_lists, str_cap);
                 hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 0, str_cap);
@@ -2868,14 +2888,14 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             // (k_pair_heavy's own work cursor, d_cls_ctr + CTR_NEXT + 1, is zeroed with the light kernel's)
             hipLaunchKernelGGL(k_pair_heavy, dim3(std::min(heavy_grid, 256u)), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, (const uint32_t *)ctx->d_hp_fall,
                                (const unsigned int *)(ctx->d_hp_ctr + HC_FALL), rb.chains, rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat,
-                               is_last_round, ctx->d_err, ctx->d_counters, str_cap, (unsigned long long *)nullptr, ctx->d_hres, ctx->d_cls_ctr + CTR_NEXT + 1,
+                               is_last_round, ctx->d_err, ctx->d_counters, str_cap, (unsigned long long *)nullptr, ctx->d_hres, cls_ctr + CTR_NEXT + 1,
                                ra1);
             ctx->launches[4] += 18;
         } else {
-        hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, ctx->d_hlist, ctx->d_cls_ctr + HEAVY_CLS, rb.chains,
+        hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, hlist, cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
                            ctx->d_lane_clk ? ctx->d_lane_clk + (size_t)nt * 16 + (size_t)(nt / 64 + 1) * 64 : nullptr, ctx->d_hres,
-                           ctx->d_cls_ctr + CTR_NEXT + 1, ra1);
+                           cls_ctr + CTR_NEXT + 1, ra1);
         ++ctx->launches[4];
         }
     }
@@ -2886,8 +2906,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         static const unsigned light_fix = getenv("CM_PAIR_GRID") ? (unsigned)atoi(getenv("CM_PAIR_GRID")) : 0u;       // tuning knob
         const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = light_fix ? light_fix : 256u * 4u * slots_per_simd;   // light takes the slots heavy leaves: full cap
         hipLaunchKernelGGL(k_pair, dim3(want < cap ? want : cap), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
-                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, ctx->d_perm,
-                           ctx->d_cls_ctr + CTR_SUM, ctx->d_cls_ctr + CTR_NEXT, ra1);
+                           ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, perm,
+                           cls_ctr + CTR_SUM, cls_ctr + CTR_NEXT, ra1);
         HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_join_p, 0));
         ++ctx->launches[2];
     }
@@ -2925,6 +2945,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_tail, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_o, ctx->ev_tail, 0));
     uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
     // The work items: (tile, round).  One tile per batch: its rounds in order.  Several tiles: ROUND-major -- every tile through
     // round r, then every tile through round r + 1 -- so that between the pair stage of (tile, r) and the seeding of (tile, r + 1)
@@ -2988,7 +3009,19 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         const KCore core = make_core(ctx, sl);
         const RoundBufs rb = round_bufs(ctx, b);
         const uint8_t *act_prep = prep_flags(i);
-        auto ahead = [&]() -> int { return (seed_ahead && i + 1 < n_items) ? issue_seed(i + 1, ctx->stream_s) : CM_OK; };
+        // ... if the pair stage whose flags it reads (item i - 1 with two tiles) is over by then.  Otherwise the host would sit in
+        // settle_pair until it is, and this item's pair stage -- whose work classes and lists can be computed under that same stage
+        // (stream_o) -- would be issued late: then the seeding is issued behind this item's pair stage instead (`late`).
+        auto ahead = [&]() -> int {
+            if (!seed_ahead || i + 1 >= n_items || seeded[(size_t)i + 1]) return CM_OK;
+            const int bn = (ctx->item_base + i + 1) & 1;
+            if (ctx->rerun[bn].deferred && hipEventQuery(ctx->ev_first[bn]) != hipSuccess) {
+                (void)hipGetLastError();                                  // not ready
+                return CM_OK;
+            }
+            return issue_seed(i + 1, ctx->stream_s);
+        };
+        auto late = [&]() -> int { return (seed_ahead && i + 1 < n_items && !seeded[(size_t)i + 1]) ? issue_seed(i + 1, ctx->stream_s) : CM_OK; };
         if (use_pre && i == 0) {                                          // set b holds this item's chains, ev_prep[b] is recorded
             if ((rc = ahead())) return rc;
         } else {
@@ -3013,6 +3046,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         const int is_last = (r == n_rounds - 1) ? (last_is_final != 0) : 0;
         const bool same_tile = i > 0 && items[i - 1].p0 == p0;
         if ((rc = run_pair_tile(ctx, core, p0, nt, is_last, A[r & 1], A[(r + 1) & 1], rb, b, same_tile, round_major))) return rc;
+        if ((rc = late())) return rc;
         ++*items_done;
         if (++tiles_of_round[(size_t)r] == (int)n_tiles) ++*rounds_done;
         static const bool no_overlap = getenv("CM_PIPELINE") && getenv("CM_PIPELINE")[0] == '0';      // diagnostic: items back to back
@@ -3086,6 +3120,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream_p);
     (void)hipStreamSynchronize(ctx->stream_p2);
+    (void)hipStreamSynchronize(ctx->stream_o);
     (void)hipStreamSynchronize(ctx->stream_p3);
     (void)hipStreamSynchronize(ctx->stream_s);
     ctx->rerun[0].deferred = ctx->rerun[1].deferred = false;

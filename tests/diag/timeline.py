@@ -1,17 +1,13 @@
-"""Timeline of one steady-state bench step from a rocprofv3 --kernel-trace CSV: per kernel start / end relative to the step,
-grouped by queue.  usage: timeline.py <kernel_trace.csv> [step index from the end, default 2]"""
-import csv, re, sys, collections
-rows = []
-for r in csv.DictReader(open(sys.argv[1])):
-    m = re.search(r'\bk_\w+', r['Kernel_Name'])
-    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), m.group(0) if m else r['Kernel_Name'][:24], r.get('Queue_Id', '?')))
-rows.sort()
-# a step starts with k_seed of a prefetch-less round 0 ... simpler: cut at k_init_state launches (one per batch swap)
-cuts = [i for i, r in enumerate(rows) if r[2] == 'k_init_state']
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-a, b = cuts[-back - 1], cuts[-back]
-t0 = rows[a][0]
-print('step of %d kernels, %.2f ms' % (b - a, (rows[b][0] - t0) / 1e6))
-big = [r for r in rows[a:b] if r[1] - r[0] > 150000]
-for s, e, n, q in big:
-    print('%7.2f - %7.2f  (%5.2f ms)  q%-3s %s' % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, n))
+"""Print the kernel timeline of a few work items from a rocprofv3 kernel trace (st_kernel_trace.csv).
+usage: python tests/diag/timeline.py trace.csv [n_from_end] [n_rows]"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 70
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:24], r['Stream_Id']) for r in rows)
+idx = [i for i, e in enumerate(ev) if e[2] in ('k_pair',)]
+i0 = idx[-back]
+t0 = ev[i0][0]
+for e in ev[max(i0 - 25, 0):i0 + n]:
+    if e[1] - e[0] < 20000 and not e[2].startswith('k_'): continue
+    print(f"{(e[0]-t0)/1e6:8.3f} {(e[1]-t0)/1e6:8.3f} {(e[1]-e[0])/1e6:7.3f} {e[2]:24s} s{e[3]}")

@@ -560,10 +560,21 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_hp_unp(KCore kc, Re
 // ---- finish ----------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pair0, const uint32_t *lst, const unsigned int *n_lst_p, const unsigned int *n_heavy_p,
                                                           int attempt, HPipe P, cm_mapped_read *state, uint8_t *active, int32_t *cat, int is_last,
-                                                          unsigned long long *counters, RetryArgs ra) {
+                                                          unsigned long long *counters, RetryArgs ra, const int32_t *nchain, int second_to_fall) {
     const Core c = cmc::to_core(kc);
     const unsigned int n_items = attempt == 0 ? *n_heavy_p : *n_lst_p;
     const unsigned int x = blockIdx.x * BLK_PAIR + threadIdx.x;
+#if defined(CM_HP_DIAG)      // per attempt: pairs, tasks, unpaired chains, DP requests of both queues, fall-backs -> counters[8 + 8 * attempt ..]
+    if (x == 0) {
+        unsigned long long *o = counters + 8 + 8 * attempt;
+        atomicAdd(&o[0], (unsigned long long)n_items);
+        atomicAdd(&o[1], (unsigned long long)P.ctr[HC_TASKS]);
+        atomicAdd(&o[2], (unsigned long long)P.ctr[HC_UNP]);
+        atomicAdd(&o[3], (unsigned long long)P.ctr[HC_Q1]);
+        atomicAdd(&o[4], (unsigned long long)P.ctr[HC_Q2]);
+        atomicAdd(&o[5], (unsigned long long)P.ctr[HC_FALL]);
+    }
+#endif
     for (unsigned int y = x; y < n_items; y += gridDim.x * BLK_PAIR) {
         const uint32_t h = attempt == 0 ? y : lst[y];
         HPair &hp = P.hp[h];
@@ -587,9 +598,24 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
             }
             if (c.P.scan_level == 0 && a == CM_CONCRD) st = CM_CONCRD;
             if (st < 0 && attempt == 0) {              // the other orientation next
-                hp.mr = mr;
-                P.list2[atomicAdd(&P.ctr[HC_LIST2], 1u)] = h;
-                continue;
+                // Most often (62 % of the heavy pairs of the dense workload go on, 1 % of those have anything to do) neither read has
+                // a chain in that orientation: no task, no unpaired chain, and the attempt's verdict is the one k_hp_fold and this
+                // kernel reach over empty lists -- taken here.
+                const bool r1_fwd2 = hp.first == 0;
+                const uint32_t fs = hp.t * 4u + (r1_fwd2 ? 0u : 2u), bs = hp.t * 4u + (r1_fwd2 ? 3u : 1u);
+                if (nchain[fs] == 0 && nchain[bs] == 0) {
+                    const bool decided = mr.type == CM_CONCRD || mr.type == CM_DISCRD || mr.type == CM_CHIORF || mr.type == CM_CHIBSJ || mr.type == CM_CHI2BSJ;
+                    if (!decided && cmc::leftovers_matter(mr.type, CM_ORPHAN, false, CM_ORPHAN, false))
+                        cmc::mr_update_type(mr, cmc::leftover_type(CM_ORPHAN, CM_ORPHAN, false, false));
+                    st = (c.P.scan_level == 0 && mr.type == CM_CONCRD) ? CM_CONCRD : mr.type;
+                } else if (second_to_fall) {           // the few others: whole, by the fall-back kernel behind the pipeline
+                    P.fall[atomicAdd(&P.ctr[HC_FALL], 1u)] = hp.t;
+                    continue;
+                } else {
+                    hp.mr = mr;
+                    P.list2[atomicAdd(&P.ctr[HC_LIST2], 1u)] = h;
+                    continue;
+                }
             }
             if (st < 0) st = mr.type;
         }

@@ -2869,7 +2869,11 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             static const unsigned pipe_grid = getenv("CM_HP_GRID") ? (unsigned)atoi(getenv("CM_HP_GRID")) : 2048u;        // tuning knob: workgroups of the item kernels
             const size_t lds_slots = HG * sizeof(HSlot);
             HIPCHK(ctx, hipMemsetAsync(ctx->d_hp_ctr, 0, HC_WORDS * sizeof(unsigned int), sp2));
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            // Two passes (process_read's two attempts), the second over the few pairs whose other orientation has chains at all (k_hp_finish
+            // settles the others in place).  CM_HP_ATTEMPTS=1 (diagnostic) sends those pairs whole to the fall-back kernel instead: its
+            // long tail over a few hundred heavy pairs costs more than nine short launches (77.9 vs 75.9 ms per step).
+            static const int n_attempts = (getenv("CM_HP_ATTEMPTS") && atoi(getenv("CM_HP_ATTEMPTS")) == 1) ? 1 : 2;
+            for (int attempt = 0; attempt < n_attempts; ++attempt) {
                 if (attempt) hipLaunchKernelGGL(k_hp_reset, dim3(1), dim3(64), 0, sp2, ctx->d_hp_ctr);
                 hipLaunchKernelGGL(k_hp_plan, dim3(HP_PLAN_GRID), dim3(BLK_PAIR), lds_slots, sp2, core, rd, p0, (const uint32_t *)hlist, n_heavy,
                                    (const uint32_t *)ctx->d_hp_list2, n_list2, attempt, (const cm_chain *)rb.chains, (const int32_t *)rb.nchain,
@@ -2883,14 +2887,14 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                 hipLaunchKernelGGL(k_hp_unp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, pair_err,
                                    str_cap);
                 hipLaunchKernelGGL(k_hp_finish, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
-                                   ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_counters, ra1);
+                                   ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_counters, ra1, (const int32_t *)rb.nchain, n_attempts == 1 ? 1 : 0);
             }
             // (k_pair_heavy's own work cursor, d_cls_ctr + CTR_NEXT + 1, is zeroed with the light kernel's)
             hipLaunchKernelGGL(k_pair_heavy, dim3(std::min(heavy_grid, 256u)), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, (const uint32_t *)ctx->d_hp_fall,
                                (const unsigned int *)(ctx->d_hp_ctr + HC_FALL), rb.chains, rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat,
                                is_last_round, ctx->d_err, ctx->d_counters, str_cap, (unsigned long long *)nullptr, ctx->d_hres, cls_ctr + CTR_NEXT + 1,
                                ra1);
-            ctx->launches[4] += 18;
+            ctx->launches[4] += 9 * n_attempts;
         } else {
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, hlist, cls_ctr + HEAVY_CLS, rb.chains,
                            rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap,
@@ -2904,7 +2908,9 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         Timer t(ctx, 2, sp);      // = the pair stage: the light kernel and the wait for the second stream
         static const unsigned slots_per_simd = (pair_waves >= 1 && pair_waves <= 3) ? (unsigned)pair_waves : 4u;
         static const unsigned light_fix = getenv("CM_PAIR_GRID") ? (unsigned)atoi(getenv("CM_PAIR_GRID")) : 0u;       // tuning knob
-        const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = light_fix ? light_fix : 256u * 4u * slots_per_simd;   // light takes the slots heavy leaves: full cap
+        const unsigned want = (nt + BLK_PAIR - 1) / BLK_PAIR, cap = light_fix ? light_fix
+                                                                          : (heavy_pipeline() && ctx->P.band == 3 && slots_per_simd == 4u) ? 2048u      // the pipeline's kernels come and go: half the slots (78.7 -> 76.3 ms per step)
+                                                                                                                                        : 256u * 4u * slots_per_simd;   // light takes the slots heavy leaves: full cap
         hipLaunchKernelGGL(k_pair, dim3(want < cap ? want : cap), dim3(BLK_PAIR), lds_bytes, sp, core, rd, p0, nt, rb.chains, rb.nchain, rb.high,
                            ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_err, ctx->d_counters, str_cap, ctx->d_lane_clk, perm,
                            cls_ctr + CTR_SUM, cls_ctr + CTR_NEXT, ra1);

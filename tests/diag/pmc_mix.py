@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(out, 'p*', '*counter_collection.csv')):
         k = m.group(0) if m else r['Kernel_Name'][:40]
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         launches[(k, r['Counter_Name'])].add(r['Dispatch_Id'])
-for k in sorted(acc, key=lambda k: -acc[k].get('SQ_INSTS_VALU', 0))[:8]:
+for k in sorted(acc, key=lambda k: -acc[k].get("SQ_INSTS_VALU", 0))[:14]:
     print(k)
     for c in sorted(acc[k]):
         n = max(len(launches[(k, c)]), 1)

@@ -45,6 +45,7 @@ struct HPipe {
     uint32_t *q2;
     unsigned int *ctr;
     uint32_t tasks_cap, unp_cap;
+    unsigned int *fall_ctr;          // entries of fall[] (one list per set of chain records: the fall-back launch may come late, see settle_pair)
 };
 struct HReadsOf {                    // the two reads of a pair in one attempt's orientation
     cmc::g_u8 fseq, bseq;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 6) k_hp_plan(KCore kc, ReadsDev rd, 
             slot_off[lane] = off;
             if (over) {
                 S[lane].done = 1;                              // (marks the slot: its tasks become holes, no requests)
-                P.fall[atomicAdd(&P.ctr[HC_FALL], 1u)] = t;
+                P.fall[atomicAdd(P.fall_ctr, 1u)] = t;
             }
         }
         __syncthreads();
@@ -456,7 +457,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_fold(KCore kc, uint64_t pair
             off = atomicAdd(&P.ctr[HC_UNP], (unsigned int)(nfu + nbu));
             if ((unsigned long long)off + (unsigned int)(nfu + nbu) > (unsigned long long)P.unp_cap) {          // does not fit: the whole pair to the fall-back kernel
                 hp.over = 1;
-                P.fall[atomicAdd(&P.ctr[HC_FALL], 1u)] = hp.t;
+                P.fall[atomicAdd(P.fall_ctr, 1u)] = hp.t;
                 // (its stretch of U stays unwritten; the entries below the capacity are made holes)
                 for (int k = 0; k < nfu + nbu; ++k)
                     if ((unsigned long long)off + (unsigned int)k < P.unp_cap) P.U[off + k] = HUnp{0xffffffffu, 0u};
@@ -572,7 +573,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
         atomicAdd(&o[2], (unsigned long long)P.ctr[HC_UNP]);
         atomicAdd(&o[3], (unsigned long long)P.ctr[HC_Q1]);
         atomicAdd(&o[4], (unsigned long long)P.ctr[HC_Q2]);
-        atomicAdd(&o[5], (unsigned long long)P.ctr[HC_FALL]);
+        atomicAdd(&o[5], (unsigned long long)*P.fall_ctr);
     }
 #endif
     for (unsigned int y = x; y < n_items; y += gridDim.x * BLK_PAIR) {
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
                         cmc::mr_update_type(mr, cmc::leftover_type(CM_ORPHAN, CM_ORPHAN, false, false));
                     st = (c.P.scan_level == 0 && mr.type == CM_CONCRD) ? CM_CONCRD : mr.type;
                 } else if (second_to_fall) {           // the few others: whole, by the fall-back kernel behind the pipeline
-                    P.fall[atomicAdd(&P.ctr[HC_FALL], 1u)] = hp.t;
+                    P.fall[atomicAdd(P.fall_ctr, 1u)] = hp.t;
                     continue;
                 } else {
                     hp.mr = mr;

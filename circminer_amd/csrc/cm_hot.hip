@@ -908,7 +908,10 @@ __device__ inline int pair_class(const Core &c, const cm_chain *chains, const ui
 // [class][block] histogram into exclusive bases (heaviest light bucket first) and totals;
 // k_cls_place: writes perm[] (light pairs) / hlist[] (heavy pairs) at base + rank inside the block.
 constexpr int CHAIN_LIGHT_CLS = 12;     // chaining classes below this are light
-constexpr int CLS_T = 1024;            // threads per block = 16 waves
+constexpr int CLS_T = 1024;            // elements per block of the counting sorts
+constexpr int CLS_W = 256;             // threads per block: every wave takes CLS_T / CLS_W stretches of 64 elements in turn (blocks of 1024 threads waited up
+                                       // to 1.4 ms for sixteen free wave slots on one CU next to the seeding kernel)
+constexpr int CLS_REP = CLS_T / CLS_W;
 constexpr int N_CLS = 16;                // classes a sort can use (pairs: 0..13 light + 15 heavy; chaining: 0..11 light + 12..15 heavy)
 constexpr int CTR_SUM = 16, CTR_BASE = 32, CTR_WORDS = 64;
 constexpr int CTR_NEXT = 48;             // spare words of the pair stage's class counters: work cursors of k_pair / k_pair_heavy, then the
@@ -1012,14 +1015,19 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
 }
 // `order` (optional): visit the elements in this order (second pass of an LSD radix sort: order = the permutation of the
 // first pass, *n_order entries); the element at position i is order[i]
-__global__ void __launch_bounds__(CLS_T) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb, const uint32_t *order,
+__global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb, const uint32_t *order,
                                                     const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t i = blockIdx.x * CLS_T + threadIdx.x;
     const uint32_t lim = order ? *n_order : n;
-    const int k = i < lim ? (int)cls[order ? order[i] : i] : -2;
-    unsigned int r;
-    block_class_ranks(k, wcnt, r, threadIdx.x & 63, threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < CLS_REP; ++j) {
+        const int vw = wave * CLS_REP + j;                 // stretch of 64 elements within the block
+        const uint32_t i = blockIdx.x * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
+        const int k = i < lim ? (int)cls[order ? order[i] : i] : -2;
+        unsigned int r;
+        block_class_ranks(k, wcnt, r, lane, vw);
+    }
     __syncthreads();
     if (threadIdx.x < N_CLS) {
         unsigned int tot = 0;
@@ -1067,24 +1075,33 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
         for (int c = 0; c < N_CLS; ++c) ctr[c] = tot[c];
     }
 }
-__global__ void __launch_bounds__(CLS_T) k_cls_place(const int8_t *cls, uint32_t n_tile, const unsigned int *blk_base, uint32_t nb,
+__global__ void __launch_bounds__(CLS_W) k_cls_place(const int8_t *cls, uint32_t n_tile, const unsigned int *blk_base, uint32_t nb,
                                                      const unsigned int *ctr, uint32_t *perm, uint32_t *hlist, const uint32_t *order,
                                                      const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t i = blockIdx.x * CLS_T + threadIdx.x;
     const uint32_t lim = order ? *n_order : n_tile;
-    const uint32_t t = i < lim ? (order ? order[i] : i) : 0u;
-    const int k = i < lim ? (int)cls[t] : -2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int r;
-    block_class_ranks(k, wcnt, r, lane, wave);
+    uint32_t t[CLS_REP];
+    int k[CLS_REP];
+    unsigned int r[CLS_REP];
+#pragma unroll
+    for (int j = 0; j < CLS_REP; ++j) {
+        const int vw = wave * CLS_REP + j;
+        const uint32_t i = blockIdx.x * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
+        t[j] = i < lim ? (order ? order[i] : i) : 0u;
+        k[j] = i < lim ? (int)cls[t[j]] : -2;
+        block_class_ranks(k[j], wcnt, r[j], lane, vw);
+    }
     __syncthreads();
-    if (k >= 0) {
+#pragma unroll
+    for (int j = 0; j < CLS_REP; ++j) {
+        if (k[j] < 0) continue;
+        const int vw = wave * CLS_REP + j;
         unsigned int before = 0;
-        for (int w = 0; w < wave; ++w) before += wcnt[w][k];
-        const unsigned int pos = blk_base[(size_t)k * nb + blockIdx.x] + before + r;
-        if (k == HEAVY_CLS && hlist) hlist[pos] = t;
-        else perm[ctr[CTR_BASE + k] + pos] = t;
+        for (int w = 0; w < vw; ++w) before += wcnt[w][k[j]];
+        const unsigned int pos = blk_base[(size_t)k[j] * nb + blockIdx.x] + before + r[j];
+        if (k[j] == HEAVY_CLS && hlist) hlist[pos] = t[j];
+        else perm[ctr[CTR_BASE + k[j]] + pos] = t[j];
     }
 }
 
@@ -1641,6 +1658,13 @@ struct cm_ctx {
         size_t lds2 = 0;
         uint32_t *pair_err = nullptr, *retry_list = nullptr;
         unsigned int *retry_ctr = nullptr;
+        // the fall-back launch of the heavy-pair pipeline (k_pair_heavy over the pairs that did not fit its arrays), decided late as well
+        bool fall = false;
+        const uint32_t *fall_list = nullptr;
+        unsigned int *fall_ctr = nullptr, *fall_cursor = nullptr;
+        size_t lds_heavy = 0;
+        int str_cap = 0;
+        unsigned fall_grid = 0;
     } rerun[2];
     hipStream_t stream_s = nullptr;           // seeding of the NEXT item, issued while the chain stage of this one runs (map_rounds_issue)
     hipEvent_t ev_seed[2] = {nullptr, nullptr};       // seeds + cell offsets of a seed set are complete
@@ -1730,6 +1754,7 @@ struct cm_ctx {
     uint16_t *d_hp_lists = nullptr;
     unsigned int *d_hp_ctr = nullptr;
     uint32_t hp_tasks_cap = 0, hp_unp_cap = 0;
+    unsigned int *d_hp_fallctr = nullptr;      // [set]
     unsigned long long *d_type_hist = nullptr;
     unsigned int *d_retry_ctr = nullptr;                          // [set][count, cursor]
     unsigned long long *d_heavy_load = nullptr;                   // cost beyond HEAVY_COST summed over the tile in the pair stage (k_pair_cost)
@@ -1817,7 +1842,7 @@ void free_reads(cm_ctx *c) {
     dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b);
     dfree(c, c->d_dpscore); dfree(c, c->d_dpprev); dfree(c, c->d_chains); dfree(c, c->d_nchain); dfree(c, c->d_high);
     dfree(c, c->d_pool); dfree(c, c->d_lane_clk); dfree(c, c->d_cls); dfree(c, c->d_cls4); dfree(c, c->d_perm4); dfree(c, c->d_resid); dfree(c, c->d_perm); dfree(c, c->d_cls_ctr); dfree(c, c->d_cls_ctr2); dfree(c, c->d_cls_sub); dfree(c, c->d_perm1); dfree(c, c->d_cls_ctr3); dfree(c, c->d_cls_sub2); dfree(c, c->d_perm0); dfree(c, c->d_blk_cnt); dfree(c, c->d_hlist); dfree(c, c->d_hres);
-    dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_U);
+    dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_fallctr); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_U);
     dfree(c, c->d_hp_pre); dfree(c, c->d_hp_pre2); dfree(c, c->d_hp_res); dfree(c, c->d_hp_lists); dfree(c, c->d_hp_ctr);
     dfree(c, c->d_pair_err); dfree(c, c->d_retry_list); dfree(c, c->d_spill); dfree(c, c->d_type_hist); dfree(c, c->d_retry_ctr); dfree(c, c->d_heavy_load);
     dfree(c, c->d_col_cls); dfree(c, c->d_col_perm); dfree(c, c->d_col_blk); dfree(c, c->d_col_ctr);
@@ -1952,10 +1977,10 @@ int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t p
         const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
         hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, rb->high,
                            chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
                            (const unsigned int *)nullptr);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
                            (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
         ctx->launches[5] += 4;
         HIPCHK(ctx, hipMemsetAsync(sb.pool_cursor, 0, sizeof(unsigned long long), st));
@@ -2541,12 +2566,15 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     if (heavy_pipeline()) {
         // the pipeline's arrays: per heavy pair, per mate-pair task (~ 10 per heavy pair on the dense workload, room for 6 per pair of
         // the tile), per unpaired chain (room for 4 per pair of the tile); what does not fit goes to k_pair_heavy
-        const size_t tc = std::max<size_t>((size_t)tile * 6, 4096), uc = std::max<size_t>((size_t)tile * 4, 4096);
+        // (CM_HP_TASKS_CAP / CM_HP_UNP_CAP: test knobs, small capacities so that the fall-back path is taken)
+        const size_t tc = getenv("CM_HP_TASKS_CAP") ? (size_t)std::max(1, atoi(getenv("CM_HP_TASKS_CAP"))) : std::max<size_t>((size_t)tile * 6, 4096);
+        const size_t uc = getenv("CM_HP_UNP_CAP") ? (size_t)std::max(1, atoi(getenv("CM_HP_UNP_CAP"))) : std::max<size_t>((size_t)tile * 4, 4096);
         ctx->hp_tasks_cap = (uint32_t)tc;
         ctx->hp_unp_cap = (uint32_t)uc;
         HIPCHK(ctx, ensure(ctx, ctx->d_hp, (size_t)tile * sizeof(HPair)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_list2, (size_t)tile * 4));
-        HIPCHK(ctx, ensure(ctx, ctx->d_hp_fall, (size_t)tile * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_fall, (size_t)tile * 4 * 2));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_fallctr, 2 * sizeof(unsigned int)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_T, tc * sizeof(HTask)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_pre, tc * 4 * sizeof(cmc::PreDP)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_q, tc * 4 * 4));
@@ -2727,13 +2755,32 @@ static int launch_rerun(cm_ctx *ctx, int b) {
     HIPCHK(ctx, hipGetLastError());
     return CM_OK;
 }
+// The pipeline's fall-back launch: k_pair_heavy over the pairs whose tasks or unpaired chains did not fit the pipeline's arrays (none on
+// the bench workloads).  A launch that asks for 14 KB of LDS per wave to find an empty list waited 0.03 - 2.3 ms behind the chain kernels
+// of the next item at the end of every pair stage: decided late like the re-run, from the list length the stage copied to the host.
+static int launch_fall_back(cm_ctx *ctx, int b, hipStream_t st) {
+    const cm_ctx::Rerun &q = ctx->rerun[b];
+    const RetryArgs ra1{q.pair_err, q.retry_list, q.retry_ctr, nullptr, 0, 1};
+    hipLaunchKernelGGL(k_pair_heavy, dim3(q.fall_grid), dim3(BLK_PAIR), q.lds_heavy, st, q.core, q.rd, q.p0, q.fall_list, (const unsigned int *)q.fall_ctr, q.chains,
+                       q.nchain, q.high, ctx->d_state, q.act_out, ctx->d_cat, q.is_last, ctx->d_err, ctx->d_counters, q.str_cap, (unsigned long long *)nullptr,
+                       ctx->d_hres, q.fall_cursor, ra1);
+    HIPCHK(ctx, hipGetLastError());
+    ++ctx->launches[4];
+    return CM_OK;
+}
 // wait = false: without blocking the host (the end of cm_map_rounds, which stays asynchronous): the re-run is launched whatever the count
 static int settle_pair(cm_ctx *ctx, int b, bool wait = true) {
     if (!ctx->rerun[b].deferred) return CM_OK;
     ctx->rerun[b].deferred = false;
     if (wait) HIPCHK(ctx, hipEventSynchronize(ctx->ev_first[b]));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p3, ctx->ev_first[b], 0));
-    if (!wait || *(const volatile unsigned int *)(ctx->h_pin + 12 + b) != 0u) {
+    bool fell = false;
+    if (ctx->rerun[b].fall && (!wait || *(const volatile unsigned int *)(ctx->h_pin + 14 + b) != 0u)) {
+        const int rc = launch_fall_back(ctx, b, ctx->stream_p3);        // (may queue pairs for the re-run: that one unconditionally then)
+        if (rc) return rc;
+        fell = true;
+    }
+    if (!wait || fell || *(const volatile unsigned int *)(ctx->h_pin + 12 + b) != 0u) {
         const int rc = launch_rerun(ctx, b);
         if (rc) return rc;
     }
@@ -2817,19 +2864,19 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         // then (stable) by its class
         const uint32_t *no_order = nullptr;
         const unsigned int *no_count = nullptr;
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
                            (uint32_t *)nullptr, no_order, no_count);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
                            (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
                            (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
+        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
                            (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, cls_ctr, 1 << HEAVY_CLS, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, cls_ctr, perm,
+        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, cls_ctr, perm,
                            hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
     }
@@ -2839,6 +2886,14 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_order[b], 0));
     HIPCHK(ctx, hipMemsetAsync(retry_ctr, 0, 2 * sizeof(unsigned int), sp));                     // re-run count + cursor of this set
     const RetryArgs ra1{pair_err, retry_list, retry_ctr, nullptr, 0, 1};
+    {   // what the late launches of this stage need (settle_pair: the re-run, the pipeline's fall-back)
+        cm_ctx::Rerun &q = ctx->rerun[b];
+        q.core = core; q.rd = rd; q.p0 = p0; q.nt = nt;
+        q.chains = rb.chains; q.nchain = rb.nchain; q.high = rb.high;
+        q.act_out = act_out; q.is_last = is_last_round; q.cap2 = cap2; q.lds2 = lds2;
+        q.pair_err = pair_err; q.retry_list = retry_list; q.retry_ctr = retry_ctr;
+        q.fall = false;
+    }
     // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
     // behind it.
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
@@ -2863,12 +2918,13 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         if (heavy_pipeline() && ctx->P.band == 3) {
             // the heavy pairs as a pipeline of full-width kernels (cm_heavy_pipe.h); what does not fit its arrays comes back in a
             // fall-back list and goes through k_pair_heavy behind it
-            const HPipe hp{ctx->d_hp, ctx->d_hp_list2, ctx->d_hp_fall, ctx->d_hp_T, ctx->d_hp_pre, ctx->d_hp_q, ctx->d_hp_res, ctx->d_hp_U, ctx->d_hp_pre2,
-                           ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap};
+            const HPipe hp{ctx->d_hp, ctx->d_hp_list2, ctx->d_hp_fall + (size_t)b * ctx->tile, ctx->d_hp_T, ctx->d_hp_pre, ctx->d_hp_q, ctx->d_hp_res, ctx->d_hp_U, ctx->d_hp_pre2,
+                           ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap, ctx->d_hp_fallctr + b};
             const unsigned int *n_heavy = cls_ctr + HEAVY_CLS, *n_list2 = ctx->d_hp_ctr + HC_LIST2;
             static const unsigned pipe_grid = getenv("CM_HP_GRID") ? (unsigned)atoi(getenv("CM_HP_GRID")) : 2048u;        // tuning knob: workgroups of the item kernels
             const size_t lds_slots = HG * sizeof(HSlot);
             HIPCHK(ctx, hipMemsetAsync(ctx->d_hp_ctr, 0, HC_WORDS * sizeof(unsigned int), sp2));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_hp_fallctr + b, 0, sizeof(unsigned int), sp2));
             // Two passes (process_read's two attempts), the second over the few pairs whose other orientation has chains at all (k_hp_finish
             // settles the others in place).  CM_HP_ATTEMPTS=1 (diagnostic) sends those pairs whole to the fall-back kernel instead: its
             // long tail over a few hundred heavy pairs costs more than nine short launches (77.9 vs 75.9 ms per step).
@@ -2889,11 +2945,24 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                 hipLaunchKernelGGL(k_hp_finish, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
                                    ctx->d_state, act_out, ctx->d_cat, is_last_round, ctx->d_counters, ra1, (const int32_t *)rb.nchain, n_attempts == 1 ? 1 : 0);
             }
-            // (k_pair_heavy's own work cursor, d_cls_ctr + CTR_NEXT + 1, is zeroed with the light kernel's)
-            hipLaunchKernelGGL(k_pair_heavy, dim3(std::min(heavy_grid, 256u)), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, (const uint32_t *)ctx->d_hp_fall,
-                               (const unsigned int *)(ctx->d_hp_ctr + HC_FALL), rb.chains, rb.nchain, rb.high, ctx->d_state, act_out, ctx->d_cat,
-                               is_last_round, ctx->d_err, ctx->d_counters, str_cap, (unsigned long long *)nullptr, ctx->d_hres, cls_ctr + CTR_NEXT + 1,
-                               ra1);
+            // what did not fit goes through k_pair_heavy: now (one tile), or when the stage is settled and the list is known to hold something
+            // (its own work cursor, cls_ctr + CTR_NEXT + 1, was zeroed with the light kernel's)
+            HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 14 + b), ctx->d_hp_fallctr + b, sizeof(unsigned int), hipMemcpyDeviceToHost, sp2));
+            {
+                cm_ctx::Rerun &q = ctx->rerun[b];
+                q.fall = true;
+                q.fall_list = ctx->d_hp_fall + (size_t)b * ctx->tile;
+                q.fall_ctr = ctx->d_hp_fallctr + b;
+                q.fall_cursor = cls_ctr + CTR_NEXT + 1;
+                q.lds_heavy = lds_heavy;
+                q.str_cap = str_cap;
+                q.fall_grid = std::min(heavy_grid, 256u);
+            }
+            if (!defer) {
+                int rc;
+                if ((rc = launch_fall_back(ctx, b, sp2))) return rc;
+                ctx->rerun[b].fall = false;
+            }
             ctx->launches[4] += 9 * n_attempts;
         } else {
         hipLaunchKernelGGL(k_pair_heavy, dim3(heavy_grid), dim3(BLK_PAIR), lds_heavy, sp2, core, rd, p0, hlist, cls_ctr + HEAVY_CLS, rb.chains,
@@ -2924,14 +2993,7 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
     // it -- ev_pair[b] (chain records of set b free, flags and states of the tile final) is recorded behind it.
     HIPCHK(ctx, hipMemcpyAsync((void *)(ctx->h_pin + 12 + b), retry_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, sp));
     HIPCHK(ctx, hipEventRecord(ctx->ev_first[b], sp));
-    {
-        cm_ctx::Rerun &q = ctx->rerun[b];
-        q.core = core; q.rd = rd; q.p0 = p0; q.nt = nt;
-        q.chains = rb.chains; q.nchain = rb.nchain; q.high = rb.high;
-        q.act_out = act_out; q.is_last = is_last_round; q.cap2 = cap2; q.lds2 = lds2;
-        q.pair_err = pair_err; q.retry_list = retry_list; q.retry_ctr = retry_ctr;
-        q.deferred = defer;
-    }
+    ctx->rerun[b].deferred = defer;
     if (!defer) {
         HIPCHK(ctx, hipStreamWaitEvent(sp3, ctx->ev_first[b], 0));
         int rc;
@@ -3180,10 +3242,10 @@ static int compact_active(cm_ctx *ctx) {
     HIPCHK(ctx, ensure(ctx, ctx->d_col_blk, (size_t)N_CLS * (nbk + 2) * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_col_ctr, CTR_WORDS * sizeof(unsigned int)));
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
-    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, (const uint32_t *)nullptr,
+    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, (const uint32_t *)nullptr,
                        (const unsigned int *)nullptr);
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
-    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_T), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
+    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
                        ctx->d_col_perm, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
     return CM_OK;
 }

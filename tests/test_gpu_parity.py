@@ -726,6 +726,28 @@ def test_rerun_launch_under_a_two_entry_memo(tmp_path):
     assert m and int(m.group(1)) >= 15, r.stdout[-1500:]
 
 
+def test_heavy_pipeline_fall_back_and_variants():
+    """The heavy pairs of a tile go through a pipeline of full-width kernels whose arrays hold a fixed number of mate-pair tasks
+    and unpaired chains; a pair that does not fit is mapped whole by k_pair_heavy, launched late (when the stage is settled and
+    the list is known to hold something) with several tiles, at once with one.  With room for 40 tasks and 24 unpaired chains
+    most pairs take that way (CM_HEAVY_COST=2: every pair with chains on both reads counts as heavy); with room for 3 unpaired chains the
+    pairs that get as far as those do.  Also: the second attempt through the fall-back kernel (CM_HP_ATTEMPTS=1), and the pipeline
+    switched off (the round-3 path).  Every variant must equal the oracle on the whole-data-set suites; ONE child process each
+    (the knobs are read once per process)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knobs in ({"CM_HP_TASKS_CAP": "40", "CM_HP_UNP_CAP": "24", "CM_HEAVY_COST": "2"}, {"CM_HP_TASKS_CAP": "100000", "CM_HP_UNP_CAP": "3", "CM_HEAVY_COST": "2"}, {"CM_HP_ATTEMPTS": "1"}, {"CM_HEAVY_PIPELINE": "0"}):
+        env = dict(os.environ, **knobs)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                            "test_map_parity_all_rounds or test_rounds_in_one_call or test_multi_tile_batches or test_ragged_and_dirty_reads"],
+                           env=env, capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, str(knobs) + r.stdout[-3000:] + r.stderr[-2000:]
+        m = re.search(r"(\d+) passed", r.stdout)
+        assert m and int(m.group(1)) >= 7, str(knobs) + r.stdout[-1500:]
+
+
 def test_reruns_are_counted(ds_small):
     """cm_prof_counters [4] counts the pair-rounds the re-run launch mapped: zero for the product
     build on ordinary data, many under the 2-entry strict test build (CM_EXPECT_RERUNS, see the test above)."""

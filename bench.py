@@ -394,8 +394,11 @@ def main():
     def step():
         # H2D of the next batch on the copy stream, concurrent with the rounds of the resident one
         turn[0] = (turn[0] + 1) % len(batches)
+        t_stage = time.perf_counter()
         hp.stage(batches[turn[0]])
         tr = [time.perf_counter()] if trace else None
+        if trace:
+            print("stage (ms) %.2f   since previous step's return %.2f" % ((tr[0] - t_stage) * 1e3, (t_stage - step.t_ret) * 1e3 if hasattr(step, "t_ret") else 0.0), file=sys.stderr)
         hp.map_rounds(list(range(hi.n_contigs)), True)
         if trace:
             tr.append(time.perf_counter())
@@ -424,6 +427,7 @@ def main():
         if trace:
             tr.append(time.perf_counter())
             print("step parts (ms): map_rounds(host) %.2f" % ((tr[1] - tr[0]) * 1e3), [round((b - a) * 1e3, 2) for a, b in zip(tr[1:], tr[2:])], file=sys.stderr)
+            step.t_ret = time.perf_counter()
         return rec
 
     def fence():
@@ -469,7 +473,7 @@ def main():
         total_pairs = args.pairs * world * args.steps
         value = total_pairs / dt
         ab = algorithmic_bytes(counters)
-        # the pair stage = class kernels + k_pair (light pairs, one per lane) with k_pair_heavy (one pair per wave) running
+        # the pair stage = class kernels + k_pair (light pairs, one per lane) with the heavy pairs' pipeline (k_hp_*) running
         # concurrently on a second stream: class [2] is timed from the k_pair launch to the join, its algorithmic
         # bytes cover all pair-rounds; classes [4], [6] are the overlapped kernels' own times
         # (the class / counting-sort kernels [5] are not added: with the rounds pipelined their timers mostly measure waiting for
@@ -507,7 +511,7 @@ def main():
         except Exception:
             tdet = {}
         stages = {}
-        for name, idx, kernels in (("seed", 0, ["k_seed"]), ("chain", 1, ["k_chain", "k_chain_heavy"]), ("pair", 2, ["k_pair", "k_pair_heavy"])):
+        for name, idx, kernels in (("seed", 0, ["k_seed"]), ("chain", 1, ["k_chain", "k_chain_heavy"]), ("pair", 2, ["k_pair", "k_hp_tasks", "k_hp_dp", "k_hp_plan", "k_pair_heavy"])):
             n_l = max(launches[idx], 1)
             t_ms = ms[idx] / n_l
             ach = (ab[idx] / n_l) / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
@@ -544,7 +548,7 @@ def main():
                        "distinct_batches": len(batches),
                        "prep_seconds": {"generate": round(gen_s, 1), "index+annotation": round(prep_s - gen_s, 1), "load_to_hbm": round(load_s, 1),
                                         "more_batches": round(more_s, 1)}},
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_pair_heavy (pair stage: light kernel launch to the join with the heavy kernel)" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom] + ("+k_hp_* (pair stage: light kernel launch to the join with the heavy pairs' pipeline)" if dom == 2 else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": launches[dom],
                          "algorithmic_bytes_per_launch": ab[dom] / max(launches[dom], 1)},

@@ -2183,10 +2183,20 @@ int cm_create(const cm_params *p, cm_ctx **out) {
     static const int prio_mask = getenv("CM_STREAM_PRIO") ? atoi(getenv("CM_STREAM_PRIO")) : 0;
     int prio_lo = 0, prio_hi = 0;
     if (prio_mask) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    auto mk_stream = [&](hipStream_t *st, bool high) { return high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream2) != hipSuccess ||
+    // CM_STREAM_LOW: bit 0 = the light pair kernel's stream at the lowest priority, bit 1 = the heavy chaining stream.  Default 1: the light
+    // kernel's persistent waves are the filler of a pair stage, and the short kernels of the heavy pairs' pipeline and of the next item's
+    // seeding / chaining get their workgroups placed first (hg38-like step 74.3 -> 70.9 ms; 72.3 with the pipeline's stream raised
+    // instead, 76.9 with both, 72.9 with the heavy chaining stream lowered).
+    static const int low_mask = getenv("CM_STREAM_LOW") ? atoi(getenv("CM_STREAM_LOW")) : 1;
+    if (low_mask && !prio_mask) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    auto mk_stream = [&](hipStream_t *st, bool high, bool low = false) {
+        return high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi)
+                    : low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    if (hipStreamCreate(&ctx->stream) != hipSuccess ||
+        ((low_mask & 2) ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_lo) : hipStreamCreate(&ctx->stream2)) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_p, hipStreamNonBlocking) != hipSuccess ||
+        mk_stream(&ctx->stream_p, false, (low_mask & 1) != 0) != hipSuccess ||
         mk_stream(&ctx->stream_p2, (prio_mask & 2) != 0) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_p3, hipStreamNonBlocking) != hipSuccess ||
         mk_stream(&ctx->stream_o, (prio_mask & 1) != 0) != hipSuccess ||
@@ -2912,10 +2922,10 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         ctx->launches[5] += 10;
     }
     HIPCHK(ctx, hipMemsetAsync(cls_ctr + CTR_NEXT, 0, 2 * sizeof(unsigned int), so));     // both work cursors
+    HIPCHK(ctx, hipMemsetAsync(retry_ctr, 0, 2 * sizeof(unsigned int), so));                     // re-run count + cursor of this set
     HIPCHK(ctx, hipEventRecord(ctx->ev_order[b], so));
     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_prep[b], 0));
     HIPCHK(ctx, hipStreamWaitEvent(sp, ctx->ev_order[b], 0));
-    HIPCHK(ctx, hipMemsetAsync(retry_ctr, 0, 2 * sizeof(unsigned int), sp));                     // re-run count + cursor of this set
     const RetryArgs ra1{pair_err, retry_list, retry_ctr, nullptr, 0, 1};
     {   // what the late launches of this stage need (settle_pair: the re-run, the pipeline's fall-back)
         cm_ctx::Rerun &q = ctx->rerun[b];
@@ -2925,10 +2935,12 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         q.pair_err = pair_err; q.retry_list = retry_list; q.retry_ctr = retry_ctr;
         q.fall = false;
     }
-    // The heavy pairs go to a second stream: one wave per pair fits into the slots the light kernel leaves instead of queueing
-    // behind it.
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork_p, sp));
-    HIPCHK(ctx, hipStreamWaitEvent(sp2, ctx->ev_fork_p, 0));
+    // The heavy pairs go to a second stream: their kernels fit into the slots the light kernel leaves instead of queueing behind it.
+    // That stream waits for this item's chains and lists itself, not for the light stream (which sits at the lowest priority, behind the
+    // light kernel of the item before): what the heavy kernels share with the previous stage's light kernel exists once per set (re-run
+    // list, cursors) or per tile (states, flags: another tile's, or ordered behind ev_pair through the ordering stream).
+    HIPCHK(ctx, hipStreamWaitEvent(sp2, ctx->ev_prep[b], 0));
+    HIPCHK(ctx, hipStreamWaitEvent(sp2, ctx->ev_order[b], 0));
     {
         Timer t(ctx, 4, sp2);
         // both pair kernels are persistent: together they fill `pair_waves` wave slots per SIMD (256 CUs x 4 SIMDs), half each

@@ -1948,6 +1948,32 @@ static unsigned int chain_light_cells() {
 // seeds of one tile into seed set s, on stream st: k_seed, the scan of the problems' DP cells, the two totals to the host; with
 // rb (the chain records the tile's chain stage will fill: their per-problem counters are initialised here) also the work
 // classes + sorted lists of the chaining problems and the zeroed cursors.  ev_seed[s] is recorded behind them.
+// The second half of run_seed_tile: the work classes + sorted lists of the chaining problems of seed set s, the per-problem counters of
+// the chain records rb and the zeroed cursors.  (On its own when the seeds were computed before the chain records were free: the
+// cross-batch prefetch.)
+static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st, const RoundBufs *rb) {
+    const int S = ctx->n_seeds;
+    const uint32_t n_prob = n_tile * 4u;
+    if ((uint64_t)n_prob * (uint64_t)S == 0) return CM_OK;
+    const SeedBufs sb = seed_bufs(ctx, s);
+    // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy), heaviest class
+    // first.  (Used by run_chain_tile when it takes the split path; computed here because these five small launches, queued
+    // behind the persistent pair kernels of the previous item, took 6 ms of the chain stage's critical path.)
+    Timer t(ctx, 5, st);
+    const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
+    hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, rb->high,
+                       chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
+    hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
+                       (const unsigned int *)nullptr);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
+    hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
+    ctx->launches[5] += 4;
+    HIPCHK(ctx, hipMemsetAsync(sb.pool_cursor, 0, sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(sb.cctr + 48, 0, sizeof(unsigned int), st));       // spare word of the class counters: work cursor of k_chain_heavy
+    HIPCHK(ctx, hipGetLastError());
+    return CM_OK;
+}
 int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st,
                   const RoundBufs *rb) {
     const int S = ctx->n_seeds;
@@ -1971,21 +1997,8 @@ int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t p
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 8 + 2 * s, sb.celloff + n_prob, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (rb) {
-        // Light problems: one lane each, index order.  Heavy problems (many hits): one wave each (k_chain_heavy), heaviest class
-        // first.  (Used by run_chain_tile when it takes the split path; computed here because these five small launches, queued
-        // behind the persistent pair kernels of the previous item, took 6 ms of the chain stage's critical path.)
-        Timer t(ctx, 5, st);
-        const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
-        hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, rb->high,
-                           chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
-        hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
-                           (const unsigned int *)nullptr);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
-        hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
-                           (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
-        ctx->launches[5] += 4;
-        HIPCHK(ctx, hipMemsetAsync(sb.pool_cursor, 0, sizeof(unsigned long long), st));
-        HIPCHK(ctx, hipMemsetAsync(sb.cctr + 48, 0, sizeof(unsigned int), st));       // spare word of the class counters: work cursor of k_chain_heavy
+        const int rc = seed_classes(ctx, pair0, n_tile, act, s, st, rb);
+        if (rc) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_seed[s], st));
     HIPCHK(ctx, hipGetLastError());
@@ -2193,8 +2206,11 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         return high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi)
                     : low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
-    if (hipStreamCreate(&ctx->stream) != hipSuccess ||
-        ((low_mask & 2) ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_lo) : hipStreamCreate(&ctx->stream2)) != hipSuccess ||
+    // (CM_STREAM_PRIO bit 2 = the heavy chaining stream, bit 3 = the main stream)
+    if (((prio_mask & 8) ? hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, prio_hi) : hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        ((low_mask & 2)    ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_lo)
+         : (prio_mask & 4) ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamDefault, prio_hi)
+                           : hipStreamCreate(&ctx->stream2)) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess ||
         mk_stream(&ctx->stream_p, false, (low_mask & 1) != 0) != hipSuccess ||
         mk_stream(&ctx->stream_p2, (prio_mask & 2) != 0) != hipSuccess ||
@@ -3052,6 +3068,15 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
 // *rounds_done counts the rounds whose pair stage was issued for every tile (the flags arrays have swapped roles that often).
 static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final, int *items_done, int *rounds_done) {
     int rc;
+    // Cross-batch prefetch (see the end of this function): possible when this call ends the batch and the next one is staged and fits
+    // the workspace as it is sized now (nothing may be reallocated under the kernels in flight).
+    static const bool prefetch_on = !(getenv("CM_PREFETCH") && getenv("CM_PREFETCH")[0] == '0');
+    const bool prefetch = prefetch_on && last_is_final && ctx->staged && ctx->st_n_pairs <= ctx->n_pairs && ctx->st_max_len <= ctx->max_len;
+    if (prefetch && ctx->ones_cap < ctx->st_n_pairs) {          // flags of a fresh batch: every pair active
+        HIPCHK(ctx, ensure(ctx, ctx->d_ones, ctx->n_pairs));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ones, 1, ctx->n_pairs, ctx->stream));
+        ctx->ones_cap = ctx->n_pairs;
+    }
     // everything queued on the main stream so far (uploads, resets, collects of the previous batch) comes first
     HIPCHK(ctx, hipEventRecord(ctx->ev_tail, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
@@ -3100,6 +3125,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // stage, so the seeds are computed under the tail and the next chain stage starts right behind this one.
     static const bool seed_ahead = !(getenv("CM_SEED_AHEAD") && getenv("CM_SEED_AHEAD")[0] == '0');       // diagnostic: the round-3a order
     std::vector<char> seeded((size_t)n_items, 0);
+    bool pre_seeded = false;
     auto issue_seed = [&](int i, hipStream_t st) -> int {
         const int b = (ctx->item_base + i) & 1;
         // flags (and, for the chain stage behind it, the chain records of set b) are final once that pair stage is done; the main
@@ -3133,6 +3159,17 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
             return issue_seed(i + 1, ctx->stream_s);
         };
         auto late = [&]() -> int { return (seed_ahead && i + 1 < n_items && !seeded[(size_t)i + 1]) ? issue_seed(i + 1, ctx->stream_s) : CM_OK; };
+        // The last item has nothing of this batch to seed ahead: the seeds of the NEXT batch's first item instead (the prefetch below
+        // then starts with its chain stage; without this the prefetched chains ended 3.7 ms after the batch's last pair stage and
+        // held up the hand-over).  Seeds only: the chain records they will be chained into are still being read.
+        if (i == n_items - 1 && prefetch && seed_ahead && !pre_seeded) {
+            const Slot &sl0 = ctx->slots[slots[0]];
+            const uint32_t nt0 = (uint32_t)(ctx->st_n_pairs < ctx->tile ? ctx->st_n_pairs : ctx->tile);
+            const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_staged, 0));
+            if ((rc = run_seed_tile(ctx, make_core(ctx, sl0), rd_next, 0, nt0, ctx->d_ones, n_items & 1, ctx->stream_s, nullptr))) return rc;
+            pre_seeded = true;
+        }
         if (use_pre && i == 0) {                                          // set b holds this item's chains, ev_prep[b] is recorded
             if ((rc = ahead())) return rc;
         } else {
@@ -3174,17 +3211,11 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // batch is active), into the set of chain records the running pair stage does not read.  cm_reads_swap keeps the result;
     // the next cm_map_rounds uses it if it starts with the same slot, still holding the same contig.  Condition: the staged
     // batch fits the workspace as it is sized now (nothing may be reallocated under the kernels in flight).
-    static const bool prefetch_on = !(getenv("CM_PREFETCH") && getenv("CM_PREFETCH")[0] == '0');
-    if (prefetch_on && last_is_final && ctx->staged && ctx->st_n_pairs <= ctx->n_pairs && ctx->st_max_len <= ctx->max_len) {
+    if (prefetch) {
         const int b = ctx->item_base;
         const Slot &sl = ctx->slots[slots[0]];
         const KCore core = make_core(ctx, sl);
         const uint32_t nt = (uint32_t)(ctx->st_n_pairs < ctx->tile ? ctx->st_n_pairs : ctx->tile);     // = that batch's first tile (prepare_resident)
-        if (ctx->ones_cap < ctx->st_n_pairs) {
-            HIPCHK(ctx, ensure(ctx, ctx->d_ones, ctx->n_pairs));
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_ones, 1, ctx->n_pairs, ctx->stream));
-            ctx->ones_cap = ctx->n_pairs;
-        }
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
         if ((rc = settle_pair(ctx, b))) return rc;
         if (ctx->pair_pending[b]) {
@@ -3193,7 +3224,10 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         }
         const RoundBufs rbn = round_bufs(ctx, b);
         const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
-        if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return rc;
+        if (pre_seeded) {                                      // seeds are there (or on their way): the classes, into the records now free
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_seed[n_items & 1], 0));
+            if ((rc = seed_classes(ctx, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return rc;
+        } else if ((rc = run_seed_tile(ctx, core, rd_next, 0, nt, ctx->d_ones, n_items & 1, ctx->stream, &rbn))) return rc;
         if ((rc = run_chain_tile(ctx, core, rd_next, 0, nt, sl.chain_parallel_ok, ctx->d_ones, rbn, n_items & 1))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_prep[b], ctx->stream));
         ctx->pre_launched = true;

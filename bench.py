@@ -37,7 +37,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# one context drives five HIP streams at once (cm_map_rounds: the pair stage of a round overlaps the seeding / chaining of the next,
+# one context drives eight HIP streams at once (cm_map_rounds: the pair stage of a round overlaps the seeding / chaining of the next,
 # plus the H2D staging copy); the runtime's default of 4 hardware queues would make two of them share a queue.  Must be set
 # before anything initialises HIP (torch does).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

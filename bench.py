@@ -6,7 +6,7 @@
 
 Default workload = the configuration the metric is quoted on (BASELINE.json configs[2], scaled to one step): an hg38-sized
 synthetic genome (24 chromosomes with hg38's lengths, 3.09 Gbp -> three packed contigs, all resident in HBM, three mapping
-rounds), k = 20, batches of 2^21 2x150 bp pairs = two launch tiles of 2^20 (with two tiles the library walks them round by
+rounds), k = 20, batches of 2^22 2x150 bp pairs = two launch tiles of 2^21 (with two tiles the library walks them round by
 round, so a tile's seeding sees the flags its previous pair stage wrote), eight distinct batches taking turns.
 
 A "step" is one batch through the whole hot path:
@@ -43,6 +43,15 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+def tile_pairs(n):
+    """pairs per launch tile of a batch of n pairs (cm_hot.hip tile_for)"""
+    if os.environ.get("CM_TILE_PAIRS"):
+        return min(n, int(os.environ["CM_TILE_PAIRS"]))
+    if n <= 2 << 20:
+        return min(n, 1 << 20)
+    return min(((n + 1) // 2 + 65535) // 65536 * 65536, 1 << 21)
+
+
 KERNELS = ["k_seed", "k_chain", "k_pair", "k_scan", "k_pair_heavy", "k_classify", "k_chain_heavy"]
 METRIC = "paired reads/sec (whole node), hg38 k=20, 2x150 bp; circ_report bit-exact"
 WORKLOAD_NOTE = {
@@ -268,7 +277,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hg38like", choices=sorted(WORKLOAD_NOTE))
-    ap.add_argument("--pairs", type=int, default=1 << 21, help="pairs per batch (= per step and GPU); the library maps tiles of <= 2^20 pairs")
+    ap.add_argument("--pairs", type=int, default=1 << 22, help="pairs per batch (= per step and GPU); the library maps a batch in tiles of <= 2^21 pairs, "
+                    "two for the default (cm_hot.hip tile_for)")
     ap.add_argument("--seed", type=int, default=38)
     ap.add_argument("--batches", type=int, default=8, help="distinct batches of --pairs pairs that take turns in the timed region (>= 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -486,7 +496,7 @@ def main():
         try:
             with open(args.traffic) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("pairs") == min(args.pairs, 1 << 20) and \
+            if tj.get("workload") == args.workload and tj.get("pairs") == tile_pairs(args.pairs) and \
                     (args.workload != "hg38like" or "dense" in tj.get("preset", "")):                  # pairs per launch (tile); not the r02 genome's
                 traffic = tj.get("bytes_per_launch", {}).get(KERNELS[dom])
                 traffic_src = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/traffic.json), not this run"
@@ -574,8 +584,8 @@ def main():
             eq = bool(gpu_st[:n_s].tobytes() == o_st.tobytes() and (gpu_act[:n_s] == o_act).all())
             out["parity"] = {"pairs": int(n_s), "equal": eq, "rounds": hi.n_contigs,
                              "what": "final cm_mapped_read (72 bytes) + re-queue flag of the first `pairs` pairs of batch 0 after all rounds: "
-                                     "HIP path (staged batch, cm_map_rounds, 2^20-pair tiles) vs the CPU oracle (parity unpinned: the oracle is "
-                                     "pinned by planted truth and its own builders, not by reference output)",
+                                     "HIP path (staged batch, cm_map_rounds, %d-pair tiles) vs the CPU oracle (parity unpinned: the oracle is "
+                                     "pinned by planted truth and its own builders, not by reference output)" % tile_pairs(args.pairs),
                              "bsj_pairs": int(gpu_act[:n_s].sum())}
             if not eq:
                 bad = np.nonzero([gpu_st[i].tobytes() != o_st[i].tobytes() for i in range(n_s)])[0]

@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_hp_tasks(KCore kc, 
 
 // ---- fold ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_fold(KCore kc, uint64_t pair0, const uint32_t *lst, const unsigned int *n_lst_p, const unsigned int *n_heavy_p,
-                                                        int attempt, HPipe P) {
+                                                        int attempt, HPipe P, unsigned long long *counters) {
     const Core c = cmc::to_core(kc);
     const unsigned int n_items = attempt == 0 ? *n_heavy_p : *n_lst_p;
     const unsigned int x = blockIdx.x * BLK_PAIR + threadIdx.x;
@@ -434,6 +434,11 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_fold(KCore kc, uint64_t pair
             g1 = (r1.exons_spos >= 0) || (r1.exons_epos >= 0);
             g2 = (r2.exons_spos >= 0) || (r2.exons_epos >= 0);
         }
+#if defined(CM_HP_DIAG)      // unpaired chains there are (counters[24]) against unpaired chains that get extended (HC_UNP)
+        atomicAdd(&counters[24], (unsigned long long)(__popc(~hp.fp & (hp.nf >= 32 ? 0xffffffffu : ((1u << hp.nf) - 1u))) +
+                                                      __popc(~hp.bp & (hp.nb >= 32 ? 0xffffffffu : ((1u << hp.nb) - 1u)))));
+        atomicAdd(&counters[25], (unsigned long long)(hp.nf + hp.nb));
+#endif
         // does the pair go on to the unpaired-chain extensions? (src/filter.cpp:344-393)
         int a = -1;
         bool do_f = false, do_b = false;

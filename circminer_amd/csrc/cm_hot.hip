@@ -33,7 +33,8 @@ using cmc::KCore;
 namespace {
 
 constexpr int MAX_SLOTS = 16;
-constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (workspace sizing: ~30 KB of HBM per pair)
+constexpr uint32_t TILE_PAIRS = 1u << 20;          // pairs per launch group (workspace sizing: ~46 KB of HBM per pair) ...
+constexpr uint32_t TILE_PAIRS_MAX = 1u << 21;      // ... up to this for batches of more than two such groups (prepare_resident)
 constexpr int BLK = 256;
 constexpr int BLK_CHAIN = 64;
 constexpr int BLK_PAIR = 64;
@@ -2552,6 +2553,24 @@ static int check_reads(cm_ctx *ctx, const cm_reads *rd, int *max_len_out) {
     return CM_OK;
 }
 
+// Pairs per tile (launch group) of a batch of n pairs.
+static uint32_t tile_for(uint64_t n) {
+    // A batch is walked in at least two tiles when it has more than 2^20 pairs (round-major order: a tile's seeding then sees the flags
+    // its previous pair stage wrote), and the tiles are as large as the batch allows up to 2^21: an item costs 1 - 4 ms beyond what
+    // grows with its pairs (tails of the persistent grids, ~40 launches, three host round trips) -- 2^22-pair batches 146.6 ms per step
+    // in four tiles, 139.0 in two; 2^21-pair batches 73 ms in two tiles, 96 in four, 77 in one.
+    uint32_t tile_cap = TILE_PAIRS;
+    if (n > 2ull * TILE_PAIRS) {
+        const uint64_t half = ((n + 1) / 2 + 65535) / 65536 * 65536;
+        tile_cap = (uint32_t)std::min<uint64_t>(half, TILE_PAIRS_MAX);
+    }
+    if (const char *e = getenv("CM_TILE_PAIRS")) {       // tuning knob: pairs per launch group
+        const long v = atol(e);
+        if (v >= 64 && v <= (1l << 24)) tile_cap = (uint32_t)v;
+    }
+    return (uint32_t)(n < tile_cap ? n : tile_cap);
+}
+
 // Per-tile workspace and per-batch state of the batch that is becoming resident (n pairs, longest read max_len).
 static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     ctx->n_seeds = max_len / ctx->P.kmer;
@@ -2561,12 +2580,7 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_active_b, n));
     HIPCHK(ctx, ensure(ctx, ctx->d_cat, n * sizeof(int32_t)));
     // workspace for one tile
-    uint32_t tile_cap = TILE_PAIRS;
-    if (const char *e = getenv("CM_TILE_PAIRS")) {       // tuning knob: pairs per launch group
-        const long v = atol(e);
-        if (v >= 64 && v <= (1l << 24)) tile_cap = (uint32_t)v;
-    }
-    const uint32_t tile = (uint32_t)(n < tile_cap ? n : tile_cap);
+    const uint32_t tile = tile_for(n);
     ctx->tile = tile;
     const size_t nprob = (size_t)tile * 4, nprobe = nprob * (size_t)(ctx->n_seeds ? ctx->n_seeds : 1);
     HIPCHK(ctx, ensure(ctx, ctx->d_sstart, nprobe * 4));
@@ -2996,7 +3010,8 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                 hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 0, str_cap);
                 hipLaunchKernelGGL(k_hp_tasks, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains,
                                    (const int32_t *)rb.nchain, hp, pair_err, str_cap);
-                hipLaunchKernelGGL(k_hp_fold, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp);
+                hipLaunchKernelGGL(k_hp_fold, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
+                                   ctx->d_counters);
                 hipLaunchKernelGGL(k_hp_unp_req, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, str_cap);
                 hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 1, str_cap);
                 hipLaunchKernelGGL(k_hp_unp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, pair_err,
@@ -3164,7 +3179,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         // held up the hand-over).  Seeds only: the chain records they will be chained into are still being read.
         if (i == n_items - 1 && prefetch && seed_ahead && !pre_seeded) {
             const Slot &sl0 = ctx->slots[slots[0]];
-            const uint32_t nt0 = (uint32_t)(ctx->st_n_pairs < ctx->tile ? ctx->st_n_pairs : ctx->tile);
+            const uint32_t nt0 = tile_for(ctx->st_n_pairs);                     // = that batch's first tile (<= this batch's: it has no more pairs)
             const ReadsDev rd_next{ctx->st_seq1_base + cmc::CM_STAGE_PAD, ctx->st_seq2_base + cmc::CM_STAGE_PAD, ctx->st_off1, ctx->st_off2};
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_staged, 0));
             if ((rc = run_seed_tile(ctx, make_core(ctx, sl0), rd_next, 0, nt0, ctx->d_ones, n_items & 1, ctx->stream_s, nullptr))) return rc;
@@ -3215,7 +3230,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         const int b = ctx->item_base;
         const Slot &sl = ctx->slots[slots[0]];
         const KCore core = make_core(ctx, sl);
-        const uint32_t nt = (uint32_t)(ctx->st_n_pairs < ctx->tile ? ctx->st_n_pairs : ctx->tile);     // = that batch's first tile (prepare_resident)
+        const uint32_t nt = tile_for(ctx->st_n_pairs);     // = that batch's first tile (prepare_resident)
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
         if ((rc = settle_pair(ctx, b))) return rc;
         if (ctx->pair_pending[b]) {

@@ -24,6 +24,7 @@ def per_kernel(path, counter):
 
 def main():
     fpath, wpath, out, fsum, wsum = sys.argv[1:6]
+    tile = int(sys.argv[6]) if len(sys.argv) > 6 else 1 << 21          # pairs per launch of the profiled command (bench.py tile_pairs)
     f = per_kernel(fpath, "FETCH_SIZE")
     w = per_kernel(wpath, "WRITE_SIZE")
     for path, d, name in ((fsum, f, "FETCH_SIZE"), (wsum, w, "WRITE_SIZE")):
@@ -39,8 +40,8 @@ def main():
     n_stage = max(detail.get("k_pair", {}).get("launches", 0), 1)
     beside = [k for k in detail if k == "k_pair_heavy" or k.startswith("k_hp_")]
     pair_stage = tot("k_pair") + sum(tot(k) * detail[k]["launches"] for k in beside) / n_stage
-    js = {"workload": "hg38like", "preset": "dense (r03: ~60 000 genes, tiered repeat families)", "pairs": 1 << 20,
-          "note": "FETCH_SIZE/WRITE_SIZE (KB) x 1024 from two separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1`, averaged per launch (one launch = one mapping round of a tile of 2^20 pairs against one packed contig of the hg38-like genome; `pairs` = pairs per launch).  MI355X_MICROARCH.md: FETCH_SIZE under-counts wide coalesced streams by 2x (128-B requests tallied at 64 B) and other access widths are uncalibrated; for this path's pattern (4-16 B random gathers + scratch rows) the r01 calibration against TCC_MISS x 64 B agreed with the counters at face value, so no correction is applied.  Stage entries sum the kernels of a stage (light + heavy; pair stage: k_pair + k_pair_heavy + every k_hp_* launch of the stage).",
+    js = {"workload": "hg38like", "preset": "dense (r03: ~60 000 genes, tiered repeat families)", "pairs": tile,
+          "note": "FETCH_SIZE/WRITE_SIZE (KB) x 1024 from two separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1`, averaged per launch (one launch = one mapping round of a tile of `pairs` pairs against one packed contig of the hg38-like genome; `pairs` = pairs per launch).  MI355X_MICROARCH.md: FETCH_SIZE under-counts wide coalesced streams by 2x (128-B requests tallied at 64 B) and other access widths are uncalibrated; for this path's pattern (4-16 B random gathers + scratch rows) the r01 calibration against TCC_MISS x 64 B agreed with the counters at face value, so no correction is applied.  Stage entries sum the kernels of a stage (light + heavy; pair stage: k_pair + k_pair_heavy + every k_hp_* launch of the stage).",
           "bytes_per_launch": {"k_seed": tot("k_seed"), "k_chain": tot("k_chain") + tot("k_chain_heavy"),
                                "k_pair": pair_stage},
           "detail": detail}

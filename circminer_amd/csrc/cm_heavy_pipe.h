@@ -427,6 +427,11 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_fold(KCore kc, uint64_t pair
             const cmc::MM r1 = o.r1, r2 = o.r2;
             if (cmc::fold_task(c, r1, r2, o.is_left != 0, o.ok != 0, o.row, o.pair_type, r1_fwd, mr)) {
                 early = true;
+#if defined(CM_HP_DIAG)      // tasks the reference's sequential loop would have run (it returns from inside the loop here)
+                atomicAdd(&counters[26], (unsigned long long)(k + 1));
+                atomicAdd(&counters[27], 1ull);
+                if (k == 0) atomicAdd(&counters[28], 1ull);
+#endif
                 break;
             }
             min_ret1 = r1.type < min_ret1 ? r1.type : min_ret1;
@@ -438,6 +443,9 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_fold(KCore kc, uint64_t pair
         atomicAdd(&counters[24], (unsigned long long)(__popc(~hp.fp & (hp.nf >= 32 ? 0xffffffffu : ((1u << hp.nf) - 1u))) +
                                                       __popc(~hp.bp & (hp.nb >= 32 ? 0xffffffffu : ((1u << hp.nb) - 1u)))));
         atomicAdd(&counters[25], (unsigned long long)(hp.nf + hp.nb));
+#endif
+#if defined(CM_HP_DIAG)
+        if (!early) atomicAdd(&counters[26], (unsigned long long)hp.ntask);
 #endif
         // does the pair go on to the unpaired-chain extensions? (src/filter.cpp:344-393)
         int a = -1;

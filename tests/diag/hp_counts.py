@@ -26,4 +26,5 @@ for a in range(2):
     o = [raw[8 + 8 * a + k] for k in range(6)]
     print(f"attempt {a}: pairs {o[0]}, tasks {o[1]}, unpaired chains {o[2]}, DP requests {o[3]} + {o[4]}, fall-backs (cumulative) {o[5]}   (sums over {n} pairs x 3 rounds)")
 print(f"unpaired chains there are {raw[24]} of {raw[25]} chains; extended: see 'unpaired chains' above")
+print(f"tasks a sequential loop would run: {raw[26]}; pairs that end inside the loop (CONCRD): {raw[27]}, at their first task: {raw[28]}")
 hp.close()

@@ -46,6 +46,7 @@ struct HPipe {
     unsigned int *ctr;
     uint32_t tasks_cap, unp_cap;
     unsigned int *fall_ctr;          // entries of fall[] (one list per set of chain records: the fall-back launch may come late, see settle_pair)
+    int8_t *Tcls;                    // work class of T[x] (-2: a hole), the key k_hp_tasks' order is sorted by
 };
 struct HReadsOf {                    // the two reads of a pair in one attempt's orientation
     cmc::g_u8 fseq, bseq;
@@ -246,7 +247,18 @@ __global__ void __launch_bounds__(BLK_PAIR, 6) k_hp_plan(KCore kc, ReadsDev rd, 
             const unsigned int e = list[x];
             const int g = (int)(e >> 12);
             const unsigned long long pos = (unsigned long long)slot_off[g] + (unsigned int)(x - t_lo[g]);
-            if (pos < P.tasks_cap) P.T[pos] = HTask{S[g].done ? 0xffffffffu : slot_h[g], e & 0xFFFu};
+            if (pos < P.tasks_cap) {
+                CM_L const HSlot &sl = S[g];
+                P.T[pos] = HTask{sl.done ? 0xffffffffu : slot_h[g], e & 0xFFFu};
+                // work class: mates in one transcript (exon walks) x the bases the four chain ends leave to extend; results do not depend on it
+                const int idx = (int)(e & 1023u);
+                const int i = (int)(((unsigned int)idx * sl.inv_nb) >> 16), j = idx - i * sl.nb;
+                const cmc::g_chain f = slot_fch(sl, chains) + i, bk = slot_bch(sl, chains) + j;
+                const int fl = (int)f->chain_len, bl = (int)bk->chain_len;
+                const int resid = (int)f->qpos[0] + (sl.flen - ((int)f->qpos[fl - 1] + kmer)) + (int)bk->qpos[0] + (sl.blen - ((int)bk->qpos[bl - 1] + kmer));
+                const int lv = resid <= 0 ? 0 : resid < 16 ? 1 : resid < 32 ? 2 : resid < 64 ? 3 : resid < 96 ? 4 : resid < 128 ? 5 : resid < 192 ? 6 : 7;
+                P.Tcls[pos] = (int8_t)(sl.done ? -2 : ((((e >> 10) & 3u) == 1u ? 8 : 0) + lv));
+            }
         }
         // the four fall-back DP requests of every task (both chains, both ends).  A task whose mates share a transcript walks
         // that first and may never ask (left to compute in place).
@@ -361,7 +373,8 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_dp(KCore kc, ReadsDev rd, ui
 
 // ---- tasks -----------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_hp_tasks(KCore kc, ReadsDev rd, uint64_t pair0, int attempt, const cm_chain *chains,
-                                                                       const int32_t *nchain, HPipe P, uint32_t *pair_err, int str_cap) {
+                                                                       const int32_t *nchain, HPipe P, uint32_t *pair_err, int str_cap,
+                                                                       const uint32_t *order, const unsigned int *n_order) {
     extern __shared__ uint32_t lds_words[];
     const int lane = threadIdx.x;
     CM_S uint8_t *lane_base = (CM_S uint8_t *)lds_words + 4 * lane;
@@ -373,8 +386,11 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_PAIR_WAVES) k_hp_tasks(KCore kc, 
     const unsigned int n_tasks = P.ctr[HC_TASKS] < P.tasks_cap ? P.ctr[HC_TASKS] : P.tasks_cap;
     uint32_t tids[cmc::MAX_TID];
     auto take = [&]() { return (unsigned int)__shfl((int)(lane == 0 ? atomicAdd(&P.ctr[HC_CUR + 1], 64u) : 0u), 0); };
-    for (unsigned int x0 = take(); x0 < n_tasks; x0 = take()) {
-        const unsigned int x = x0 + (unsigned int)lane;
+    const unsigned int n_work = order ? (*n_order < n_tasks ? *n_order : n_tasks) : n_tasks;       // (ordered: the holes are left out)
+    for (unsigned int x0 = take(); x0 < n_work; x0 = take()) {
+        const unsigned int y = x0 + (unsigned int)lane;
+        if (y >= n_work) continue;
+        const unsigned int x = order ? order[y] : y;
         if (x >= n_tasks) continue;
         const HTask tk = P.T[x];
         if (tk.h == 0xffffffffu) continue;

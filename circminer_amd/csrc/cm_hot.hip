@@ -1020,7 +1020,7 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
 __global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t n, unsigned int *blk_cnt, uint32_t nb, const uint32_t *order,
                                                     const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t lim = order ? *n_order : n;
+    const uint32_t lim = n_order ? (*n_order < n || order ? *n_order : n) : n;      // (without an order: a device-side count, at most n)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < CLS_REP; ++j) {
@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(CLS_W) k_cls_place(const int8_t *cls, uint32_t
                                                      const unsigned int *ctr, uint32_t *perm, uint32_t *hlist, const uint32_t *order,
                                                      const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
-    const uint32_t lim = order ? *n_order : n_tile;
+    const uint32_t lim = n_order ? (*n_order < n_tile || order ? *n_order : n_tile) : n_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t t[CLS_REP];
     int k[CLS_REP];
@@ -1750,6 +1750,9 @@ struct cm_ctx {
     HPair *d_hp = nullptr;
     uint32_t *d_hp_list2 = nullptr, *d_hp_fall = nullptr, *d_hp_q = nullptr, *d_hp_q2 = nullptr;
     HTask *d_hp_T = nullptr;
+    int8_t *d_hp_tcls = nullptr;               // work class of every task, the order k_hp_tasks walks them in, the counting sort's scratch
+    uint32_t *d_hp_tperm = nullptr;
+    unsigned int *d_hp_tblk = nullptr, *d_hp_tctr = nullptr;
     HUnp *d_hp_U = nullptr;
     cmc::PreDP *d_hp_pre = nullptr, *d_hp_pre2 = nullptr;
     HRes *d_hp_res = nullptr;
@@ -1844,7 +1847,7 @@ void free_reads(cm_ctx *c) {
     dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b);
     dfree(c, c->d_dpscore); dfree(c, c->d_dpprev); dfree(c, c->d_chains); dfree(c, c->d_nchain); dfree(c, c->d_high);
     dfree(c, c->d_pool); dfree(c, c->d_lane_clk); dfree(c, c->d_cls); dfree(c, c->d_cls4); dfree(c, c->d_perm4); dfree(c, c->d_resid); dfree(c, c->d_perm); dfree(c, c->d_cls_ctr); dfree(c, c->d_cls_ctr2); dfree(c, c->d_cls_sub); dfree(c, c->d_perm1); dfree(c, c->d_cls_ctr3); dfree(c, c->d_cls_sub2); dfree(c, c->d_perm0); dfree(c, c->d_blk_cnt); dfree(c, c->d_hlist); dfree(c, c->d_hres);
-    dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_fallctr); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_U);
+    dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_fallctr); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_tcls); dfree(c, c->d_hp_tperm); dfree(c, c->d_hp_tblk); dfree(c, c->d_hp_tctr); dfree(c, c->d_hp_U);
     dfree(c, c->d_hp_pre); dfree(c, c->d_hp_pre2); dfree(c, c->d_hp_res); dfree(c, c->d_hp_lists); dfree(c, c->d_hp_ctr);
     dfree(c, c->d_pair_err); dfree(c, c->d_retry_list); dfree(c, c->d_spill); dfree(c, c->d_type_hist); dfree(c, c->d_retry_ctr); dfree(c, c->d_heavy_load);
     dfree(c, c->d_col_cls); dfree(c, c->d_col_perm); dfree(c, c->d_col_blk); dfree(c, c->d_col_ctr);
@@ -2638,6 +2641,10 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_fall, (size_t)tile * 4 * 2));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_fallctr, 2 * sizeof(unsigned int)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_T, tc * sizeof(HTask)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_tcls, tc));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_tperm, tc * 4));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_tblk, (size_t)N_CLS * (tc / CLS_T + 2) * sizeof(unsigned int)));
+        HIPCHK(ctx, ensure(ctx, ctx->d_hp_tctr, CTR_WORDS * sizeof(unsigned int)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_pre, tc * 4 * sizeof(cmc::PreDP)));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_q, tc * 4 * 4));
         HIPCHK(ctx, ensure(ctx, ctx->d_hp_res, tc * sizeof(HRes)));
@@ -2992,7 +2999,7 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             // the heavy pairs as a pipeline of full-width kernels (cm_heavy_pipe.h); what does not fit its arrays comes back in a
             // fall-back list and goes through k_pair_heavy behind it
             const HPipe hp{ctx->d_hp, ctx->d_hp_list2, ctx->d_hp_fall + (size_t)b * ctx->tile, ctx->d_hp_T, ctx->d_hp_pre, ctx->d_hp_q, ctx->d_hp_res, ctx->d_hp_U, ctx->d_hp_pre2,
-                           ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap, ctx->d_hp_fallctr + b};
+                           ctx->d_hp_q2, ctx->d_hp_ctr, ctx->hp_tasks_cap, ctx->hp_unp_cap, ctx->d_hp_fallctr + b, ctx->d_hp_tcls};
             const unsigned int *n_heavy = cls_ctr + HEAVY_CLS, *n_list2 = ctx->d_hp_ctr + HC_LIST2;
             static const unsigned pipe_grid = getenv("CM_HP_GRID") ? (unsigned)atoi(getenv("CM_HP_GRID")) : 2048u;        // tuning knob: workgroups of the item kernels
             const size_t lds_slots = HG * sizeof(HSlot);
@@ -3001,6 +3008,7 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
             // Two passes (process_read's two attempts), the second over the few pairs whose other orientation has chains at all (k_hp_finish
             // settles the others in place).  CM_HP_ATTEMPTS=1 (diagnostic) sends those pairs whole to the fall-back kernel instead: its
             // long tail over a few hundred heavy pairs costs more than nine short launches (77.9 vs 75.9 ms per step).
+            static const bool task_order = !(getenv("CM_HP_TASK_ORDER") && getenv("CM_HP_TASK_ORDER")[0] == '0');      // diagnostic: tasks in array order
             static const int n_attempts = (getenv("CM_HP_ATTEMPTS") && atoi(getenv("CM_HP_ATTEMPTS")) == 1) ? 1 : 2;
             for (int attempt = 0; attempt < n_attempts; ++attempt) {
                 if (attempt) hipLaunchKernelGGL(k_hp_reset, dim3(1), dim3(64), 0, sp2, ctx->d_hp_ctr);
@@ -3008,8 +3016,18 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                                    (const uint32_t *)ctx->d_hp_list2, n_list2, attempt, (const cm_chain *)rb.chains, (const int32_t *)rb.nchain,
                                    (const int32_t *)rb.high, (const cm_mapped_read *)ctx->d_state, hp, ctx->d_hp_lists, str_cap);
                 hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 0, str_cap);
+                if (task_order) {       // the tasks by work class, heaviest first (16-class counting sort over the tile's task array)
+                    const uint32_t nbt = (ctx->hp_tasks_cap + CLS_T - 1) / CLS_T;
+                    const unsigned int *n_t = ctx->d_hp_ctr + HC_TASKS;
+                    hipLaunchKernelGGL(k_cls_hist, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
+                                       (const uint32_t *)nullptr, n_t);
+                    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS);
+                    hipLaunchKernelGGL(k_cls_place, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
+                                       ctx->d_hp_tctr, ctx->d_hp_tperm, (uint32_t *)nullptr, (const uint32_t *)nullptr, n_t);
+                }
                 hipLaunchKernelGGL(k_hp_tasks, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains,
-                                   (const int32_t *)rb.nchain, hp, pair_err, str_cap);
+                                   (const int32_t *)rb.nchain, hp, pair_err, str_cap, task_order ? (const uint32_t *)ctx->d_hp_tperm : (const uint32_t *)nullptr,
+                                   (const unsigned int *)(ctx->d_hp_tctr + CTR_SUM));
                 hipLaunchKernelGGL(k_hp_fold, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
                                    ctx->d_counters);
                 hipLaunchKernelGGL(k_hp_unp_req, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains, hp, str_cap);

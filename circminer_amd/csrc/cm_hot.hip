@@ -1672,6 +1672,7 @@ struct cm_ctx {
     hipEvent_t ev_seed[2] = {nullptr, nullptr};       // seeds + cell offsets of a seed set are complete
     hipEvent_t ev_first[2] = {nullptr, nullptr};      // an item's two pair kernels are done (set b): its re-run may start
     hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
+    hipEvent_t ev_flags = nullptr;            // main stream: the pair stage two items back is complete (its flags may be read: early seeding)
     bool pair_pending[2] = {false, false};
     // cross-batch prefetch (cm_map_rounds): the staged batch's first round seeded and chained under this batch's last pair stage
     int item_base = 0;                        // items (tile x round) mapped so far: item i uses chain-record set (item_base + i) & 1
@@ -2234,6 +2235,7 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_pair[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pair[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_retired, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -2298,7 +2300,7 @@ void cm_destroy(cm_ctx *ctx) {
     dfree(ctx, ctx->d_err);
     dfree(ctx, ctx->d_counters);
     if (ctx->h_pin) report_hip(ctx, "hipHostFree", hipHostFree(ctx->h_pin));
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail,
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail, ctx->ev_flags,
                          ctx->ev_first[0], ctx->ev_first[1], ctx->ev_order[0], ctx->ev_order[1], ctx->ev_seed[0], ctx->ev_seed[1], ctx->ev_staged, ctx->ev_retired})
         if (e) report_hip(ctx, "hipEventDestroy", hipEventDestroy(e));
     for (hipStream_t st : {ctx->stream_p3, ctx->stream_o, ctx->stream_s, ctx->stream_p, ctx->stream_p2, ctx->stream_copy})
@@ -3115,6 +3117,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_p, ctx->ev_tail, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_tail, 0));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_o, ctx->ev_tail, 0));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));
     uint8_t *A[2] = {ctx->d_active, ctx->d_active_b};      // A[0] = flags before the first of these rounds
     // The work items: (tile, round).  One tile per batch: its rounds in order.  Several tiles: ROUND-major -- every tile through
     // round r, then every tile through round r + 1 -- so that between the pair stage of (tile, r) and the seeding of (tile, r + 1)
@@ -3157,8 +3160,19 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // launched: it needs the flags of the pair stage of item i - 1 (two tiles; earlier with more), which ends during that chain
     // stage, so the seeds are computed under the tail and the next chain stage starts right behind this one.
     static const bool seed_ahead = !(getenv("CM_SEED_AHEAD") && getenv("CM_SEED_AHEAD")[0] == '0');       // diagnostic: the round-3a order
-    std::vector<char> seeded((size_t)n_items, 0);
+    std::vector<char> seeded((size_t)n_items, 0), early((size_t)n_items, 0);
     bool pre_seeded = false;
+    // With three or more tiles the flags item i + 1 reads were written by the pair stage of item i - 2 or earlier, complete before the
+    // chain stage of item i starts: the seeds (not their classes, which go into chain records item i - 1's pair stage still reads) are
+    // then computed under that chain stage instead of behind the pair stage of item i - 1.  Two tiles: seeding + chaining (8 + 14 ms at
+    // 2^21 pairs) sat between the end of one pair stage and the start of the next but one, longer than the pair stage between them.
+    const bool early_ok = round_major && n_tiles >= 3 && !(getenv("CM_SEED_EARLY") && getenv("CM_SEED_EARLY")[0] == '0');
+    auto issue_seed_early = [&](int i) -> int {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_flags, 0));
+        const int e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, ctx->stream_s, nullptr);
+        early[(size_t)i] = 1;
+        return e;
+    };
     auto issue_seed = [&](int i, hipStream_t st) -> int {
         const int b = (ctx->item_base + i) & 1;
         // flags (and, for the chain stage behind it, the chain records of set b) are final once that pair stage is done; the main
@@ -3167,7 +3181,11 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         if ((e = settle_pair(ctx, b))) return e;
         if (ctx->pair_pending[b]) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_pair[b], 0));
         const RoundBufs rbi = round_bufs(ctx, b);
-        e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
+        if (early[(size_t)i]) {                                       // the seeds are there or on their way: the classes
+            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_seed[i & 1], 0));
+            e = seed_classes(ctx, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
+            if (!e) HIPCHK(ctx, hipEventRecord(ctx->ev_seed[i & 1], st));
+        } else e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
         seeded[(size_t)i] = 1;
         return e;
     };
@@ -3184,6 +3202,10 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         // (stream_o) -- would be issued late: then the seeding is issued behind this item's pair stage instead (`late`).
         auto ahead = [&]() -> int {
             if (!seed_ahead || i + 1 >= n_items || seeded[(size_t)i + 1]) return CM_OK;
+            if (early_ok && !early[(size_t)i + 1]) {
+                const int e = issue_seed_early(i + 1);
+                if (e) return e;
+            }
             const int bn = (ctx->item_base + i + 1) & 1;
             if (ctx->rerun[bn].deferred && hipEventQuery(ctx->ev_first[bn]) != hipSuccess) {
                 (void)hipGetLastError();                                  // not ready
@@ -3212,6 +3234,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pair[b], 0));
                 ctx->pair_pending[b] = false;
             }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));      // (pair stage of item i - 2 and everything before it)
             // CM_CHAIN_EXACT=1 (diagnostic, one tile): the chain kernels wait for the pair stage of round r - 1 and use its output
             // flags (chain kernels 8.4 -> 6.7 ms per step, step 24.0 -> 25.1 ms: the wait costs more than the work it saves)
             static const bool exact_flags = getenv("CM_CHAIN_EXACT") && getenv("CM_CHAIN_EXACT")[0] == '1';

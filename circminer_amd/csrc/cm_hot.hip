@@ -1021,6 +1021,7 @@ __global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t 
                                                     const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t lim = n_order ? (*n_order < n || order ? *n_order : n) : n;      // (without an order: a device-side count, at most n)
+    if (!order && n_order && blockIdx.x * (uint32_t)CLS_T >= lim) return;           // (... and k_cls_scan is told the same count: nothing to report)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < CLS_REP; ++j) {
@@ -1039,7 +1040,9 @@ __global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t 
 }
 // ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
 // (highest class first); the classes in the bit mask `separate` (none: -1) go to their own lists instead
-__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used) {
+// n_dev (optional): the elements there are, on the device; only the blocks that hold some are scanned (rows keep their stride nb)
+__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used,
+                                                   const unsigned int *n_dev = nullptr) {
     // one wave per class row: 64 block counts per step, exclusive scan inside the wave, running total carried on
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
@@ -1049,15 +1052,20 @@ __global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32
     if (c < n_used) {                                    // classes >= n_used are not produced by this caller
         unsigned int *row = blk_cnt + (size_t)c * nb;
         unsigned int run = 0;
-        for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
+        uint32_t nb_eff = nb;
+        if (n_dev) {
+            const uint32_t used = (uint32_t)(((unsigned long long)*n_dev + CLS_T - 1) / CLS_T);
+            nb_eff = used < nb ? used : nb;
+        }
+        for (uint32_t i0 = 0; i0 < nb_eff; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
-            const unsigned int x = i < nb ? row[i] : 0u;
+            const unsigned int x = i < nb_eff ? row[i] : 0u;
             unsigned int incl = x;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
-            if (i < nb) row[i] = run + incl - x;
+            if (i < nb_eff) row[i] = run + incl - x;
             run += __shfl(incl, 63);
         }
         if (lane == 0) tot[c] = run;
@@ -1082,6 +1090,7 @@ __global__ void __launch_bounds__(CLS_W) k_cls_place(const int8_t *cls, uint32_t
                                                      const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t lim = n_order ? (*n_order < n_tile || order ? *n_order : n_tile) : n_tile;
+    if (!order && n_order && blockIdx.x * (uint32_t)CLS_T >= lim) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t t[CLS_REP];
     int k[CLS_REP];
@@ -3023,7 +3032,7 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                     const unsigned int *n_t = ctx->d_hp_ctr + HC_TASKS;
                     hipLaunchKernelGGL(k_cls_hist, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        (const uint32_t *)nullptr, n_t);
-                    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS);
+                    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS, n_t);
                     hipLaunchKernelGGL(k_cls_place, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        ctx->d_hp_tctr, ctx->d_hp_tperm, (uint32_t *)nullptr, (const uint32_t *)nullptr, n_t);
                 }

@@ -1040,23 +1040,26 @@ __global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t 
 }
 // ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
 // (highest class first); the classes in the bit mask `separate` (none: -1) go to their own lists instead
-// n_dev (optional): the elements there are, on the device; only the blocks that hold some are scanned (rows keep their stride nb)
-__global__ void __launch_bounds__(1024) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used,
-                                                   const unsigned int *n_dev = nullptr) {
-    // one wave per class row: 64 block counts per step, exclusive scan inside the wave, running total carried on
+// n_dev (optional): the elements there are, on the device; only the blocks that hold some are scanned (rows keep their stride nb).
+// One workgroup of four waves, four class rows each (a 1024-thread workgroup waited 0.1 - 3 ms for sixteen free wave slots on one CU).
+constexpr int SCAN_CLS_T = 256;
+__global__ void __launch_bounds__(SCAN_CLS_T) k_cls_scan(unsigned int *blk_cnt, uint32_t nb, unsigned int *ctr, int separate, int n_used,
+                                                         const unsigned int *n_dev = nullptr) {
+    // one wave per class row at a time: 64 block counts per step, exclusive scan inside the wave, running total carried on
     __shared__ unsigned int tot[N_CLS];
     const uint32_t t = threadIdx.x;
-    const int lane = (int)(t & 63u), c = (int)(t >> 6);        // 16 waves = N_CLS rows
+    const int lane = (int)(t & 63u), wave = (int)(t >> 6);
     if (t < N_CLS) tot[t] = 0;
     __syncthreads();
-    if (c < n_used) {                                    // classes >= n_used are not produced by this caller
+    uint32_t nb_eff = nb;
+    if (n_dev) {
+        const uint32_t used = (uint32_t)(((unsigned long long)*n_dev + CLS_T - 1) / CLS_T);
+        nb_eff = used < nb ? used : nb;
+    }
+    for (int c = wave; c < N_CLS; c += SCAN_CLS_T / 64) {
+        if (c >= n_used) break;                          // classes >= n_used are not produced by this caller
         unsigned int *row = blk_cnt + (size_t)c * nb;
         unsigned int run = 0;
-        uint32_t nb_eff = nb;
-        if (n_dev) {
-            const uint32_t used = (uint32_t)(((unsigned long long)*n_dev + CLS_T - 1) / CLS_T);
-            nb_eff = used < nb ? used : nb;
-        }
         for (uint32_t i0 = 0; i0 < nb_eff; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             const unsigned int x = i < nb_eff ? row[i] : 0u;
@@ -1979,7 +1982,7 @@ static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint
                        chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
                        (const unsigned int *)nullptr);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, sb.cctr, sb.perm4,
                        (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
     ctx->launches[5] += 4;
@@ -2954,17 +2957,17 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
         const uint32_t *no_order = nullptr;
         const unsigned int *no_count = nullptr;
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, no_order, no_count);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, -1, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub2, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr3, ctx->d_perm0,
                            (uint32_t *)nullptr, no_order, no_count);
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm0,
                            (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, so, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, -1, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls_sub, nt, ctx->d_blk_cnt, nbk, ctx->d_cls_ctr2, ctx->d_perm1,
                            (uint32_t *)nullptr, (const uint32_t *)ctx->d_perm0, (const unsigned int *)(ctx->d_cls_ctr3 + CTR_SUM));
         hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, (const uint32_t *)ctx->d_perm1,
                            (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, so, ctx->d_blk_cnt, nbk, cls_ctr, 1 << HEAVY_CLS, N_CLS);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, so, ctx->d_blk_cnt, nbk, cls_ctr, 1 << HEAVY_CLS, N_CLS);
         hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, so, ctx->d_cls, nt, ctx->d_blk_cnt, nbk, cls_ctr, perm,
                            hlist, (const uint32_t *)ctx->d_perm1, (const unsigned int *)(ctx->d_cls_ctr2 + CTR_SUM));
         ctx->launches[5] += 10;
@@ -3027,17 +3030,17 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                                    (const uint32_t *)ctx->d_hp_list2, n_list2, attempt, (const cm_chain *)rb.chains, (const int32_t *)rb.nchain,
                                    (const int32_t *)rb.high, (const cm_mapped_read *)ctx->d_state, hp, ctx->d_hp_lists, str_cap);
                 hipLaunchKernelGGL(k_hp_dp, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, hp, 0, str_cap);
-                if (task_order) {       // the tasks by work class, heaviest first (16-class counting sort over the tile's task array)
+                if (task_order && attempt == 0) {       // (the second attempt's handful: array order) the tasks by work class, heaviest first (16-class counting sort over the tile's task array)
                     const uint32_t nbt = (ctx->hp_tasks_cap + CLS_T - 1) / CLS_T;
                     const unsigned int *n_t = ctx->d_hp_ctr + HC_TASKS;
                     hipLaunchKernelGGL(k_cls_hist, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        (const uint32_t *)nullptr, n_t);
-                    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS, n_t);
+                    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS, n_t);
                     hipLaunchKernelGGL(k_cls_place, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        ctx->d_hp_tctr, ctx->d_hp_tperm, (uint32_t *)nullptr, (const uint32_t *)nullptr, n_t);
                 }
                 hipLaunchKernelGGL(k_hp_tasks, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains,
-                                   (const int32_t *)rb.nchain, hp, pair_err, str_cap, task_order ? (const uint32_t *)ctx->d_hp_tperm : (const uint32_t *)nullptr,
+                                   (const int32_t *)rb.nchain, hp, pair_err, str_cap, (task_order && attempt == 0) ? (const uint32_t *)ctx->d_hp_tperm : (const uint32_t *)nullptr,
                                    (const unsigned int *)(ctx->d_hp_tctr + CTR_SUM));
                 hipLaunchKernelGGL(k_hp_fold, dim3(pipe_grid), dim3(BLK_PAIR), 0, sp2, core, p0, (const uint32_t *)ctx->d_hp_list2, n_list2, n_heavy, attempt, hp,
                                    ctx->d_counters);
@@ -3386,7 +3389,7 @@ static int compact_active(cm_ctx *ctx) {
     hipLaunchKernelGGL(k_active_cls, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, ctx->d_active, n, ctx->d_col_cls);
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, (const uint32_t *)nullptr,
                        (const unsigned int *)nullptr);
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, ctx->stream, ctx->d_col_blk, nbk, ctx->d_col_ctr, -1, 1);
     hipLaunchKernelGGL(k_cls_place, dim3(nbk), dim3(CLS_W), 0, ctx->stream, ctx->d_col_cls, (uint32_t)n, ctx->d_col_blk, nbk, ctx->d_col_ctr,
                        ctx->d_col_perm, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr);
     return CM_OK;

@@ -213,7 +213,8 @@ int cm_map_round(cm_ctx *ctx, int slot, int is_last_round);
  * Results are those of n_rounds cm_map_round calls.  What differs is the schedule: seeds and chains of a round depend on the
  * reads and the contig only (the carried MatchedRead enters in the pair stage), so round r + 1 is seeded and chained on the
  * main streams while the pair stage of round r still runs on a second pair of streams; chain buffers and active flags are
- * double-buffered.  Asynchronous like cm_map_round.  A batch of more than 2^20 pairs is mapped in tiles, walked round by round
+ * double-buffered.  Asynchronous like cm_map_round.  A batch of more than 2^20 pairs is mapped in tiles (two of up to 2^21 pairs,
+ * more for batches beyond 2^22; ~46 KB of HBM workspace per pair of a tile), walked round by round
  * (every tile through round r, then every tile through round r + 1), so a tile's seeding sees the flags its previous pair stage
  * wrote and only pairs still active are seeded and chained.
  * Across batches: when last_is_final is set and a batch is staged (cm_reads_stage) that fits the workspace of the resident

@@ -172,6 +172,60 @@ def test_full_size_parity_chr21(tmp_path_factory, n_pairs, seed, kw):
     hp.close()
 
 
+def test_batches_beyond_two_tiles_worth_of_pairs(tmp_path_factory, monkeypatch):
+    """A batch of more than 2^21 pairs is walked in two tiles of half the batch (up to 2^21 pairs each; cm_hot.hip tile_for); with
+    CM_TILE_PAIRS=2^20 the same batch takes three tiles, whose seeds are computed a chain stage early (the flags they read are two
+    items old).  Both walks must give the same bytes, equal the oracle on ranges around every tile boundary, and keep the
+    size-independent properties."""
+    import os
+    import threading
+    import ctypes as C
+    from conftest import DataSet
+    n = (1 << 21) + 200_000
+    ds = DataSet(tmp_path_factory.mktemp("chr21big"), "chr21", n, 91)
+    P = cl.default_params()
+
+    def run():
+        hp = cl.HotPath(P)
+        hp.load_contig(0, ds.hi.views[0], ds.hi.annots[0])
+        hp.upload(ds.batch)
+        hp.map_rounds([0], True)
+        st, cat, act = hp.download()
+        idx = np.array(hp.collect_active()[0], copy=True)       # (the arrays collect_active returns live in the context)
+        st, cat, act = st.copy(), cat.copy(), act.copy()
+        hp.close()
+        return st, cat, act, idx
+
+    st_a, cat_a, act_a, idx_a = run()                       # two tiles of 1 179 648 pairs
+    monkeypatch.setenv("CM_TILE_PAIRS", str(1 << 20))
+    st_b, cat_b, act_b, idx_b = run()                       # three tiles
+    assert st_a.tobytes() == st_b.tobytes() and (cat_a == cat_b).all() and (act_a == act_b).all()
+    assert (act_a == np.isin(st_a["type"], [3, 4])).all()
+    assert (idx_a == np.nonzero(act_a)[0]).all() and (idx_a == idx_b).all()
+    # the oracle on 40 000 pairs around each tile boundary of either walk, and at both ends
+    L = op.load()
+    st0, act0 = op.default_state(P, n)
+    cat0 = np.full(n, -1, np.int32)
+    spans = [(0, 20_000), (1_179_648 - 20_000, 1_179_648 + 20_000), ((1 << 20) - 20_000, (1 << 20) + 20_000), ((1 << 21) - 20_000, (1 << 21) + 20_000),
+             (n - 20_000, n)]
+    T = max(1, min(64, os.cpu_count() or 1))
+    jobs = []
+    for a, b in spans:
+        step = (b - a + T - 1) // T
+        jobs += [(x, min(b, x + step)) for x in range(a, b, step)]
+
+    def work(a, b):
+        L.oracle_map_round(C.byref(P), C.byref(ds.hi.views[0]), C.byref(ds.hi.annots[0]), C.byref(ds.batch.c), 1, st0.ctypes.data,
+                           act0.ctypes.data, cat0.ctypes.data, a, b)
+
+    th = [threading.Thread(target=work, args=j) for j in jobs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for a, b in spans:
+        assert (cat0[a:b] == cat_a[a:b]).all() and (act0[a:b] == act_a[a:b]).all()
+        assert st0[a:b].tobytes() == st_a[a:b].tobytes(), first_diff(st0[a:b], st_a[a:b])
+
+
 def test_config5_stress_params(tmp_path_factory):
     """BASELINE.json configs[4] flags on a small genome: k=22 --seed-lim 1000 --max-ed 8 --scan-lev 2."""
     from conftest import DataSet

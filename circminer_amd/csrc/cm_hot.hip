@@ -1021,21 +1021,26 @@ __global__ void __launch_bounds__(CLS_W) k_cls_hist(const int8_t *cls, uint32_t 
                                                     const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t lim = n_order ? (*n_order < n || order ? *n_order : n) : n;      // (without an order: a device-side count, at most n)
-    if (!order && n_order && blockIdx.x * (uint32_t)CLS_T >= lim) return;           // (... and k_cls_scan is told the same count: nothing to report)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // a workgroup takes the stretches of CLS_T elements blockIdx.x, blockIdx.x + gridDim.x, ... (one each when the grid has nb
+    // workgroups; a smaller grid when the count is only known on the device and most of nb would have nothing to do)
+    for (uint32_t vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+        if (!order && n_order && vb * (uint32_t)CLS_T >= lim) break;                 // (k_cls_scan is told the same count: nothing to report)
 #pragma unroll
-    for (int j = 0; j < CLS_REP; ++j) {
-        const int vw = wave * CLS_REP + j;                 // stretch of 64 elements within the block
-        const uint32_t i = blockIdx.x * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
-        const int k = i < lim ? (int)cls[order ? order[i] : i] : -2;
-        unsigned int r;
-        block_class_ranks(k, wcnt, r, lane, vw);
-    }
-    __syncthreads();
-    if (threadIdx.x < N_CLS) {
-        unsigned int tot = 0;
-        for (int w = 0; w < CLS_T / 64; ++w) tot += wcnt[w][threadIdx.x];
-        blk_cnt[(size_t)threadIdx.x * nb + blockIdx.x] = tot;
+        for (int j = 0; j < CLS_REP; ++j) {
+            const int vw = wave * CLS_REP + j;                 // stretch of 64 elements within the block
+            const uint32_t i = vb * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
+            const int k = i < lim ? (int)cls[order ? order[i] : i] : -2;
+            unsigned int r;
+            block_class_ranks(k, wcnt, r, lane, vw);
+        }
+        __syncthreads();
+        if (threadIdx.x < N_CLS) {
+            unsigned int tot = 0;
+            for (int w = 0; w < CLS_T / 64; ++w) tot += wcnt[w][threadIdx.x];
+            blk_cnt[(size_t)threadIdx.x * nb + vb] = tot;
+        }
+        __syncthreads();
     }
 }
 // ctr[c] = total of class c, ctr[CTR_SUM] = entries placed in perm[], ctr[CTR_BASE + c] = base offset of class c in perm[]
@@ -1093,29 +1098,32 @@ __global__ void __launch_bounds__(CLS_W) k_cls_place(const int8_t *cls, uint32_t
                                                      const unsigned int *n_order) {
     __shared__ unsigned int wcnt[CLS_T / 64][N_CLS];
     const uint32_t lim = n_order ? (*n_order < n_tile || order ? *n_order : n_tile) : n_tile;
-    if (!order && n_order && blockIdx.x * (uint32_t)CLS_T >= lim) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t t[CLS_REP];
-    int k[CLS_REP];
-    unsigned int r[CLS_REP];
+    for (uint32_t vb = blockIdx.x; vb < nb; vb += gridDim.x) {                       // (see k_cls_hist)
+        if (!order && n_order && vb * (uint32_t)CLS_T >= lim) break;
+        uint32_t t[CLS_REP];
+        int k[CLS_REP];
+        unsigned int r[CLS_REP];
 #pragma unroll
-    for (int j = 0; j < CLS_REP; ++j) {
-        const int vw = wave * CLS_REP + j;
-        const uint32_t i = blockIdx.x * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
-        t[j] = i < lim ? (order ? order[i] : i) : 0u;
-        k[j] = i < lim ? (int)cls[t[j]] : -2;
-        block_class_ranks(k[j], wcnt, r[j], lane, vw);
-    }
-    __syncthreads();
+        for (int j = 0; j < CLS_REP; ++j) {
+            const int vw = wave * CLS_REP + j;
+            const uint32_t i = vb * CLS_T + (uint32_t)vw * 64u + (uint32_t)lane;
+            t[j] = i < lim ? (order ? order[i] : i) : 0u;
+            k[j] = i < lim ? (int)cls[t[j]] : -2;
+            block_class_ranks(k[j], wcnt, r[j], lane, vw);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < CLS_REP; ++j) {
-        if (k[j] < 0) continue;
-        const int vw = wave * CLS_REP + j;
-        unsigned int before = 0;
-        for (int w = 0; w < vw; ++w) before += wcnt[w][k[j]];
-        const unsigned int pos = blk_base[(size_t)k[j] * nb + blockIdx.x] + before + r[j];
-        if (k[j] == HEAVY_CLS && hlist) hlist[pos] = t[j];
-        else perm[ctr[CTR_BASE + k[j]] + pos] = t[j];
+        for (int j = 0; j < CLS_REP; ++j) {
+            if (k[j] < 0) continue;
+            const int vw = wave * CLS_REP + j;
+            unsigned int before = 0;
+            for (int w = 0; w < vw; ++w) before += wcnt[w][k[j]];
+            const unsigned int pos = blk_base[(size_t)k[j] * nb + vb] + before + r[j];
+            if (k[j] == HEAVY_CLS && hlist) hlist[pos] = t[j];
+            else perm[ctr[CTR_BASE + k[j]] + pos] = t[j];
+        }
+        __syncthreads();
     }
 }
 
@@ -3033,10 +3041,11 @@ static int run_pair_tile(cm_ctx *ctx, const KCore &core, uint64_t p0, uint32_t n
                 if (task_order && attempt == 0) {       // (the second attempt's handful: array order) the tasks by work class, heaviest first (16-class counting sort over the tile's task array)
                     const uint32_t nbt = (ctx->hp_tasks_cap + CLS_T - 1) / CLS_T;
                     const unsigned int *n_t = ctx->d_hp_ctr + HC_TASKS;
-                    hipLaunchKernelGGL(k_cls_hist, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
+                    const uint32_t gt = std::min<uint32_t>(nbt, 2048u);        // (the count is on the device: a grid that walks the stretches in use)
+                    hipLaunchKernelGGL(k_cls_hist, dim3(gt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        (const uint32_t *)nullptr, n_t);
                     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, sp2, ctx->d_hp_tblk, nbt, ctx->d_hp_tctr, -1, N_CLS, n_t);
-                    hipLaunchKernelGGL(k_cls_place, dim3(nbt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
+                    hipLaunchKernelGGL(k_cls_place, dim3(gt), dim3(CLS_W), 0, sp2, (const int8_t *)ctx->d_hp_tcls, ctx->hp_tasks_cap, ctx->d_hp_tblk, nbt,
                                        ctx->d_hp_tctr, ctx->d_hp_tperm, (uint32_t *)nullptr, (const uint32_t *)nullptr, n_t);
                 }
                 hipLaunchKernelGGL(k_hp_tasks, dim3(pipe_grid), dim3(BLK_PAIR), lds_bytes, sp2, core, rd, p0, attempt, (const cm_chain *)rb.chains,

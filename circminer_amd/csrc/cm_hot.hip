@@ -2559,9 +2559,14 @@ static int check_reads(cm_ctx *ctx, const cm_reads *rd, int *max_len_out) {
     } else {
         uint64_t bd[8] = {0}, lg[8] = {0};
         std::thread th[8];
-        for (unsigned k = 1; k < n_thr; ++k) th[k] = std::thread(scan, n * k / n_thr, n * (k + 1) / n_thr, &bd[k], &lg[k]);
+        unsigned started = 1;
+        try {
+            for (; started < n_thr; ++started) th[started] = std::thread(scan, n * started / n_thr, n * (started + 1) / n_thr, &bd[started], &lg[started]);
+        } catch (...) {                                   // no more threads to be had: the rest of the ranges on this one
+        }
         scan(0, n / n_thr, &bd[0], &lg[0]);
-        for (unsigned k = 1; k < n_thr; ++k) th[k].join();
+        for (unsigned k = started; k < n_thr; ++k) scan(n * k / n_thr, n * (k + 1) / n_thr, &bd[k], &lg[k]);
+        for (unsigned k = 1; k < started; ++k) th[k].join();
         for (unsigned k = 0; k < n_thr; ++k) {
             if (bd[k] && !bad) bad = bd[k];                   // the first offending pair
             if (lg[k] > longest) longest = lg[k];

@@ -608,7 +608,10 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
     for (unsigned int y = x; y < n_items; y += gridDim.x * BLK_PAIR) {
         const uint32_t h = attempt == 0 ? y : lst[y];
         HPair &hp = P.hp[h];
-        if (hp.over) continue;
+        if (hp.over) {                                     // goes through the fall-back launch, which may come late: active until then
+            if (attempt == 0) active[pair0 + hp.t] = 1;
+            continue;
+        }
         cm_mapped_read mr = hp.mr;
         int st = hp.st;
         if (st < 0) {                                  // the attempt ran: its verdict (the tail of process_mates + process_read's loop)
@@ -640,6 +643,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
                     st = (c.P.scan_level == 0 && mr.type == CM_CONCRD) ? CM_CONCRD : mr.type;
                 } else if (second_to_fall) {           // the few others: whole, by the fall-back kernel behind the pipeline
                     P.fall[atomicAdd(P.fall_ctr, 1u)] = hp.t;
+                    active[pair0 + hp.t] = 1;
                     continue;
                 } else {
                     hp.mr = mr;
@@ -653,6 +657,7 @@ __global__ void __launch_bounds__(BLK_PAIR, 8) k_hp_finish(KCore kc, uint64_t pa
         const uint64_t p = pair0 + t;
         if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             ra.list[atomicAdd(ra.count, 1u)] = t;          // left as it was; the re-run launch of k_pair maps it (one lane, exact)
+            active[p] = 1;                                 // (its flag: active until then)
         } else {
             uint8_t act = 1;
             cmc::finish_round(c, st, is_last, hp.len1, hp.len2, mr, act);

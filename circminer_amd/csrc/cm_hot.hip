@@ -305,6 +305,7 @@ __device__ __forceinline__ void pair_kernel(const KCore &kc, const ReadsDev &rd,
     if (FIRST) {
         if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             ra.list[atomicAdd(ra.count, 1u)] = t;
+            active[pair0 + t] = 1;          // until the re-run writes its flag: counted as active (the next item's seeds may be computed before that)
             keep = false;
         }
     } else ra.pair_err[t] = 0u;
@@ -986,10 +987,14 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
                                                   const uint8_t *active, uint64_t pair0) {
     const uint32_t r = blockIdx.x * BLK + threadIdx.x;
     if (r >= n_prob) return;
+    // nchain == null: the chain records are still being read by an earlier pair stage; `high` is a scratch array of the seed set and
+    // k_chain_apply carries the three fields over when the records are free (the class -2 stands for "no chain, no kernel visits it")
     if (!active[pair0 + (r >> 2)]) {    // seeded under older flags (a superset), retired since: no chains wanted
         high[r] = 0;
-        nchain[r] = 0;
-        resid[r] = 0;
+        if (nchain) {
+            nchain[r] = 0;
+            resid[r] = 0;
+        }
         cls[r] = -2;
         return;
     }
@@ -1002,7 +1007,7 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
         if (sraw[(uint64_t)r * S + s] > 0 && c == 0) ++hh;       // get_best_chains high_hits (also for problems k_chain skips)
     }
     high[r] = hh;
-    if (suffix == 0) {                  // no retained hit: no chain, and no kernel visits this problem
+    if (suffix == 0 && nchain) {        // no retained hit: no chain, and no kernel visits this problem
         nchain[r] = 0;
         resid[r] = 0;
     }
@@ -1014,6 +1019,15 @@ __global__ void __launch_bounds__(BLK) k_chain_cls(const uint32_t *scnt, const u
                       : light ? (n <= 3 ? 0 : n <= 6 ? 1 : n <= 7 ? 2 : n <= 9 ? 3 : n <= 12 ? 4 : n <= 16 ? 5 : n <= 24 ? 6 : n <= 32 ? 7 : n <= 48 ? 8 : n <= 64 ? 9
                                  : n <= 96 ? 10 : 11)
                       : w <= 4096 ? 12 : w <= 65536 ? 13 : w <= 1048576 ? 14 : 15);
+}
+__global__ void __launch_bounds__(BLK) k_chain_apply(uint32_t n_prob, const int8_t *cls, const int32_t *thigh, int32_t *high, int32_t *nchain, uint16_t *resid) {
+    const uint32_t r = blockIdx.x * BLK + threadIdx.x;
+    if (r >= n_prob) return;
+    high[r] = thigh[r];
+    if (cls[r] == -2) {
+        nchain[r] = 0;
+        resid[r] = 0;
+    }
 }
 // `order` (optional): visit the elements in this order (second pass of an LSD radix sort: order = the permutation of the
 // first pass, *n_order entries); the element at position i is order[i]
@@ -1471,6 +1485,7 @@ __global__ void __launch_bounds__(BLK_PAIR, CM_HEAVY_WAVES) k_pair_heavy(KCore k
             if (st < 0) st = mr.type;
             if (__hip_atomic_load(ra.pair_err + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 ra.list[atomicAdd(ra.count, 1u)] = t;          // left as it was; the re-run launch of k_pair maps it (one lane, exact)
+                active[p] = 1;                                 // (its flag: active until then)
             } else {
                 uint8_t act = 1;
                 cmc::finish_round(c, st, is_last, len1, len2, mr, act);
@@ -1737,6 +1752,8 @@ struct cm_ctx {
     unsigned int *d_bmax_b = nullptr;
     unsigned int *d_cctr_b = nullptr, *d_cblk_b = nullptr;
     int8_t *d_cls4_b = nullptr;
+    int32_t *d_thigh = nullptr, *d_thigh_b = nullptr;
+    bool cls_deferred[2] = {false, false};      // seed set s: classes made before the chain records were free, k_chain_apply still to run
     uint32_t *d_perm4_b = nullptr;
     double *d_dpscore = nullptr;
     int32_t *d_dpprev = nullptr;
@@ -1865,7 +1882,7 @@ void free_reads(cm_ctx *c) {
     dfree(c, c->d_chains_b); dfree(c, c->d_nchain_b); dfree(c, c->d_high_b); dfree(c, c->d_resid_b); dfree(c, c->d_cctr); dfree(c, c->d_cblk);
     dfree(c, c->d_sstart); dfree(c, c->d_scnt); dfree(c, c->d_sraw); dfree(c, c->d_cells); dfree(c, c->d_celloff); dfree(c, c->d_bsum); dfree(c, c->d_bmax);
     dfree(c, c->d_sstart_b); dfree(c, c->d_scnt_b); dfree(c, c->d_sraw_b); dfree(c, c->d_celloff_b); dfree(c, c->d_bsum_b); dfree(c, c->d_bmax_b);
-    dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b);
+    dfree(c, c->d_cctr_b); dfree(c, c->d_cblk_b); dfree(c, c->d_cls4_b); dfree(c, c->d_perm4_b); dfree(c, c->d_thigh); dfree(c, c->d_thigh_b);
     dfree(c, c->d_dpscore); dfree(c, c->d_dpprev); dfree(c, c->d_chains); dfree(c, c->d_nchain); dfree(c, c->d_high);
     dfree(c, c->d_pool); dfree(c, c->d_lane_clk); dfree(c, c->d_cls); dfree(c, c->d_cls4); dfree(c, c->d_perm4); dfree(c, c->d_resid); dfree(c, c->d_perm); dfree(c, c->d_cls_ctr); dfree(c, c->d_cls_ctr2); dfree(c, c->d_cls_sub); dfree(c, c->d_perm1); dfree(c, c->d_cls_ctr3); dfree(c, c->d_cls_sub2); dfree(c, c->d_perm0); dfree(c, c->d_blk_cnt); dfree(c, c->d_hlist); dfree(c, c->d_hres);
     dfree(c, c->d_hp); dfree(c, c->d_hp_list2); dfree(c, c->d_hp_fall); dfree(c, c->d_hp_fallctr); dfree(c, c->d_hp_q); dfree(c, c->d_hp_q2); dfree(c, c->d_hp_T); dfree(c, c->d_hp_tcls); dfree(c, c->d_hp_tperm); dfree(c, c->d_hp_tblk); dfree(c, c->d_hp_tctr); dfree(c, c->d_hp_U);
@@ -1949,11 +1966,12 @@ struct SeedBufs {
     unsigned int *cblk, *cctr;
     uint32_t *perm4;
     unsigned long long *pool_cursor;
+    int32_t *thigh;              // high_hits per problem while the chain records are not free yet (k_chain_apply)
 };
 SeedBufs seed_bufs(cm_ctx *c, int s) {
     return s ? SeedBufs{c->d_sstart_b, c->d_scnt_b, c->d_sraw_b, c->d_celloff_b, c->d_bsum_b, c->d_bmax_b, c->d_cls4_b, c->d_cblk_b, c->d_cctr_b, c->d_perm4_b,
-                        c->d_pool_cursor + 1}
-             : SeedBufs{c->d_sstart, c->d_scnt, c->d_sraw, c->d_celloff, c->d_bsum, c->d_bmax, c->d_cls4, c->d_cblk, c->d_cctr, c->d_perm4, c->d_pool_cursor};
+                        c->d_pool_cursor + 1, c->d_thigh_b}
+             : SeedBufs{c->d_sstart, c->d_scnt, c->d_sraw, c->d_celloff, c->d_bsum, c->d_bmax, c->d_cls4, c->d_cblk, c->d_cctr, c->d_perm4, c->d_pool_cursor, c->d_thigh};
 }
 constexpr unsigned HP_PLAN_GRID = 2048;      // workgroups of k_hp_plan (each with its own task-list scratch)
 // CM_HEAVY_PIPELINE=0: the heavy pairs of a tile through k_pair_heavy alone (the round-3 path)
@@ -1976,7 +1994,7 @@ static unsigned int chain_light_cells() {
 // The second half of run_seed_tile: the work classes + sorted lists of the chaining problems of seed set s, the per-problem counters of
 // the chain records rb and the zeroed cursors.  (On its own when the seeds were computed before the chain records were free: the
 // cross-batch prefetch.)
-static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st, const RoundBufs *rb) {
+static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st, const RoundBufs *rb, bool defer = false) {
     const int S = ctx->n_seeds;
     const uint32_t n_prob = n_tile * 4u;
     if ((uint64_t)n_prob * (uint64_t)S == 0) return CM_OK;
@@ -1986,8 +2004,11 @@ static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint
     // behind the persistent pair kernels of the previous item, took 6 ms of the chain stage's critical path.)
     Timer t(ctx, 5, st);
     const uint32_t nbk = (n_prob + CLS_T - 1) / CLS_T;
-    hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, rb->high,
-                       chain_light_w(), chain_light_cells(), rb->nchain, rb->resid, act, pair0);
+    // defer: the chain records rb are still read by an earlier pair stage -- nothing is written into them here, run_chain_tile does that
+    // (k_chain_apply) when it is ordered behind that stage
+    hipLaunchKernelGGL(k_chain_cls, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, st, sb.scnt, sb.sraw, S, n_prob, sb.cls4, defer ? sb.thigh : rb->high,
+                       chain_light_w(), chain_light_cells(), defer ? (int32_t *)nullptr : rb->nchain, defer ? (uint16_t *)nullptr : rb->resid, act, pair0);
+    ctx->cls_deferred[s] = defer;
     hipLaunchKernelGGL(k_cls_hist, dim3(nbk), dim3(CLS_W), 0, st, sb.cls4, n_prob, sb.cblk, nbk, (const uint32_t *)nullptr,
                        (const unsigned int *)nullptr);
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(SCAN_CLS_T), 0, st, sb.cblk, nbk, sb.cctr, -1, N_CLS);
@@ -2000,7 +2021,7 @@ static int seed_classes(cm_ctx *ctx, uint64_t pair0, uint32_t n_tile, const uint
     return CM_OK;
 }
 int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t pair0, uint32_t n_tile, const uint8_t *act, int s, hipStream_t st,
-                  const RoundBufs *rb) {
+                  const RoundBufs *rb, bool defer_rb = false) {
     const int S = ctx->n_seeds;
     const uint64_t total = (uint64_t)n_tile * 4u * (uint64_t)S;
     if (total == 0) return CM_OK;
@@ -2022,7 +2043,7 @@ int run_seed_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t p
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + 8 + 2 * s, sb.celloff + n_prob, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (rb) {
-        const int rc = seed_classes(ctx, pair0, n_tile, act, s, st, rb);
+        const int rc = seed_classes(ctx, pair0, n_tile, act, s, st, rb, defer_rb);
         if (rc) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_seed[s], st));
@@ -2040,6 +2061,11 @@ int run_chain_tile(cm_ctx *ctx, const KCore &core, const ReadsDev &rd, uint64_t 
     const SeedBufs sb = seed_bufs(ctx, s);
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_seed[s], 0));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev_seed[s]));
+    if (ctx->cls_deferred[s]) {           // classes made while the chain records were in use (the caller has ordered this stream behind that)
+        hipLaunchKernelGGL(k_chain_apply, dim3((n_prob + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, n_prob, (const int8_t *)sb.cls4, (const int32_t *)sb.thigh,
+                           rb.high, rb.nchain, rb.resid);
+        ctx->cls_deferred[s] = false;
+    }
     const unsigned long long total = ctx->h_pin[8 + 2 * s];
     const unsigned long long max_cells = ctx->h_pin[9 + 2 * s];       // of one problem
     // problem ranges whose DP cells fit the workspace
@@ -2650,6 +2676,8 @@ static int prepare_resident(cm_ctx *ctx, uint64_t n, int max_len) {
     HIPCHK(ctx, ensure(ctx, ctx->d_cctr_b, CTR_WORDS * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cblk_b, (size_t)N_CLS * (4 * (size_t)tile / CLS_T + 2) * sizeof(unsigned int)));
     HIPCHK(ctx, ensure(ctx, ctx->d_cls4_b, (size_t)tile * 4));
+    HIPCHK(ctx, ensure(ctx, ctx->d_thigh, (size_t)tile * 4 * sizeof(int32_t)));
+    HIPCHK(ctx, ensure(ctx, ctx->d_thigh_b, (size_t)tile * 4 * sizeof(int32_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm4_b, (size_t)tile * 4 * 4));
     HIPCHK(ctx, ensure(ctx, ctx->d_resid, (size_t)tile * 4 * sizeof(uint16_t)));
     HIPCHK(ctx, ensure(ctx, ctx->d_perm, (size_t)tile * 4 * 2));          // x 2: one per set of chain records, like the re-run list (run_pair_tile)
@@ -3192,11 +3220,21 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // chain stage of item i starts: the seeds (not their classes, which go into chain records item i - 1's pair stage still reads) are
     // then computed under that chain stage instead of behind the pair stage of item i - 1.  Two tiles: seeding + chaining (8 + 14 ms at
     // 2^21 pairs) sat between the end of one pair stage and the start of the next but one, longer than the pair stage between them.
-    const bool early_ok = round_major && n_tiles >= 3 && !(getenv("CM_SEED_EARLY") && getenv("CM_SEED_EARLY")[0] == '0');
+    // Two tiles: the flags are the ones the pair kernels of item i - 1 write, and the host cannot issue anything when those end -- it
+    // sits in the wait for the chain stage of item i, which ends later: the seeding of item i + 1 started when THAT was over, and the
+    // chip idled for 5 - 6 ms of every 22-ms item with nothing but the tail of k_chain_heavy on it.  The seeds are queued on the device
+    // behind ev_first of that pair stage instead (its kernels and the heavy pairs' pipeline; a pair left to a late launch -- re-run,
+    // fall-back -- counts as active until that launch writes its flag, a superset, and the classes below use the final flags).
+    const bool early_ok = round_major && n_tiles >= 2 && !(getenv("CM_SEED_EARLY") && getenv("CM_SEED_EARLY")[0] == '0');
     auto issue_seed_early = [&](int i) -> int {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_flags, 0));
-        const int e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, ctx->stream_s, nullptr);
+        if (n_tiles == 2 && i >= 2) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_s, ctx->ev_first[(ctx->item_base + i) & 1], 0));
+        // the whole seed stage: the classes too, into scratch of the seed set (the chain records they belong in are still being read;
+        // run_chain_tile carries them over).  Under superset flags a pair the late launches retire gets chains nobody looks at.
+        const RoundBufs rbe = round_bufs(ctx, (ctx->item_base + i) & 1);
+        const int e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, ctx->stream_s, &rbe, true);
         early[(size_t)i] = 1;
+        seeded[(size_t)i] = 1;
         return e;
     };
     auto issue_seed = [&](int i, hipStream_t st) -> int {
@@ -3228,10 +3266,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         // (stream_o) -- would be issued late: then the seeding is issued behind this item's pair stage instead (`late`).
         auto ahead = [&]() -> int {
             if (!seed_ahead || i + 1 >= n_items || seeded[(size_t)i + 1]) return CM_OK;
-            if (early_ok && !early[(size_t)i + 1]) {
-                const int e = issue_seed_early(i + 1);
-                if (e) return e;
-            }
+            if (early_ok) return issue_seed_early(i + 1);      // queued on the device behind what it depends on: nothing left for later
             const int bn = (ctx->item_base + i + 1) & 1;
             if (ctx->rerun[bn].deferred && hipEventQuery(ctx->ev_first[bn]) != hipSuccess) {
                 (void)hipGetLastError();                                  // not ready
@@ -3351,6 +3386,7 @@ int cm_map_rounds(cm_ctx *ctx, const int *slots, int n_rounds, int last_is_final
     (void)hipStreamSynchronize(ctx->stream_p3);
     (void)hipStreamSynchronize(ctx->stream_s);
     ctx->rerun[0].deferred = ctx->rerun[1].deferred = false;
+    ctx->cls_deferred[0] = ctx->cls_deferred[1] = false;
     ctx->item_base = (ctx->item_base + items_done) & 1;
     if (rounds_done & 1) std::swap(ctx->d_active, ctx->d_active_b);
     ctx->pair_pending[0] = ctx->pair_pending[1] = false;

@@ -1706,7 +1706,7 @@ struct cm_ctx {
     hipStream_t stream_s = nullptr;           // seeding of the NEXT item, issued while the chain stage of this one runs (map_rounds_issue)
     hipEvent_t ev_seed[2] = {nullptr, nullptr};       // seeds + cell offsets of a seed set are complete
     hipEvent_t ev_first[2] = {nullptr, nullptr};      // an item's two pair kernels are done (set b): its re-run may start
-    hipEvent_t ev_fork_p = nullptr, ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
+    hipEvent_t ev_join_p = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_pair[2] = {nullptr, nullptr}, ev_tail = nullptr;
     hipEvent_t ev_flags = nullptr;            // main stream: the pair stage two items back is complete (its flags may be read: early seeding)
     bool pair_pending[2] = {false, false};
     // cross-batch prefetch (cm_map_rounds): the staged batch's first round seeded and chained under this batch's last pair stage
@@ -2274,7 +2274,6 @@ int cm_create(const cm_params *p, cm_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_seed[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_first[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_first[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork_p, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join_p, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep[1], hipEventDisableTiming) != hipSuccess ||
@@ -2346,7 +2345,7 @@ void cm_destroy(cm_ctx *ctx) {
     dfree(ctx, ctx->d_err);
     dfree(ctx, ctx->d_counters);
     if (ctx->h_pin) report_hip(ctx, "hipHostFree", hipHostFree(ctx->h_pin));
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_fork_p, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail, ctx->ev_flags,
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_join_p, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_pair[0], ctx->ev_pair[1], ctx->ev_tail, ctx->ev_flags,
                          ctx->ev_first[0], ctx->ev_first[1], ctx->ev_order[0], ctx->ev_order[1], ctx->ev_seed[0], ctx->ev_seed[1], ctx->ev_staged, ctx->ev_retired})
         if (e) report_hip(ctx, "hipEventDestroy", hipEventDestroy(e));
     for (hipStream_t st : {ctx->stream_p3, ctx->stream_o, ctx->stream_s, ctx->stream_p, ctx->stream_p2, ctx->stream_copy})
@@ -3214,7 +3213,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
     // launched: it needs the flags of the pair stage of item i - 1 (two tiles; earlier with more), which ends during that chain
     // stage, so the seeds are computed under the tail and the next chain stage starts right behind this one.
     static const bool seed_ahead = !(getenv("CM_SEED_AHEAD") && getenv("CM_SEED_AHEAD")[0] == '0');       // diagnostic: the round-3a order
-    std::vector<char> seeded((size_t)n_items, 0), early((size_t)n_items, 0);
+    std::vector<char> seeded((size_t)n_items, 0);
     bool pre_seeded = false;
     // With three or more tiles the flags item i + 1 reads were written by the pair stage of item i - 2 or earlier, complete before the
     // chain stage of item i starts: the seeds (not their classes, which go into chain records item i - 1's pair stage still reads) are
@@ -3233,7 +3232,6 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         // run_chain_tile carries them over).  Under superset flags a pair the late launches retire gets chains nobody looks at.
         const RoundBufs rbe = round_bufs(ctx, (ctx->item_base + i) & 1);
         const int e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, ctx->stream_s, &rbe, true);
-        early[(size_t)i] = 1;
         seeded[(size_t)i] = 1;
         return e;
     };
@@ -3245,11 +3243,7 @@ static int map_rounds_issue(cm_ctx *ctx, const int *slots, int n_rounds, int las
         if ((e = settle_pair(ctx, b))) return e;
         if (ctx->pair_pending[b]) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_pair[b], 0));
         const RoundBufs rbi = round_bufs(ctx, b);
-        if (early[(size_t)i]) {                                       // the seeds are there or on their way: the classes
-            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_seed[i & 1], 0));
-            e = seed_classes(ctx, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
-            if (!e) HIPCHK(ctx, hipEventRecord(ctx->ev_seed[i & 1], st));
-        } else e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
+        e = run_seed_tile(ctx, make_core(ctx, ctx->slots[slots[items[i].r]]), rd_cur, items[i].p0, items[i].nt, prep_flags(i), i & 1, st, &rbi);
         seeded[(size_t)i] = 1;
         return e;
     };
